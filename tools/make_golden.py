@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE model on CPU.
+
+Build-container only: imports /root/reference/phase1_lifting/baselineModel.py
+(read-only, never copied) and records inputs + the reference's outputs as data.
+The reference source does not travel; these vectors do.
+
+Weights come from oracle.lifter_oracle.init_state(np.random.default_rng(seed))
+so that full-size (17 MB) weight sets need not be committed: a fixture stores
+the seed recipe, the inputs and what the reference computed from them.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+warnings.filterwarnings("ignore")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/phase1_lifting")
+sys.dont_write_bytecode = True
+
+import torch  # noqa: E402
+
+import baselineModel as ref  # noqa: E402  (the reference, imported as-is)
+from oracle import lifter_oracle as orc  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def h36m_stats():
+    d = "/root/reference/phase1_lifting"
+    return {k: np.load(f"{d}/{k}.npy").astype(np.float32)
+            for k in ("mean_train_2d", "std_train_2d", "mean_train_3d", "std_train_3d")}
+
+
+def synth_batch(rng, B, stats):
+    """H3.6M-shaped synthetic batch: x2d ~ N(mean2d, std2d) clipped to [0,1];
+    y3d ~ N(0, std3d) root-relative metres with the root row zeroed."""
+    x = rng.standard_normal((B, 17, 2)).astype(np.float32) * stats["std_train_2d"] + stats["mean_train_2d"]
+    x = np.clip(x, 0.0, 1.0).astype(np.float32)
+    y = rng.standard_normal((B, 17, 3)).astype(np.float32) * stats["std_train_3d"]
+    y[:, 0, :] = 0
+    return x, y.astype(np.float32)
+
+
+def load_into(model, st):
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in st.items()}
+    model.load_state_dict(sd, strict=True)
+
+
+def state_of(model):
+    return {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+
+
+def grads_of(model):
+    return {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters()
+            if p.grad is not None}
+
+
+def capture_masks(model):
+    """Record the keep mask of every nn.Dropout call in call order."""
+    masks, handles = [], []
+
+    def hook(_m, inp, out):
+        masks.append((out != 0).cpu().numpy())
+
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout):
+            handles.append(m.register_forward_hook(hook))
+    return masks, handles
+
+
+def sample_idx(rng, n, k=1024):
+    return np.sort(rng.choice(n, size=min(k, n), replace=False)).astype(np.int64)
+
+
+def main():
+    stats = h36m_stats()
+    np.savez(os.path.join(OUT, "h36m_stats.npz"), **stats)
+
+    # ---- G1/G6: eval forward, full size, non-trivial BN state --------------------------
+    cfg = dict(in_dim=34, out_dim=51, hidden=1024, num_stage=2)
+    st = orc.init_state(**cfg, rng=np.random.default_rng(101), nontrivial_bn=True)
+    m = ref.LinearModel(34, 51, linear_size=1024, num_stage=2, p_dropout=0.5, BN=True)
+    load_into(m, st)
+    m.eval()
+    x, _ = synth_batch(np.random.default_rng(102), 64, stats)
+    with torch.no_grad():
+        y = m(torch.from_numpy(x)).numpy()
+        y64 = m.double()(torch.from_numpy(x).double()).numpy()
+    np.savez(os.path.join(OUT, "g1_eval_full.npz"), weight_seed=101, x=x, y=y, y_fp64=y64,
+             hidden=1024, num_stage=2)
+
+    # ---- G2: train fwd+bwd, p_dropout = 0 ----------------------------------------------
+    for tag, hidden, S, B, bn in (("small", 64, 2, 32, True), ("full", 1024, 2, 128, True),
+                                  ("nobn", 64, 2, 32, False), ("s3", 32, 3, 16, True)):
+        seed = {"small": 201, "full": 202, "nobn": 203, "s3": 204}[tag]
+        st = orc.init_state(34, 51, hidden, S, rng=np.random.default_rng(seed), nontrivial_bn=bn)
+        m = ref.LinearModel(34, 51, linear_size=hidden, num_stage=S, p_dropout=0.0, BN=bn)
+        load_into(m, st)
+        m.train()
+        rng = np.random.default_rng(seed + 1000)
+        x, t = synth_batch(rng, B, stats)
+        xt = torch.from_numpy(x).requires_grad_(True)
+        pred = m(xt).reshape(B, 17, 3)
+        loss = torch.nn.MSELoss(reduction="mean")(pred, torch.from_numpy(t))
+        loss.backward()
+        g = grads_of(m)
+        after = state_of(m)
+        rec = dict(weight_seed=seed, hidden=hidden, num_stage=S, bn=int(bn), x=x, t=t,
+                   pred=pred.detach().numpy(), loss=np.float32(loss.item()),
+                   dx=xt.grad.numpy())
+        if tag == "full":
+            for k, v in g.items():
+                flat = v.reshape(-1)
+                idx = sample_idx(rng, flat.size)
+                rec["gidx:" + k] = idx
+                rec["gval:" + k] = flat[idx]
+                rec["gnorm:" + k] = np.float64(np.linalg.norm(flat.astype(np.float64)))
+            for k, v in after.items():
+                if "running" in k or "num_batches" in k:
+                    rec["after:" + k] = v
+        else:
+            for k, v in st.items():
+                rec["state:" + k] = v
+            for k, v in g.items():
+                rec["grad:" + k] = v
+            for k, v in after.items():
+                if "running" in k or "num_batches" in k:
+                    rec["after:" + k] = v
+        np.savez_compressed(os.path.join(OUT, f"g2_train_nodrop_{tag}.npz"), **rec)
+
+    # ---- G3: train fwd+bwd with the reference's own dropout masks captured ------------
+    st = orc.init_state(34, 51, 64, 2, rng=np.random.default_rng(301), nontrivial_bn=True)
+    m = ref.LinearModel(34, 51, linear_size=64, num_stage=2, p_dropout=0.5, BN=True)
+    load_into(m, st)
+    m.train()
+    torch.manual_seed(7)
+    masks, handles = capture_masks(m)
+    x, t = synth_batch(np.random.default_rng(1301), 32, stats)
+    pred = m(torch.from_numpy(x)).reshape(32, 17, 3)
+    loss = torch.nn.MSELoss(reduction="mean")(pred, torch.from_numpy(t))
+    loss.backward()
+    for h in handles:
+        h.remove()
+    rec = dict(weight_seed=301, hidden=64, num_stage=2, bn=1, x=x, t=t, pred=pred.detach().numpy(),
+               loss=np.float32(loss.item()), masks=np.stack(masks))
+    for k, v in st.items():
+        rec["state:" + k] = v
+    for k, v in grads_of(m).items():
+        rec["grad:" + k] = v
+    np.savez_compressed(os.path.join(OUT, "g3_train_masks_small.npz"), **rec)
+
+    # ---- G4: three AdamW steps (p_dropout = 0) -----------------------------------------
+    st = orc.init_state(34, 51, 64, 2, rng=np.random.default_rng(401))
+    m = ref.LinearModel(34, 51, linear_size=64, num_stage=2, p_dropout=0.0, BN=True)
+    load_into(m, st)
+    m.train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4)          # train_1.py:39 (wd default 0.01)
+    rng = np.random.default_rng(1401)
+    xs, ts, losses = [], [], []
+    for _ in range(3):
+        x, t = synth_batch(rng, 32, stats)
+        opt.zero_grad()
+        pred = m(torch.from_numpy(x)).reshape(32, 17, 3)
+        loss = torch.nn.MSELoss(reduction="mean")(pred, torch.from_numpy(t))
+        loss.backward()
+        opt.step()
+        xs.append(x), ts.append(t), losses.append(loss.item())
+    rec = dict(weight_seed=401, hidden=64, num_stage=2, xs=np.stack(xs), ts=np.stack(ts),
+               losses=np.array(losses, np.float32), lr=1e-4, wd=0.01)
+    for k, v in st.items():
+        rec["state:" + k] = v
+    for k, v in state_of(m).items():
+        rec["final:" + k] = v
+    np.savez_compressed(os.path.join(OUT, "g4_adamw_small.npz"), **rec)
+
+    # ---- G5: loss_MPJPE (train_1.py:19-23) + epoch reduction (:100-104) ----------------
+    sys.path.insert(0, ROOT)
+    rng = np.random.default_rng(501)
+    _, a = synth_batch(rng, 48, stats)
+    _, b = synth_batch(rng, 48, stats)
+    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
+    # restated from train_1.py:19-23 with stock torch ops (train_1.py itself needs cv2/wandb)
+    metric = torch.sum(torch.norm(ta - tb, dim=-1), dim=0)
+    epoch = torch.mean((metric / 48)[1:17]) * (17 / 16) * 1000
+    np.savez(os.path.join(OUT, "g5_mpjpe.npz"), pred=a, tgt=b, metric=metric.numpy(),
+             epoch_mm=np.float64(epoch.item()))
+
+    # ---- G7: weight_init (baselineModel.py:10-12) leaves biases/BN alone ---------------
+    # (recorded as a property, not as values: kaiming_normal consumes the torch RNG)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
