@@ -1,0 +1,10 @@
+"""MI355X-native 2D->3D pose-lifting train path (the hot path of RHnejad/3D_PoseEstimation).
+
+Import as `importlib.import_module("3d_poseestimation_amd")` or through the `poselift`
+alias module at the repository root.
+"""
+from ._lib import PoseliftError, lib  # noqa: F401
+from .model import Linear, LinearModel, weight_init  # noqa: F401
+from .optim import FlatAdamW  # noqa: F401
+from .train import epoch_mpjpe_mm, eval_step, loss_MPJPE, mse_loss, train_step  # noqa: F401
+from . import dp, layout, synth  # noqa: F401

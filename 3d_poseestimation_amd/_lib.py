@@ -1,0 +1,97 @@
+"""ctypes binding of libposelift.so (include/poselift.h).
+
+The library is the product: there is no CPU or eager-torch fallback.  If the shared
+object is missing, or an entry point reports an error, this module raises.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (loads torch's bundled HIP runtime first so the library binds to it)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libposelift.so")
+
+PL_F32, PL_BF16 = 0, 1
+
+
+class PLDesc(ctypes.Structure):
+    _fields_ = [
+        ("in_dim", ctypes.c_int32), ("hidden", ctypes.c_int32), ("out_dim", ctypes.c_int32),
+        ("num_stage", ctypes.c_int32), ("bn", ctypes.c_int32), ("dtype", ctypes.c_int32),
+        ("p_dropout", ctypes.c_float), ("bn_eps", ctypes.c_float), ("bn_momentum", ctypes.c_float),
+        ("reserved", ctypes.c_int32),
+        ("params", ctypes.c_void_p), ("bn_running", ctypes.c_void_p), ("bn_batches", ctypes.c_void_p),
+    ]
+
+
+_c = ctypes
+_P = ctypes.c_void_p
+_D = ctypes.POINTER(PLDesc)
+# name -> (restype, argtypes); one entry per declaration in include/poselift.h
+SIGNATURES = {
+    "pl_version": (_c.c_int, []),
+    "pl_last_error": (_c.c_char_p, []),
+    "pl_num_hidden": (_c.c_int64, [_D]),
+    "pl_param_tensors": (_c.c_int64, [_D]),
+    "pl_param_offset": (_c.c_int64, [_D, _c.c_int64]),
+    "pl_param_numel": (_c.c_int64, [_D, _c.c_int64]),
+    "pl_param_arena_floats": (_c.c_int64, [_D]),
+    "pl_workspace_bytes": (_c.c_size_t, [_D, _c.c_int64]),
+    "pl_workspace_view": (_c.c_int, [_D, _c.c_int64, _c.c_int, _c.c_int64,
+                                     _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_size_t)]),
+    "pl_lifter_fwd_eval": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _P]),
+    "pl_lifter_fwd_train": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _c.c_uint64,
+                                       _c.c_uint64, _P, _P]),
+    "pl_lifter_bwd": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _P, _P, _P]),
+    "pl_mse_scratch_bytes": (_c.c_size_t, [_c.c_int64]),
+    "pl_mse_fwd_bwd": (_c.c_int, [_P, _P, _c.c_int64, _c.c_float, _P, _P, _P, _P]),
+    "pl_mpjpe_scratch_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64]),
+    "pl_mpjpe_accum": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P, _P]),
+    "pl_adamw_flat": (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_float, _c.c_float, _c.c_float,
+                                 _c.c_float, _c.c_float, _c.c_int64, _c.c_float, _P]),
+    "pl_gemm_f32": (_c.c_int, [_c.c_int, _P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P,
+                               _c.c_int, _P, _P]),
+}
+
+_lib = None
+
+
+class PoseliftError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PoseliftError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError if the symbol is missing
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().pl_last_error().decode("utf-8", "replace")
+        raise PoseliftError(f"{what} failed (status {rc}): {msg}")
+
+
+def current_stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device_tensor(t, name, dtype=torch.float32):
+    if not t.is_cuda:
+        raise PoseliftError(
+            f"{name} is on {t.device}: the lifter runs on an MI355X (ROCm) device only; "
+            "there is no CPU path")
+    if t.dtype != dtype:
+        raise PoseliftError(f"{name} has dtype {t.dtype}, expected {dtype}")
+    if not t.is_contiguous():
+        raise PoseliftError(f"{name} must be contiguous")

@@ -1,0 +1,407 @@
+// C ABI of libposelift.so: arena layout, workspace plan and the forward / backward
+// launch sequences of the lifter (include/poselift.h).  Host code only; every kernel
+// lives in gemm_f32.hip / elementwise.hip.
+//
+// Layer numbering used everywhere: hidden layer 0 is LinearModel.w1/batch_norm1
+// (baselineModel.py:67-68,90-94); residual block s owns hidden layers 1+2s (its w1) and
+// 2+2s (its w2) (baselineModel.py:23-27,33-45); "final" is LinearModel.w2 (:77,100).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <vector>
+
+#include "pl_internal.h"
+
+namespace pl {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+namespace {
+
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+int check_desc(const PLDesc* d, bool need_arenas) {
+  if (!d) PL_FAIL(PL_EINVAL, "descriptor is NULL");
+  if (d->in_dim <= 0 || d->out_dim <= 0 || d->hidden <= 0 || d->num_stage < 0)
+    PL_FAIL(PL_ESHAPE, "bad dims in=%d hidden=%d out=%d stages=%d", d->in_dim, d->hidden, d->out_dim, d->num_stage);
+  if (d->hidden % 4 != 0) PL_FAIL(PL_ESHAPE, "hidden=%d must be a multiple of 4", d->hidden);
+  if (d->dtype != PL_F32) PL_FAIL(PL_EDTYPE, "dtype %d not built (fp32 MFMA path only in this version)", d->dtype);
+  if (!(d->p_dropout >= 0.f && d->p_dropout <= 1.f)) PL_FAIL(PL_EINVAL, "p_dropout=%f outside [0,1]", d->p_dropout);
+  if (need_arenas) {
+    if (!d->params) PL_FAIL(PL_EINVAL, "params arena is NULL");
+    if (reinterpret_cast<uintptr_t>(d->params) & 15) PL_FAIL(PL_EINVAL, "params arena not 16-byte aligned");
+    if (d->bn && !d->bn_running) PL_FAIL(PL_EINVAL, "bn_running arena is NULL");
+  }
+  return PL_OK;
+}
+
+struct ParamLayout {
+  int L;                       // hidden layers
+  std::vector<int64_t> off, numel;
+  int64_t total;
+};
+
+ParamLayout param_layout(const PLDesc* d) {
+  ParamLayout p;
+  p.L = 1 + 2 * d->num_stage;
+  int64_t o = 0;
+  auto add = [&](int64_t n) {
+    p.off.push_back(o);
+    p.numel.push_back(n);
+    o = align_up(o + n, 64);
+  };
+  for (int l = 0; l < p.L; ++l) {
+    const int64_t fan_in = l == 0 ? d->in_dim : d->hidden;
+    add((int64_t)d->hidden * fan_in);
+    add(d->hidden);
+    add(d->hidden);
+    add(d->hidden);
+  }
+  add((int64_t)d->out_dim * d->hidden);
+  add(d->out_dim);
+  p.total = o;
+  return p;
+}
+
+int tn_splits(int M, int N, int K) {
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int s = 256 / tiles;
+  const int kmax = (K + 127) / 128;
+  if (s > kmax) s = kmax;
+  return s < 1 ? 1 : s;
+}
+
+// Workspace plan; every region starts on a 256-byte boundary.
+struct Ws {
+  int L, G, RC;
+  std::vector<size_t> z, act, bits, mean, rstd, dbpart;
+  size_t stat_a, stat_b, scale, shift, coef, ga, gb, dz, slabs, outpart, total;
+  size_t act_bytes, bits_bytes;
+};
+
+Ws plan(const PLDesc* d, int64_t B) {
+  Ws w;
+  w.L = 1 + 2 * d->num_stage;
+  const int H = d->hidden;
+  w.G = gemm_stat_groups((int)B);
+  w.RC = bwd_row_chunks((int)B);
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = o;
+    o = (size_t)align_up((int64_t)(o + bytes), 256);
+    return at;
+  };
+  w.act_bytes = (size_t)B * H * sizeof(float);
+  w.bits_bytes = (size_t)B * bitmap_words_per_row(H) * sizeof(uint64_t);
+  for (int l = 0; l < w.L; ++l) {
+    w.z.push_back(take(w.act_bytes));
+    w.act.push_back(take(w.act_bytes));
+    w.bits.push_back(take(w.bits_bytes));
+    w.mean.push_back(take((size_t)H * 4));
+    w.rstd.push_back(take((size_t)H * 4));
+    w.dbpart.push_back(take((size_t)w.RC * H * 4));
+  }
+  const size_t part = (size_t)std::max(w.G, w.RC) * H * 4;
+  w.stat_a = take(part);
+  w.stat_b = take(part);
+  w.scale = take((size_t)w.L * H * 4);
+  w.shift = take((size_t)w.L * H * 4);
+  w.coef = take((size_t)3 * H * 4);
+  w.ga = take(w.act_bytes);
+  w.gb = take(w.act_bytes);
+  w.dz = take(w.act_bytes);
+  size_t slab = 0;
+  auto need = [&](int M, int N) {
+    const int s = tn_splits(M, N, (int)B);
+    if (s > 1) slab = std::max(slab, (size_t)s * M * N * 4);
+  };
+  need(H, d->in_dim);
+  need(H, H);
+  need(d->out_dim, H);
+  w.slabs = take(slab);
+  w.outpart = take((size_t)colsum_chunks((int)B) * d->out_dim * 4);
+  w.total = o;
+  return w;
+}
+
+struct Layer {
+  const float *W, *b, *gamma, *beta;
+  float *gW, *gb, *ggamma, *gbeta;
+  float *rm, *rv;
+  int64_t* nbt;
+  int K;
+};
+
+Layer layer_of(const PLDesc* d, const ParamLayout& pl_, float* grads, int l) {
+  Layer y;
+  const int H = d->hidden;
+  y.K = l == 0 ? d->in_dim : H;
+  y.W = d->params + pl_.off[4 * l];
+  y.b = d->params + pl_.off[4 * l + 1];
+  y.gamma = d->params + pl_.off[4 * l + 2];
+  y.beta = d->params + pl_.off[4 * l + 3];
+  y.gW = grads ? grads + pl_.off[4 * l] : nullptr;
+  y.gb = grads ? grads + pl_.off[4 * l + 1] : nullptr;
+  y.ggamma = grads ? grads + pl_.off[4 * l + 2] : nullptr;
+  y.gbeta = grads ? grads + pl_.off[4 * l + 3] : nullptr;
+  y.rm = d->bn_running ? d->bn_running + (size_t)l * 2 * H : nullptr;
+  y.rv = d->bn_running ? d->bn_running + (size_t)l * 2 * H + H : nullptr;
+  y.nbt = d->bn_batches ? d->bn_batches + l : nullptr;
+  return y;
+}
+
+inline float* f32(void* ws, size_t off) { return reinterpret_cast<float*>(static_cast<char*>(ws) + off); }
+inline uint64_t* u64(void* ws, size_t off) { return reinterpret_cast<uint64_t*>(static_cast<char*>(ws) + off); }
+
+int check_ws(const Ws& w, void* ws, size_t bytes) {
+  if (!ws) PL_FAIL(PL_EWORKSPACE, "workspace is NULL");
+  if (reinterpret_cast<uintptr_t>(ws) & 255) PL_FAIL(PL_EWORKSPACE, "workspace not 256-byte aligned");
+  if (bytes < w.total) PL_FAIL(PL_EWORKSPACE, "workspace too small: %zu < %zu bytes", bytes, w.total);
+  return PL_OK;
+}
+
+// C[M][N] (+slab reduce) = A^T B with A [K][M], B [K][N]
+int gemm_tn_reduced(const float* A, int lda, const float* Bm, int ldb, float* C, int M, int N, int K,
+                    float* slabs, hipStream_t s) {
+  GemmArgs g = {};
+  g.A = A; g.B = Bm; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = N;
+  const int splits = tn_splits(M, N, K);
+  if (splits > 1) {
+    g.C = slabs; g.split_k = splits;
+    PL_TRY(launch_gemm_f32(kTN, g, s));
+    return launch_reduce_slabs(slabs, splits, (int64_t)M * N, C, s);
+  }
+  g.C = C; g.split_k = 1;
+  return launch_gemm_f32(kTN, g, s);
+}
+
+}  // namespace
+}  // namespace pl
+
+using namespace pl;
+
+extern "C" int pl_version(void) { return PL_VERSION; }
+extern "C" const char* pl_last_error(void) { return g_err; }
+
+extern "C" int64_t pl_num_hidden(const PLDesc* d) { return d ? 1 + 2 * (int64_t)d->num_stage : PL_EINVAL; }
+extern "C" int64_t pl_param_tensors(const PLDesc* d) { return d ? 4 * (1 + 2 * (int64_t)d->num_stage) + 2 : PL_EINVAL; }
+extern "C" int64_t pl_param_offset(const PLDesc* d, int64_t i) {
+  if (check_desc(d, false) != PL_OK) return PL_EINVAL;
+  const ParamLayout p = param_layout(d);
+  if (i < 0 || i >= (int64_t)p.off.size()) { set_error("tensor index %lld out of range", (long long)i); return PL_EINVAL; }
+  return p.off[i];
+}
+extern "C" int64_t pl_param_numel(const PLDesc* d, int64_t i) {
+  if (check_desc(d, false) != PL_OK) return PL_EINVAL;
+  const ParamLayout p = param_layout(d);
+  if (i < 0 || i >= (int64_t)p.numel.size()) { set_error("tensor index %lld out of range", (long long)i); return PL_EINVAL; }
+  return p.numel[i];
+}
+extern "C" int64_t pl_param_arena_floats(const PLDesc* d) {
+  if (check_desc(d, false) != PL_OK) return PL_EINVAL;
+  return param_layout(d).total;
+}
+
+extern "C" size_t pl_workspace_bytes(const PLDesc* d, int64_t B) {
+  if (check_desc(d, false) != PL_OK || B <= 0) return 0;
+  return plan(d, B).total;
+}
+
+extern "C" int pl_workspace_view(const PLDesc* d, int64_t B, int which, int64_t layer, size_t* off,
+                                 size_t* size) {
+  PL_TRY(check_desc(d, false));
+  if (B <= 0 || !off || !size) PL_FAIL(PL_EINVAL, "pl_workspace_view: bad arguments");
+  const Ws w = plan(d, B);
+  if (layer < 0 || layer >= w.L) PL_FAIL(PL_EINVAL, "pl_workspace_view: layer %lld out of range", (long long)layer);
+  const size_t hb = (size_t)d->hidden * 4;
+  switch (which) {
+    case 0: *off = w.z[layer]; *size = w.act_bytes; break;
+    case 1: *off = w.act[layer]; *size = w.act_bytes; break;
+    case 2: *off = w.bits[layer]; *size = w.bits_bytes; break;
+    case 3: *off = w.mean[layer]; *size = hb; break;
+    case 4: *off = w.rstd[layer]; *size = hb; break;
+    default: PL_FAIL(PL_EINVAL, "pl_workspace_view: which=%d", which);
+  }
+  return PL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// forward, eval mode
+// ---------------------------------------------------------------------------------------
+extern "C" int pl_lifter_fwd_eval(const PLDesc* d, const float* x, float* y, int64_t B, void* ws,
+                                  size_t ws_bytes, void* stream) {
+  PL_TRY(check_desc(d, true));
+  if (!x || !y) PL_FAIL(PL_EINVAL, "pl_lifter_fwd_eval: null x/y");
+  if (B <= 0) PL_FAIL(PL_ESHAPE, "pl_lifter_fwd_eval: B=%lld", (long long)B);
+  const Ws w = plan(d, B);
+  PL_TRY(check_ws(w, ws, ws_bytes));
+  const ParamLayout P = param_layout(d);
+  hipStream_t s = (hipStream_t)stream;
+  const int H = d->hidden;
+  for (int l = 0; l < w.L; ++l) {
+    const Layer ly = layer_of(d, P, nullptr, l);
+    PL_TRY(launch_bn_fold_eval(ly.b, ly.gamma, ly.beta, ly.rm, ly.rv, d->bn_eps, d->bn, H,
+                               f32(ws, w.scale) + (size_t)l * H, f32(ws, w.shift) + (size_t)l * H, s));
+  }
+  const float* a_in = x;
+  for (int l = 0; l < w.L; ++l) {
+    const Layer ly = layer_of(d, P, nullptr, l);
+    GemmArgs g = {};
+    g.A = a_in; g.B = ly.W; g.C = f32(ws, w.act[l]);
+    g.M = (int)B; g.N = H; g.K = ly.K; g.lda = ly.K; g.ldb = ly.K; g.ldc = H; g.split_k = 1;
+    g.col_scale = f32(ws, w.scale) + (size_t)l * H;
+    g.col_shift = f32(ws, w.shift) + (size_t)l * H;
+    g.relu = 1;
+    if (l >= 2 && (l % 2) == 0) g.resid = f32(ws, w.act[l - 2]);
+    PL_TRY(launch_gemm_f32(kNT, g, s));
+    a_in = g.C;
+  }
+  GemmArgs g = {};
+  g.A = a_in; g.B = d->params + P.off[4 * w.L]; g.C = y; g.bias = d->params + P.off[4 * w.L + 1];
+  g.M = (int)B; g.N = d->out_dim; g.K = H; g.lda = H; g.ldb = H; g.ldc = d->out_dim; g.split_k = 1;
+  return launch_gemm_f32(kNT, g, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// forward, training mode
+// ---------------------------------------------------------------------------------------
+extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, int64_t B, void* ws,
+                                   size_t ws_bytes, uint64_t seed, uint64_t step,
+                                   const uint64_t* inject_keep, void* stream) {
+  PL_TRY(check_desc(d, true));
+  if (!x || !y) PL_FAIL(PL_EINVAL, "pl_lifter_fwd_train: null x/y");
+  if (B <= 0) PL_FAIL(PL_ESHAPE, "pl_lifter_fwd_train: B=%lld", (long long)B);
+  if (d->bn && B < 2)
+    PL_FAIL(PL_EBATCH, "Expected more than 1 value per channel when training (B=%lld)", (long long)B);
+  const Ws w = plan(d, B);
+  PL_TRY(check_ws(w, ws, ws_bytes));
+  const ParamLayout P = param_layout(d);
+  hipStream_t s = (hipStream_t)stream;
+  const int H = d->hidden;
+  const size_t inj_stride = (size_t)B * bitmap_words_per_row(H);
+  const float* a_in = x;
+  for (int l = 0; l < w.L; ++l) {
+    const Layer ly = layer_of(d, P, nullptr, l);
+    GemmArgs g = {};
+    g.A = a_in; g.B = ly.W; g.C = f32(ws, w.z[l]); g.bias = ly.b;
+    g.M = (int)B; g.N = H; g.K = ly.K; g.lda = ly.K; g.ldb = ly.K; g.ldc = H; g.split_k = 1;
+    if (d->bn) { g.stat_sum = f32(ws, w.stat_a); g.stat_m2 = f32(ws, w.stat_b); }
+    PL_TRY(launch_gemm_f32(kNT, g, s));
+    const float *scale = nullptr, *shift = nullptr;
+    if (d->bn) {
+      float* sc = f32(ws, w.scale) + (size_t)l * H;
+      float* sh = f32(ws, w.shift) + (size_t)l * H;
+      PL_TRY(launch_bn_finalize(g.stat_sum, g.stat_m2, w.G, (int)B, H, ly.gamma, ly.beta, d->bn_eps,
+                                d->bn_momentum, ly.rm, ly.rv, ly.nbt, f32(ws, w.mean[l]),
+                                f32(ws, w.rstd[l]), sc, sh, s));
+      scale = sc; shift = sh;
+    }
+    const float* resid = (l >= 2 && (l % 2) == 0) ? f32(ws, w.act[l - 2]) : nullptr;
+    PL_TRY(launch_bn_apply(g.C, scale, shift, resid, f32(ws, w.act[l]), u64(ws, w.bits[l]), (int)B, H,
+                           d->p_dropout, seed, step, l,
+                           inject_keep ? inject_keep + (size_t)l * inj_stride : nullptr, s));
+    a_in = f32(ws, w.act[l]);
+  }
+  GemmArgs g = {};
+  g.A = a_in; g.B = d->params + P.off[4 * w.L]; g.C = y; g.bias = d->params + P.off[4 * w.L + 1];
+  g.M = (int)B; g.N = d->out_dim; g.K = H; g.lda = H; g.ldb = H; g.ldc = d->out_dim; g.split_k = 1;
+  return launch_gemm_f32(kNT, g, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------
+extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, int64_t B, void* ws,
+                             size_t ws_bytes, float* dx, float* grads, void* stream) {
+  PL_TRY(check_desc(d, true));
+  if (!x || !dy || !grads) PL_FAIL(PL_EINVAL, "pl_lifter_bwd: null x/dy/flat_grads");
+  if (B <= 0) PL_FAIL(PL_ESHAPE, "pl_lifter_bwd: B=%lld", (long long)B);
+  const Ws w = plan(d, B);
+  PL_TRY(check_ws(w, ws, ws_bytes));
+  const ParamLayout P = param_layout(d);
+  hipStream_t s = (hipStream_t)stream;
+  const int H = d->hidden, O = d->out_dim, Bi = (int)B;
+  const float kscale = (d->p_dropout > 0.f && d->p_dropout < 1.f) ? 1.0f / (1.0f - d->p_dropout) : 1.0f;
+  float* slabs = f32(ws, w.slabs);
+  float* GA = f32(ws, w.ga);
+  float* GB = f32(ws, w.gb);
+  float* DZ = f32(ws, w.dz);
+
+  // final Linear (LinearModel.w2): dW = dy^T h, db = sum dy, g = dy W
+  const float* W5 = d->params + P.off[4 * w.L];
+  const float* h_last = f32(ws, w.act[w.L - 1]);
+  PL_TRY(gemm_tn_reduced(dy, O, h_last, H, grads + P.off[4 * w.L], O, H, Bi, slabs, s));
+  PL_TRY(launch_colsum_partial(dy, Bi, O, f32(ws, w.outpart), s));
+  PL_TRY(launch_reduce_slabs(f32(ws, w.outpart), colsum_chunks(Bi), O, grads + P.off[4 * w.L + 1], s));
+  {
+    GemmArgs g = {};
+    g.A = dy; g.B = W5; g.C = GA; g.M = Bi; g.N = H; g.K = O; g.lda = O; g.ldb = H; g.ldc = H; g.split_k = 1;
+    PL_TRY(launch_gemm_f32(kNN, g, s));
+  }
+
+  for (int l = w.L - 1; l >= 0; --l) {
+    const Layer ly = layer_of(d, P, grads, l);
+    // gradient w.r.t. this layer's activation: GA for layer 0 and even layers, GB for odd ones
+    const float* gin = (l % 2 == 1) ? GB : GA;
+    const uint64_t* bits = u64(ws, w.bits[l]);
+    const float* z = f32(ws, w.z[l]);
+    if (d->bn) {
+      PL_TRY(launch_bn_bwd_reduce(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), kscale, Bi, H,
+                                  f32(ws, w.stat_a), f32(ws, w.stat_b), s));
+      PL_TRY(launch_bn_bwd_finalize(f32(ws, w.stat_a), f32(ws, w.stat_b), w.RC, Bi, H, ly.gamma,
+                                    f32(ws, w.rstd[l]), f32(ws, w.coef), ly.ggamma, ly.gbeta, s));
+    } else {
+      PL_TRY(launch_fill(ly.ggamma, H, 0.f, s));
+      PL_TRY(launch_fill(ly.gbeta, H, 0.f, s));
+    }
+    PL_TRY(launch_bn_bwd_dz(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), f32(ws, w.coef), kscale,
+                            d->bn, Bi, H, DZ, f32(ws, w.dbpart[l]), s));
+    PL_TRY(launch_reduce_slabs(f32(ws, w.dbpart[l]), w.RC, H, ly.gb, s));
+    const float* a_in = l == 0 ? x : f32(ws, w.act[l - 1]);
+    PL_TRY(gemm_tn_reduced(DZ, H, a_in, ly.K, ly.gW, H, ly.K, Bi, slabs, s));
+    if (l > 0) {
+      // da_in = dz W ; a residual block's first Linear also receives the skip gradient (in GA)
+      GemmArgs g = {};
+      g.A = DZ; g.B = ly.W; g.M = Bi; g.N = H; g.K = H; g.lda = H; g.ldb = H; g.ldc = H; g.split_k = 1;
+      if (l % 2 == 1) { g.C = GA; g.addend = GA; } else { g.C = GB; }
+      PL_TRY(launch_gemm_f32(kNN, g, s));
+    } else if (dx) {
+      GemmArgs g = {};
+      g.A = DZ; g.B = ly.W; g.C = dx; g.M = Bi; g.N = d->in_dim; g.K = H; g.lda = H; g.ldb = d->in_dim;
+      g.ldc = d->in_dim; g.split_k = 1;
+      PL_TRY(launch_gemm_f32(kNN, g, s));
+    }
+  }
+  return PL_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// GEMM building block (tests)
+// ---------------------------------------------------------------------------------------
+extern "C" int pl_gemm_f32(int layout, const float* A, const float* Bm, float* C, int64_t M, int64_t N,
+                           int64_t K, const float* bias, int split_k, float* slabs, void* stream) {
+  if (layout < 0 || layout > 2) PL_FAIL(PL_EINVAL, "pl_gemm_f32: layout %d", layout);
+  if (M <= 0 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX)
+    PL_FAIL(PL_ESHAPE, "pl_gemm_f32: bad shape");
+  GemmArgs g = {};
+  g.A = A; g.B = Bm; g.C = C; g.M = (int)M; g.N = (int)N; g.K = (int)K; g.bias = bias;
+  g.lda = layout == kTN ? (int)M : (int)K;
+  g.ldb = layout == kNT ? (int)K : (int)N;
+  g.ldc = (int)N;
+  g.split_k = 1;
+  hipStream_t s = (hipStream_t)stream;
+  if (split_k > 1) {
+    if (layout != kTN || !slabs || bias) PL_FAIL(PL_EINVAL, "pl_gemm_f32: split_k needs layout 2, slabs and no bias");
+    g.C = slabs; g.split_k = split_k;
+    PL_TRY(launch_gemm_f32(kTN, g, s));
+    return launch_reduce_slabs(slabs, split_k, M * N, C, s);
+  }
+  return launch_gemm_f32((GemmLayout)layout, g, s);
+}

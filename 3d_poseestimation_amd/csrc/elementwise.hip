@@ -1,0 +1,624 @@
+// HBM-streaming kernels of the lifter path: BatchNorm statistics/apply/backward, ReLU,
+// dropout, residual add, slab reductions, MSE, MPJPE and the flat AdamW.
+//
+// They replace, on the reference path, native_batch_norm(+backward), relu_, dropout, add
+// (phase1_lifting/baselineModel.py:35-37,41-45,92-94), mse_loss (train_1.py:37,94),
+// loss_MPJPE (train_1.py:19-23) and AdamW.step (train_1.py:39,96).
+//
+// Common shape: a (B x H) fp32 activation is walked with one float4 per lane, a
+// wavefront covering 256 consecutive columns of one row (1 KiB per wave-instruction,
+// fully coalesced).  Every column reduction is a fixed-order two-stage sum (per-block
+// partials, then a small finalize kernel): results are bitwise reproducible, no float
+// atomics anywhere.
+#include "philox.h"
+#include "pl_internal.h"
+
+namespace pl {
+namespace {
+
+constexpr int NTHR = 256;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// -------------------------------------------------------------------------------------
+// BatchNorm statistics finalize: Chan merge of (sum, M2) over 64-row groups.
+// grid = ceil(H/64), block = 256 = 64 columns x 4 group-parts.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHR) void bn_finalize_kernel(
+    const float* __restrict__ stat_sum, const float* __restrict__ stat_m2, int G, int B, int H,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    float* running_mean, float* running_var, int64_t* batches, float* mean_out, float* rstd_out,
+    float* scale_out, float* shift_out) {
+  __shared__ float red[4][64];
+  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const bool ok = c < H;
+  float s = 0.f;
+  if (ok)
+    for (int g = part; g < G; g += 4) s += stat_sum[(size_t)g * H + c];
+  red[part][cl] = s;
+  __syncthreads();
+  const float mean = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / (float)B;
+  __syncthreads();
+  float m2 = 0.f;
+  if (ok)
+    for (int g = part; g < G; g += 4) {
+      const int n = max(0, min(64, B - g * 64));
+      if (n > 0) {
+        const float d = stat_sum[(size_t)g * H + c] / (float)n - mean;
+        m2 += stat_m2[(size_t)g * H + c] + (float)n * d * d;
+      }
+    }
+  red[part][cl] = m2;
+  __syncthreads();
+  if (part == 0 && ok) {
+    const float var = (red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]) / (float)B;  // biased
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float sc = gamma[c] * rstd;
+    mean_out[c] = mean;
+    rstd_out[c] = rstd;
+    scale_out[c] = sc;
+    shift_out[c] = beta[c] - mean * sc;
+    if (running_mean) {
+      const float unbiased = var * ((float)B / (float)(B - 1));
+      running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+    }
+  }
+  if (batches && blockIdx.x == 0 && threadIdx.x == 0) batches[0] += 1;
+}
+
+// -------------------------------------------------------------------------------------
+// act = [resid +] dropout(relu(z*scale + shift)); bitmap of (positive & kept).
+// grid = (ceil(H/256), gy), block = 256: wave w walks rows blockIdx.y*4+w, +4*gy, ...
+// Bitmap layout: row r, 256-column strip q, word j (0..3): bit l <-> column 256q + 4l + j.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHR) void bn_apply_kernel(
+    const float* __restrict__ z, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* resid, float* act, uint64_t* __restrict__ bits, int B, int H, int mode,
+    uint32_t thr, float kscale, uint32_t k0, uint32_t k1, uint32_t c3, uint32_t layer,
+    const uint64_t* __restrict__ inject) {
+  // mode: 0 keep all, 1 philox, 2 injected bitmap, 3 drop all
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int strip = blockIdx.x;
+  const int c = strip * 256 + lane * 4;
+  const bool active = c < H;
+  const int wpr = ((H + 255) >> 8) * 4;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active && scale) { sc = ld4(scale + c); sh = ld4(shift + c); }
+  for (int r = blockIdx.y * 4 + wave; r < B; r += gridDim.y * 4) {
+    const size_t off = (size_t)r * H + c;
+    float y[4] = {0.f, 0.f, 0.f, 0.f};
+    bool keep[4] = {true, true, true, true};
+    if (active) {
+      const float4 v = ld4(z + off);
+      y[0] = fmaf(v.x, sc.x, sh.x); y[1] = fmaf(v.y, sc.y, sh.y);
+      y[2] = fmaf(v.z, sc.z, sh.z); y[3] = fmaf(v.w, sc.w, sh.w);
+      if (mode == 1) {
+        const uint64_t g = ((uint64_t)r * (uint64_t)H + (uint64_t)c) >> 2;
+        const Philox4 u = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), layer, c3, k0, k1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) keep[j] = u.v[j] >= thr;
+      } else if (mode == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) keep[j] = (inject[(size_t)r * wpr + strip * 4 + j] >> lane) & 1ull;
+      } else if (mode == 3) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) keep[j] = false;
+      }
+    }
+    bool on[4];
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      on[j] = active && keep[j] && (y[j] > 0.f);
+      o[j] = on[j] ? y[j] * kscale : 0.f;
+    }
+    uint64_t word = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t b = __ballot(on[j]);
+      if (lane == j) word = b;
+    }
+    if (lane < 4) bits[(size_t)r * wpr + strip * 4 + lane] = word;
+    if (active) {
+      float4 out = make_float4(o[0], o[1], o[2], o[3]);
+      if (resid) {
+        const float4 rv = ld4(resid + off);
+        out.x += rv.x; out.y += rv.y; out.z += rv.z; out.w += rv.w;
+      }
+      st4(act + off, out);
+    }
+  }
+}
+
+// block-level combine of per-wave float4 column partials; wave 0 returns the total
+__device__ __forceinline__ float4 combine4(float4 v, float4 (*sm)[64], int wave, int lane) {
+  sm[wave][lane] = v;
+  __syncthreads();
+  float4 t = sm[0][lane];
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 u = sm[w][lane];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+  }
+  __syncthreads();
+  return t;
+}
+
+// -------------------------------------------------------------------------------------
+// BN backward pass 1: per-block partial column sums of dy and dy*zhat.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHR) void bn_bwd_reduce_kernel(
+    const float* __restrict__ g, const uint64_t* __restrict__ bits, const float* __restrict__ z,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float kscale, int B, int H,
+    float* __restrict__ part_dy, float* __restrict__ part_dyz) {
+  __shared__ float4 sm[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int strip = blockIdx.x;
+  const int c = strip * 256 + lane * 4;
+  const bool active = c < H;
+  const int wpr = ((H + 255) >> 8) * 4;
+  float4 mu = make_float4(0, 0, 0, 0), rs = mu, s1 = mu, s2 = mu;
+  if (active) { mu = ld4(mean + c); rs = ld4(rstd + c); }
+  for (int r = blockIdx.y * 4 + wave; r < B; r += gridDim.y * 4) {
+    if (!active) continue;
+    const size_t off = (size_t)r * H + c;
+    const float4 gv = ld4(g + off), zv = ld4(z + off);
+    const uint64_t* bw = bits + (size_t)r * wpr + strip * 4;
+    const float d0 = ((bw[0] >> lane) & 1ull) ? gv.x * kscale : 0.f;
+    const float d1 = ((bw[1] >> lane) & 1ull) ? gv.y * kscale : 0.f;
+    const float d2 = ((bw[2] >> lane) & 1ull) ? gv.z * kscale : 0.f;
+    const float d3 = ((bw[3] >> lane) & 1ull) ? gv.w * kscale : 0.f;
+    s1.x += d0; s1.y += d1; s1.z += d2; s1.w += d3;
+    s2.x = fmaf(d0, (zv.x - mu.x) * rs.x, s2.x);
+    s2.y = fmaf(d1, (zv.y - mu.y) * rs.y, s2.y);
+    s2.z = fmaf(d2, (zv.z - mu.z) * rs.z, s2.z);
+    s2.w = fmaf(d3, (zv.w - mu.w) * rs.w, s2.w);
+  }
+  const float4 t1 = combine4(s1, sm, wave, lane);
+  const float4 t2 = combine4(s2, sm, wave, lane);
+  if (wave == 0 && active) {
+    st4(part_dy + (size_t)blockIdx.y * H + c, t1);
+    st4(part_dyz + (size_t)blockIdx.y * H + c, t2);
+  }
+}
+
+__global__ __launch_bounds__(NTHR) void bn_bwd_finalize_kernel(
+    const float* __restrict__ part_dy, const float* __restrict__ part_dyz, int RC, int B, int H,
+    const float* __restrict__ gamma, const float* __restrict__ rstd, float* __restrict__ coef,
+    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[2][4][64];
+  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const bool ok = c < H;
+  float a = 0.f, b = 0.f;
+  if (ok)
+    for (int k = part; k < RC; k += 4) {
+      a += part_dy[(size_t)k * H + c];
+      b += part_dyz[(size_t)k * H + c];
+    }
+  red[0][part][cl] = a;
+  red[1][part][cl] = b;
+  __syncthreads();
+  if (part == 0 && ok) {
+    const float sdy = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+    const float sdyz = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    coef[c] = gamma[c] * rstd[c];
+    coef[H + c] = sdy / (float)B;
+    coef[2 * H + c] = sdyz / (float)B;
+    dgamma[c] = sdyz;
+    dbeta[c] = sdy;
+  }
+}
+
+// -------------------------------------------------------------------------------------
+// BN backward pass 2: dz = c0*(dy - c1 - zhat*c2) (or dz = dy without BN) + db partials.
+// -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHR) void bn_bwd_dz_kernel(
+    const float* __restrict__ g, const uint64_t* __restrict__ bits, const float* __restrict__ z,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ coef,
+    float kscale, int bn, int B, int H, float* __restrict__ dz, float* __restrict__ part_db) {
+  __shared__ float4 sm[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int strip = blockIdx.x;
+  const int c = strip * 256 + lane * 4;
+  const bool active = c < H;
+  const int wpr = ((H + 255) >> 8) * 4;
+  float4 zero = make_float4(0, 0, 0, 0);
+  float4 mu = zero, rs = zero, c0 = zero, c1 = zero, c2 = zero, sdb = zero;
+  if (active && bn) {
+    mu = ld4(mean + c); rs = ld4(rstd + c);
+    c0 = ld4(coef + c); c1 = ld4(coef + H + c); c2 = ld4(coef + 2 * H + c);
+  }
+  for (int r = blockIdx.y * 4 + wave; r < B; r += gridDim.y * 4) {
+    if (!active) continue;
+    const size_t off = (size_t)r * H + c;
+    const float4 gv = ld4(g + off);
+    const uint64_t* bw = bits + (size_t)r * wpr + strip * 4;
+    float4 d;
+    d.x = ((bw[0] >> lane) & 1ull) ? gv.x * kscale : 0.f;
+    d.y = ((bw[1] >> lane) & 1ull) ? gv.y * kscale : 0.f;
+    d.z = ((bw[2] >> lane) & 1ull) ? gv.z * kscale : 0.f;
+    d.w = ((bw[3] >> lane) & 1ull) ? gv.w * kscale : 0.f;
+    if (bn) {
+      const float4 zv = ld4(z + off);
+      d.x = c0.x * (d.x - c1.x - (zv.x - mu.x) * rs.x * c2.x);
+      d.y = c0.y * (d.y - c1.y - (zv.y - mu.y) * rs.y * c2.y);
+      d.z = c0.z * (d.z - c1.z - (zv.z - mu.z) * rs.z * c2.z);
+      d.w = c0.w * (d.w - c1.w - (zv.w - mu.w) * rs.w * c2.w);
+    }
+    st4(dz + off, d);
+    sdb.x += d.x; sdb.y += d.y; sdb.z += d.z; sdb.w += d.w;
+  }
+  const float4 t = combine4(sdb, sm, wave, lane);
+  if (wave == 0 && active) st4(part_db + (size_t)blockIdx.y * H + c, t);
+}
+
+// -------------------------------------------------------------------------------------
+// small helpers
+// -------------------------------------------------------------------------------------
+__global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, int64_t n,
+                                    float* __restrict__ out, int vec) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    const int64_t n4 = n >> 2;
+    for (; i < n4; i += stride) {
+      float4 a = ld4(slabs + 4 * i);
+      for (int s = 1; s < nslab; ++s) {
+        const float4 b = ld4(slabs + (size_t)s * n + 4 * i);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      st4(out + 4 * i, a);
+    }
+  } else {
+    for (; i < n; i += stride) {
+      float a = slabs[i];
+      for (int s = 1; s < nslab; ++s) a += slabs[(size_t)s * n + i];
+      out[i] = a;
+    }
+  }
+}
+
+__global__ void colsum_partial_kernel(const float* __restrict__ X, int rows, int cols, int rpc,
+                                      float* __restrict__ part) {
+  const int r0 = blockIdx.x * rpc, r1 = min(rows, r0 + rpc);
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += X[(size_t)r * cols + c];
+    part[(size_t)blockIdx.x * cols + c] = s;
+  }
+}
+
+__global__ void bn_fold_eval_kernel(const float* __restrict__ bias, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ rm,
+                                    const float* __restrict__ rv, float eps, int bn, int H,
+                                    float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  if (bn) {
+    const float s = gamma[c] * (1.0f / sqrtf(rv[c] + eps));
+    scale[c] = s;
+    shift[c] = fmaf(bias[c] - rm[c], s, beta[c]);
+  } else {
+    scale[c] = 1.f;
+    shift[c] = bias[c];
+  }
+}
+
+__global__ void fill_kernel(float* p, int64_t n, float v) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  const int nw = blockDim.x >> 6;
+  for (int w = 0; w < nw; ++w) t += sm[w];
+  __syncthreads();
+  return t;
+}
+
+// ---- MSE(mean) forward + backward ---------------------------------------------------------
+__global__ __launch_bounds__(NTHR) void mse_partial_kernel(const float* __restrict__ pred,
+                                                           const float* __restrict__ tgt, int64_t n,
+                                                           float coef, float* __restrict__ dpred,
+                                                           float* __restrict__ part) {
+  __shared__ float sm[4];
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float d = pred[i] - tgt[i];
+    acc = fmaf(d, d, acc);
+    if (dpred) dpred[i] = d * coef;
+  }
+  const float t = block_sum(acc, sm);
+  if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(NTHR) void mse_final_kernel(const float* __restrict__ part, int np,
+                                                         float inv_n, float* __restrict__ loss) {
+  __shared__ float sm[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < np; i += blockDim.x) acc += part[i];
+  const float t = block_sum(acc, sm);
+  if (threadIdx.x == 0) loss[0] = t * inv_n;
+}
+
+// ---- loss_MPJPE --------------------------------------------------------------------------
+__global__ void mpjpe_partial_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                     int B, int J, int rpc, float* __restrict__ part) {
+  const int r0 = blockIdx.x * rpc, r1 = min(B, r0 + rpc);
+  for (int j = threadIdx.x; j < J; j += blockDim.x) {
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) {
+      const size_t o = ((size_t)r * J + j) * 3;
+      const float dx = pred[o] - tgt[o], dy = pred[o + 1] - tgt[o + 1], dz = pred[o + 2] - tgt[o + 2];
+      s += sqrtf(fmaf(dx, dx, fmaf(dy, dy, dz * dz)));
+    }
+    part[(size_t)blockIdx.x * J + j] = s;
+  }
+}
+
+__global__ void mpjpe_final_kernel(const float* __restrict__ part, int np, int J,
+                                   float* __restrict__ metric) {
+  for (int j = threadIdx.x; j < J; j += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < np; ++k) s += part[(size_t)k * J + j];
+    metric[j] += s;
+  }
+}
+
+// ---- flat AdamW (torch single-tensor update order) ----------------------------------------
+struct AdamWK {
+  float decay;       // 1 - lr*wd
+  float one_m_b1, b2, one_m_b2;
+  float step_size;   // lr / (1 - b1^t)
+  float bc2_sqrt;    // sqrt(1 - b2^t)
+  float eps, gscale;
+};
+
+__device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v, const AdamWK& k) {
+  g *= k.gscale;
+  p *= k.decay;
+  m = m + (g - m) * k.one_m_b1;
+  v = v * k.b2 + (k.one_m_b2 * g) * g;
+  const float denom = sqrtf(v) / k.bc2_sqrt + k.eps;
+  p = p - k.step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(NTHR) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                     float* __restrict__ m, float* __restrict__ v,
+                                                     int64_t n, AdamWK k, int vec) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    const int64_t n4 = n >> 2;
+    for (; i < n4; i += stride) {
+      float4 pv = ld4(p + 4 * i), mv = ld4(m + 4 * i), vv = ld4(v + 4 * i);
+      const float4 gv = ld4(g + 4 * i);
+      adamw_one(pv.x, gv.x, mv.x, vv.x, k);
+      adamw_one(pv.y, gv.y, mv.y, vv.y, k);
+      adamw_one(pv.z, gv.z, mv.z, vv.z, k);
+      adamw_one(pv.w, gv.w, mv.w, vv.w, k);
+      st4(p + 4 * i, pv); st4(m + 4 * i, mv); st4(v + 4 * i, vv);
+    }
+    i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  }
+  for (; i < n; i += stride) adamw_one(p[i], g[i], m[i], v[i], k);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline int stream_rows_grid(int B, int strips) {
+  // ~2048 workgroups in flight (8 per CU), 4 rows per workgroup pass
+  int gy = (2048 + strips - 1) / strips;
+  const int need = (B + 3) / 4;
+  if (gy > need) gy = need;
+  return gy < 1 ? 1 : gy;
+}
+
+}  // namespace
+
+// =====================================================================================
+// launchers
+// =====================================================================================
+int launch_bn_finalize(const float* stat_sum, const float* stat_m2, int G, int B, int H,
+                       const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, int64_t* batches, float* mean,
+                       float* rstd, float* scale, float* shift, hipStream_t s) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((H + 63) / 64), dim3(NTHR), 0, s, stat_sum, stat_m2, G, B,
+                     H, gamma, beta, eps, momentum, running_mean, running_var, batches, mean, rstd,
+                     scale, shift);
+  PL_CHECK_LAUNCH("bn_finalize");
+  return PL_OK;
+}
+
+int launch_bn_apply(const float* z, const float* scale, const float* shift, const float* resid,
+                    float* act, uint64_t* bits, int B, int H, float p, uint64_t seed, uint64_t step,
+                    int layer, const uint64_t* inject_keep, hipStream_t s) {
+  int mode = 0;
+  float kscale = 1.f;
+  if (p >= 1.f) mode = 3;
+  else if (p > 0.f) {
+    mode = inject_keep ? 2 : 1;
+    kscale = 1.0f / (1.0f - p);
+  }
+  const uint32_t thr = dropout_threshold(p);
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32);
+  const int strips = (H + 255) / 256;
+  dim3 grid(strips, stream_rows_grid(B, strips));
+  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NTHR), 0, s, z, scale, shift, resid, act, bits, B, H,
+                     mode, thr, kscale, k0, k1, (uint32_t)step, (uint32_t)layer, inject_keep);
+  PL_CHECK_LAUNCH("bn_apply");
+  return PL_OK;
+}
+
+int bwd_row_chunks(int B) {
+  int rc = (B + 31) / 32;
+  if (rc > 128) rc = 128;
+  return rc < 1 ? 1 : rc;
+}
+
+int launch_bn_bwd_reduce(const float* g, const uint64_t* bits, const float* z, const float* mean,
+                         const float* rstd, float keep_scale, int B, int H, float* part_dy,
+                         float* part_dyz, hipStream_t s) {
+  dim3 grid((H + 255) / 256, bwd_row_chunks(B));
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(NTHR), 0, s, g, bits, z, mean, rstd, keep_scale, B,
+                     H, part_dy, part_dyz);
+  PL_CHECK_LAUNCH("bn_bwd_reduce");
+  return PL_OK;
+}
+
+int launch_bn_bwd_finalize(const float* part_dy, const float* part_dyz, int RC, int B, int H,
+                           const float* gamma, const float* rstd, float* coef, float* dgamma,
+                           float* dbeta, hipStream_t s) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((H + 63) / 64), dim3(NTHR), 0, s, part_dy, part_dyz, RC,
+                     B, H, gamma, rstd, coef, dgamma, dbeta);
+  PL_CHECK_LAUNCH("bn_bwd_finalize");
+  return PL_OK;
+}
+
+int launch_bn_bwd_dz(const float* g, const uint64_t* bits, const float* z, const float* mean,
+                     const float* rstd, const float* coef, float keep_scale, int bn, int B, int H,
+                     float* dz, float* part_db, hipStream_t s) {
+  dim3 grid((H + 255) / 256, bwd_row_chunks(B));
+  hipLaunchKernelGGL(bn_bwd_dz_kernel, grid, dim3(NTHR), 0, s, g, bits, z, mean, rstd, coef, keep_scale,
+                     bn, B, H, dz, part_db);
+  PL_CHECK_LAUNCH("bn_bwd_dz");
+  return PL_OK;
+}
+
+int launch_reduce_slabs(const float* slabs, int nslab, int64_t n, float* out, hipStream_t s) {
+  const int vec = ((n & 3) == 0) && aligned16(slabs) && aligned16(out);
+  const int64_t work = vec ? (n >> 2) : n;
+  int blocks = (int)((work + NTHR - 1) / NTHR);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(NTHR), 0, s, slabs, nslab, n, out, vec);
+  PL_CHECK_LAUNCH("reduce_slabs");
+  return PL_OK;
+}
+
+int colsum_chunks(int rows) {
+  int rc = (rows + 63) / 64;
+  if (rc > 64) rc = 64;
+  return rc < 1 ? 1 : rc;
+}
+
+int launch_colsum_partial(const float* X, int rows, int cols, float* part, hipStream_t s) {
+  const int rc = colsum_chunks(rows);
+  const int rpc = (rows + rc - 1) / rc;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(rc), dim3(NTHR), 0, s, X, rows, cols, rpc, part);
+  PL_CHECK_LAUNCH("colsum_partial");
+  return PL_OK;
+}
+
+int launch_bn_fold_eval(const float* bias, const float* gamma, const float* beta, const float* rm,
+                        const float* rv, float eps, int bn, int H, float* scale, float* shift,
+                        hipStream_t s) {
+  hipLaunchKernelGGL(bn_fold_eval_kernel, dim3((H + NTHR - 1) / NTHR), dim3(NTHR), 0, s, bias, gamma, beta,
+                     rm, rv, eps, bn, H, scale, shift);
+  PL_CHECK_LAUNCH("bn_fold_eval");
+  return PL_OK;
+}
+
+int launch_fill(float* p, int64_t n, float v, hipStream_t s) {
+  if (n <= 0) return PL_OK;
+  int blocks = (int)((n + NTHR - 1) / NTHR);
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(NTHR), 0, s, p, n, v);
+  PL_CHECK_LAUNCH("fill");
+  return PL_OK;
+}
+
+}  // namespace pl
+
+// =====================================================================================
+// C ABI: loss / metric / optimiser
+// =====================================================================================
+using namespace pl;
+
+static int mse_blocks(int64_t n) {
+  int64_t b = (n + NTHR * 4 - 1) / (NTHR * 4);
+  if (b > 1024) b = 1024;
+  return b < 1 ? 1 : (int)b;
+}
+
+extern "C" size_t pl_mse_scratch_bytes(int64_t n) { return (size_t)mse_blocks(n > 0 ? n : 1) * sizeof(float); }
+
+extern "C" int pl_mse_fwd_bwd(const float* pred, const float* tgt, int64_t n, float grad_scale,
+                              float* dpred, float* loss_out, void* scratch, void* stream) {
+  if (!pred || !tgt || !loss_out || !scratch) PL_FAIL(PL_EINVAL, "pl_mse_fwd_bwd: null pointer");
+  if (n <= 0) PL_FAIL(PL_ESHAPE, "pl_mse_fwd_bwd: n = %lld", (long long)n);
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = mse_blocks(n);
+  const float coef = grad_scale * 2.0f / (float)n;
+  hipLaunchKernelGGL(mse_partial_kernel, dim3(nb), dim3(NTHR), 0, s, pred, tgt, n, coef, dpred,
+                     (float*)scratch);
+  PL_CHECK_LAUNCH("mse_partial");
+  hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(NTHR), 0, s, (const float*)scratch, nb,
+                     1.0f / (float)n, loss_out);
+  PL_CHECK_LAUNCH("mse_final");
+  return PL_OK;
+}
+
+static int mpjpe_chunks(int64_t B) {
+  int64_t c = (B + 63) / 64;
+  if (c > 256) c = 256;
+  return c < 1 ? 1 : (int)c;
+}
+
+extern "C" size_t pl_mpjpe_scratch_bytes(int64_t B, int64_t joints) {
+  return (size_t)mpjpe_chunks(B) * (size_t)(joints > 0 ? joints : 1) * sizeof(float);
+}
+
+extern "C" int pl_mpjpe_accum(const float* pred, const float* tgt, int64_t B, int64_t joints,
+                              float* metric, void* scratch, void* stream) {
+  if (!pred || !tgt || !metric || !scratch) PL_FAIL(PL_EINVAL, "pl_mpjpe_accum: null pointer");
+  if (B <= 0 || joints <= 0 || joints > 1024) PL_FAIL(PL_ESHAPE, "pl_mpjpe_accum: B=%lld joints=%lld", (long long)B, (long long)joints);
+  hipStream_t s = (hipStream_t)stream;
+  const int nc = mpjpe_chunks(B);
+  const int rpc = (int)((B + nc - 1) / nc);
+  hipLaunchKernelGGL(mpjpe_partial_kernel, dim3(nc), dim3(64), 0, s, pred, tgt, (int)B, (int)joints, rpc,
+                     (float*)scratch);
+  PL_CHECK_LAUNCH("mpjpe_partial");
+  hipLaunchKernelGGL(mpjpe_final_kernel, dim3(1), dim3(64), 0, s, (const float*)scratch, nc, (int)joints,
+                     metric);
+  PL_CHECK_LAUNCH("mpjpe_final");
+  return PL_OK;
+}
+
+extern "C" int pl_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int64_t t,
+                             float grad_scale, void* stream) {
+  if (!p || !g || !m || !v) PL_FAIL(PL_EINVAL, "pl_adamw_flat: null pointer");
+  if (n <= 0 || t < 1) PL_FAIL(PL_ESHAPE, "pl_adamw_flat: n=%lld t=%lld", (long long)n, (long long)t);
+  AdamWK k;
+  const double bc1 = 1.0 - pow((double)beta1, (double)t);
+  const double bc2 = 1.0 - pow((double)beta2, (double)t);
+  k.decay = (float)(1.0 - (double)lr * (double)weight_decay);
+  k.one_m_b1 = (float)(1.0 - (double)beta1);
+  k.b2 = beta2;
+  k.one_m_b2 = (float)(1.0 - (double)beta2);
+  k.step_size = (float)((double)lr / bc1);
+  k.bc2_sqrt = (float)sqrt(bc2);
+  k.eps = eps;
+  k.gscale = grad_scale;
+  const int vec = aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v);
+  int64_t work = vec ? (n >> 2) : n;
+  int blocks = (int)((work + NTHR - 1) / NTHR);
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(NTHR), 0, (hipStream_t)stream, p, g, m, v, n, k, vec);
+  PL_CHECK_LAUNCH("adamw");
+  return PL_OK;
+}

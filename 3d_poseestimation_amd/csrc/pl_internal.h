@@ -1,0 +1,102 @@
+// Internal declarations shared by the HIP translation units of libposelift.so.
+// gfx950 (MI355X) only: 64-lane wavefronts, MFMA, 160 KB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/poselift.h"
+
+namespace pl {
+
+constexpr int kWave = 64;
+
+void set_error(const char* fmt, ...);
+
+#define PL_FAIL(code, ...)        \
+  do {                            \
+    ::pl::set_error(__VA_ARGS__); \
+    return (code);                \
+  } while (0)
+
+#define PL_CHECK_LAUNCH(what)                                              \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess)                                                 \
+      PL_FAIL(PL_EHIP, "%s: launch failed: %s", what, hipGetErrorString(e__)); \
+  } while (0)
+
+#define PL_TRY(expr)        \
+  do {                      \
+    int rc__ = (expr);      \
+    if (rc__ != PL_OK) return rc__; \
+  } while (0)
+
+// ---------------------------------------------------------------------------------
+// fp32 MFMA GEMM  (gemm_f32.hip)
+// ---------------------------------------------------------------------------------
+enum GemmLayout { kNT = 0, kNN = 1, kTN = 2 };
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  int split_k;              // >1: slice z writes C + z*M*ldc (slab), no epilogue extras
+  // epilogue (all optional)
+  const float* bias;        // [N]     v += bias[col]
+  const float* addend;      // [M][ldc] v += addend[row][col]   (may alias C)
+  float* stat_sum;          // [2*ceil(M/128)][N] per-64-row-group column sums of v
+  float* stat_m2;           //   ... and sums of squares about the group mean
+  const float* col_scale;   // [N]     v = v*scale[col] + shift[col]  (eval-mode BN fold)
+  const float* col_shift;
+  int relu;                 // v = max(v, 0)
+  const float* resid;       // [M][ldc] v += resid[row][col] after relu (may alias C)
+};
+
+int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s);
+int gemm_stat_groups(int M);  // number of 64-row groups the stats epilogue emits
+
+// ---------------------------------------------------------------------------------
+// streaming kernels (elementwise.hip)
+// ---------------------------------------------------------------------------------
+inline int bitmap_words_per_row(int H) { return ((H + 255) / 256) * 4; }
+
+// BN statistics: merge per-group (sum, M2) partials -> mean/rstd/scale/shift, update running
+int launch_bn_finalize(const float* stat_sum, const float* stat_m2, int G, int B, int H,
+                       const float* gamma, const float* beta, float eps, float momentum,
+                       float* running_mean, float* running_var, int64_t* batches,
+                       float* mean, float* rstd, float* scale, float* shift, hipStream_t s);
+
+// act = [resid +] dropout(relu(z*scale + shift)); bits = keep&positive bitmap
+int launch_bn_apply(const float* z, const float* scale, const float* shift, const float* resid,
+                    float* act, uint64_t* bits, int B, int H, float p, uint64_t seed,
+                    uint64_t step, int layer, const uint64_t* inject_keep, hipStream_t s);
+
+int bwd_row_chunks(int B);
+// pass 1: partial column sums of dy and dy*zhat, dy = g * bits * keep_scale
+int launch_bn_bwd_reduce(const float* g, const uint64_t* bits, const float* z, const float* mean,
+                         const float* rstd, float keep_scale, int B, int H, float* part_dy,
+                         float* part_dyz, hipStream_t s);
+// finalize: c = {gamma*rstd, sum_dy/B, sum_dyz/B}; dgamma, dbeta
+int launch_bn_bwd_finalize(const float* part_dy, const float* part_dyz, int RC, int B, int H,
+                           const float* gamma, const float* rstd, float* coef, float* dgamma,
+                           float* dbeta, hipStream_t s);
+// pass 2: dz = c0*(dy - c1 - zhat*c2)  (bn) or dz = dy (no bn); partial column sums of dz
+int launch_bn_bwd_dz(const float* g, const uint64_t* bits, const float* z, const float* mean,
+                     const float* rstd, const float* coef, float keep_scale, int bn, int B, int H,
+                     float* dz, float* part_db, hipStream_t s);
+
+// out[i] = sum_s slabs[s*n + i]
+int launch_reduce_slabs(const float* slabs, int nslab, int64_t n, float* out, hipStream_t s);
+// partial column sums of X[rows][cols] -> part[RC][cols], RC = colsum_chunks(rows)
+int colsum_chunks(int rows);
+int launch_colsum_partial(const float* X, int rows, int cols, float* part, hipStream_t s);
+// eval-mode fold: scale = gamma*rsqrt(rv+eps), shift = (bias - rm)*scale + beta  (bn) or 1, bias
+int launch_bn_fold_eval(const float* bias, const float* gamma, const float* beta, const float* rm,
+                        const float* rv, float eps, int bn, int H, float* scale, float* shift,
+                        hipStream_t s);
+int launch_fill(float* p, int64_t n, float v, hipStream_t s);
+
+}  // namespace pl

@@ -1,0 +1,82 @@
+"""Data-parallel driver of the lifter step: one process per GPU, RCCL over xGMI.
+
+The reference is single-process; this is the row-(e) extension.  Poses are
+independent except through the gradient sum, so each rank runs the whole step on its own
+shard of the batch (BatchNorm over the local 4096 rows, the DDP convention) and the only
+collective is ONE sum all-reduce of the flat gradient arena (4.3 M fp32 = 17.19 MB); the
+1/world_size average is folded into the AdamW kernel (grad_scale), so no extra pass.
+
+`backend="nccl"` is RCCL on ROCm.  The same code runs on `gloo` with CPU tensors, which is
+how tests/test_dp_gloo.py covers it without a GPU.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun's RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*.
+    Returns (rank, local_rank, world_size); world_size 1 without initialising anything."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def shard_rows(n_rows, rank, world):
+    """Contiguous shard [lo, hi) of a global batch: the first n_rows % world ranks get one
+    extra row, so every row is owned exactly once."""
+    base, extra = divmod(n_rows, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+class GradSync:
+    """Sum-all-reduce of a flat gradient arena; returns the scale the optimizer applies.
+
+    bucket_bytes splits the arena into contiguous buckets (default: one bucket -- at 17 MB a
+    single RCCL call is latency-optimal on the fully connected xGMI mesh)."""
+
+    def __init__(self, group=None, bucket_bytes=None):
+        self.group, self.bucket_bytes = group, bucket_bytes
+
+    def world(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def reduce_flat(self, flat):
+        world = self.world()
+        if world == 1:
+            return 1.0
+        if self.bucket_bytes:
+            step = max(1, self.bucket_bytes // flat.element_size())
+            works = [dist.all_reduce(flat[i:i + step], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                     for i in range(0, flat.numel(), step)]
+            for w in works:
+                w.wait()
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return 1.0 / world
+
+    def __call__(self, model):
+        return self.reduce_flat(model.flat_grads)
+
+
+def broadcast_model(model, src=0, group=None):
+    """Make every rank start from rank `src`'s parameters and BatchNorm buffers."""
+    if not dist.is_initialized():
+        return
+    dist.broadcast(model.flat_params, src, group=group)
+    dist.broadcast(model._bn_running, src, group=group)
+    dist.broadcast(model._bn_batches, src, group=group)

@@ -1,0 +1,288 @@
+"""LinearModel: drop-in for the reference's 2D->3D lifter, computed by libposelift.so.
+
+Same constructor, forward contract, .train()/.eval() behaviour and state_dict() keys as
+/root/reference/phase1_lifting/baselineModel.py:50-102 (residual block :14-47), so
+`train_1.py`-style code can swap the import and keep running -- on an MI355X.  The
+containers are stock nn.Linear / nn.BatchNorm1d objects (so `torch.manual_seed(s)` gives
+the reference's initial weights, and checkpoints load unchanged), but they are parameter
+holders only: their tensors are views into flat arenas and every FLOP of forward and
+backward runs in the HIP library.  There is no CPU or eager fallback.
+"""
+import ctypes
+import weakref
+
+import torch
+from torch import nn
+
+from . import _lib
+from .layout import bitmap_words_per_row, hidden_layer_prefixes, param_slots
+
+
+class Linear(nn.Module):
+    """Residual block (baselineModel.py:14-47).  A container: LinearModel.forward does the math."""
+
+    def __init__(self, linear_size, p_dropout=0.5, BN=True):
+        super().__init__()
+        self.l_size = linear_size
+        self.w1 = nn.Linear(linear_size, linear_size)
+        self.batch_norm1 = nn.BatchNorm1d(linear_size)
+        self.w2 = nn.Linear(linear_size, linear_size)
+        self.batch_norm2 = nn.BatchNorm1d(linear_size)
+        self.BN = BN
+
+    def forward(self, x):
+        raise _lib.PoseliftError("residual blocks are evaluated by LinearModel.forward as one fused path")
+
+
+class _EvalNoBackward(torch.autograd.Function):
+    """Marks an eval-mode output so a later .backward() fails loudly instead of silently
+    producing no gradients (eval-mode backward belongs to the phase5 row)."""
+
+    @staticmethod
+    def forward(ctx, y, *anchors):
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError("backward through an eval-mode LinearModel is not built yet")
+
+
+class _LifterFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x2, model, ws, *params):
+        y = model._run_fwd_train(x2, ws)
+        ctx.model, ctx.ws, ctx.token = model, ws, ws["busy"]
+        weakref.finalize(ctx, LinearModel._release_workspace, ws, ws["busy"])
+        ctx.save_for_backward(x2)
+        ctx.need_dx = x2.requires_grad
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x2,) = ctx.saved_tensors
+        model, ws = ctx.model, ctx.ws
+        dx = model._run_bwd(x2, gy.contiguous(), ws, ctx.need_dx)
+        model._release_workspace(ws, ctx.token)
+        # parameter gradients were written straight into the flat gradient arena and
+        # attached as .grad views (one arena = one all-reduce, one fused AdamW launch)
+        return (dx, None, None) + (None,) * len(model._param_list)
+
+
+class LinearModel(nn.Module):
+    def __init__(self, i_dim, o_dim, linear_size=1024, num_stage=2, p_dropout=0.5, BN=True,
+                 compute_dtype="fp32"):
+        super().__init__()
+        if linear_size % 4:
+            raise ValueError("linear_size must be a multiple of 4 for the HIP path")
+        self.linear_size, self.p_dropout, self.num_stage = linear_size, p_dropout, num_stage
+        self.input_size, self.output_size = i_dim, o_dim
+        self.w1 = nn.Linear(i_dim, linear_size)
+        self.batch_norm1 = nn.BatchNorm1d(linear_size)
+        self.linear_stages = nn.ModuleList(Linear(linear_size, p_dropout, BN) for _ in range(num_stage))
+        self.w2 = nn.Linear(linear_size, o_dim)
+        self.BN = BN
+        self.compute_dtype = {"fp32": _lib.PL_F32, "bf16": _lib.PL_BF16}[compute_dtype]
+        self._slots, self._arena_floats = param_slots(i_dim, linear_size, o_dim, num_stage)
+        self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        self._step = 0
+        self._inject_keep = None
+        self._flat = self._flat_grad = self._flat_grad_tmp = None
+        self._ws_pool, self._ws_token = {}, 0
+        self._flatten()
+
+    # ------------------------------------------------------------------ arenas
+    def _named_holders(self):
+        mods = dict(self.named_modules())
+        return [(mods[lin], mods[bn]) for lin, bn in hidden_layer_prefixes(self.num_stage)]
+
+    def _flatten(self):
+        """(Re)build the flat arenas on the parameters' current device and re-point every
+        parameter / BatchNorm buffer at its slot."""
+        named = dict(self.named_parameters())
+        dev = self.w1.weight.device
+        flat = torch.zeros(self._arena_floats, dtype=torch.float32, device=dev)
+        for s in self._slots:
+            p = named[s.name]
+            view = flat[s.offset:s.offset + s.numel].view(s.shape)
+            view.copy_(p.data.to(torch.float32))
+            p.data = view
+            p.grad = None
+        holders = self._named_holders()
+        L, H = len(holders), self.linear_size
+        running = torch.zeros(L, 2, H, dtype=torch.float32, device=dev)
+        batches = torch.zeros(L, dtype=torch.int64, device=dev)
+        for l, (_, bn) in enumerate(holders):
+            running[l, 0].copy_(bn.running_mean)
+            running[l, 1].copy_(bn.running_var)
+            batches[l] = bn.num_batches_tracked
+            bn.running_mean.data = running[l, 0]
+            bn.running_var.data = running[l, 1]
+            bn.num_batches_tracked.data = batches[l]
+        self._flat, self._bn_running, self._bn_batches = flat, running, batches
+        self._flat_grad = self._flat_grad_tmp = None
+        self._param_list = [named[s.name] for s in self._slots]
+        self._ws_pool = {}
+        self._desc = _lib.PLDesc(
+            in_dim=self.input_size, hidden=H, out_dim=self.output_size, num_stage=self.num_stage,
+            bn=int(bool(self.BN)), dtype=self.compute_dtype, p_dropout=float(self.p_dropout),
+            bn_eps=float(self.batch_norm1.eps), bn_momentum=float(self.batch_norm1.momentum), reserved=0,
+            params=flat.data_ptr(), bn_running=running.data_ptr(), bn_batches=batches.data_ptr())
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._flatten()
+        return out
+
+    def _arenas_intact(self):
+        s = self._slots[-1]
+        return self._param_list[-1].data_ptr() == self._flat.data_ptr() + 4 * s.offset
+
+    @property
+    def flat_params(self):
+        """The flat fp32 parameter arena (22 tensors + alignment padding)."""
+        return self._flat
+
+    @property
+    def flat_grads(self):
+        """The flat gradient arena (same layout); allocated on first use."""
+        if self._flat_grad is None:
+            self._flat_grad = torch.zeros_like(self._flat)
+        return self._flat_grad
+
+    def manual_seed(self, seed, step=0):
+        """Key of the Philox dropout stream (csrc/philox.h); give each DP rank its own."""
+        self._seed, self._step = int(seed) & 0xFFFFFFFFFFFFFFFF, int(step)
+        return self
+
+    def debug_inject_keep(self, keep_bitmaps):
+        """Parity mode: the next training forward takes its dropout keep decisions from
+        `keep_bitmaps` (int64/uint64 tensor [n_hidden][B][words], layout.pack_keep_bitmap)."""
+        self._inject_keep = keep_bitmaps
+
+    # ------------------------------------------------------------------ workspaces
+    def _acquire_workspace(self, B):
+        pool = self._ws_pool.setdefault(B, [])
+        self._ws_token += 1
+        for ws in pool:
+            if ws["busy"] is None:
+                ws["busy"] = self._ws_token
+                return ws
+        nbytes = _lib.lib().pl_workspace_bytes(ctypes.byref(self._desc), B)
+        if nbytes == 0:
+            _lib.check(-1, "pl_workspace_bytes")
+        ws = {"buf": torch.empty(nbytes, dtype=torch.uint8, device=self._flat.device), "bytes": nbytes,
+              "busy": self._ws_token, "B": B}
+        pool.append(ws)
+        return ws
+
+    @staticmethod
+    def _release_workspace(ws, token=None):
+        """Free a workspace for reuse.  With a token, only if that acquisition still owns it
+        (a graph freed without backward releases through a finalizer, possibly late)."""
+        if token is None or ws["busy"] == token:
+            ws["busy"] = None
+
+    def workspace_view(self, ws, which, layer):
+        """Debug/test: a saved tensor of the last training forward (pl_workspace_view)."""
+        off, size = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(_lib.lib().pl_workspace_view(ctypes.byref(self._desc), ws["B"], which, layer,
+                                                ctypes.byref(off), ctypes.byref(size)), "pl_workspace_view")
+        raw = ws["buf"][off.value:off.value + size.value]
+        H = self.linear_size
+        if which in (0, 1):
+            return raw.view(torch.float32).view(ws["B"], H)
+        if which == 2:
+            return raw.view(torch.int64).view(ws["B"], bitmap_words_per_row(H))
+        return raw.view(torch.float32)
+
+    # ------------------------------------------------------------------ launches
+    def _run_fwd_train(self, x2, ws):
+        B = x2.shape[0]
+        y = torch.empty(B, self.output_size, dtype=torch.float32, device=x2.device)
+        inj = self._inject_keep
+        self._inject_keep = None
+        if inj is not None:
+            _lib.require_device_tensor(inj, "inject_keep", inj.dtype)
+            want = (len(self._named_holders()), B, bitmap_words_per_row(self.linear_size))
+            if tuple(inj.shape) != want or inj.element_size() != 8:
+                raise _lib.PoseliftError(f"inject_keep must be 64-bit words of shape {want}")
+        self._step += 1
+        rc = _lib.lib().pl_lifter_fwd_train(
+            ctypes.byref(self._desc), x2.data_ptr(), y.data_ptr(), B, ws["buf"].data_ptr(), ws["bytes"],
+            self._seed, self._step, inj.data_ptr() if inj is not None else None,
+            _lib.current_stream_ptr())
+        _lib.check(rc, "pl_lifter_fwd_train")
+        self.last_workspace = ws
+        return y
+
+    def _run_bwd(self, x2, gy, ws, need_dx):
+        B = x2.shape[0]
+        accumulate = any(p.grad is not None for p in self._param_list)
+        if accumulate:
+            if self._flat_grad_tmp is None:
+                self._flat_grad_tmp = torch.zeros_like(self._flat)
+            target = self._flat_grad_tmp
+        else:
+            target = self.flat_grads
+        dx = torch.empty_like(x2) if need_dx else None
+        rc = _lib.lib().pl_lifter_bwd(
+            ctypes.byref(self._desc), x2.data_ptr(), gy.data_ptr(), B, ws["buf"].data_ptr(), ws["bytes"],
+            dx.data_ptr() if need_dx else None, target.data_ptr(), _lib.current_stream_ptr())
+        _lib.check(rc, "pl_lifter_bwd")
+        if accumulate:
+            for s, p in zip(self._slots, self._param_list):
+                gview = target[s.offset:s.offset + s.numel].view(s.shape)
+                if p.grad is None:
+                    p.grad = gview.clone()
+                else:
+                    p.grad.add_(gview)
+        else:
+            for s, p in zip(self._slots, self._param_list):
+                if self.BN or "batch_norm" not in s.name:
+                    p.grad = target[s.offset:s.offset + s.numel].view(s.shape)
+        return dx
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x):
+        if not self._arenas_intact():
+            self._flatten()
+        B = x.shape[0]
+        x2 = x.reshape(B, -1)
+        if x2.shape[1] != self.input_size:
+            raise ValueError(f"expected {self.input_size} input features, got {x2.shape[1]}")
+        if x2.dtype != torch.float32:
+            x2 = x2.float()
+        x2 = x2.contiguous()
+        _lib.require_device_tensor(x2, "x")
+        _lib.require_device_tensor(self._flat, "parameters")
+        if x2.device != self._flat.device:
+            raise _lib.PoseliftError(f"x on {x2.device}, parameters on {self._flat.device}")
+        with torch.cuda.device(x2.device):
+            if self.training:
+                ws = self._acquire_workspace(B)
+                needs_graph = torch.is_grad_enabled() and (
+                    x2.requires_grad or any(p.requires_grad for p in self._param_list))
+                if needs_graph:
+                    return _LifterFn.apply(x2, self, ws, *self._param_list)
+                try:
+                    return self._run_fwd_train(x2, ws)
+                finally:
+                    self._release_workspace(ws)
+            ws = self._acquire_workspace(B)
+            try:
+                y = torch.empty(B, self.output_size, dtype=torch.float32, device=x2.device)
+                rc = _lib.lib().pl_lifter_fwd_eval(
+                    ctypes.byref(self._desc), x2.data_ptr(), y.data_ptr(), B, ws["buf"].data_ptr(),
+                    ws["bytes"], _lib.current_stream_ptr())
+                _lib.check(rc, "pl_lifter_fwd_eval")
+            finally:
+                self._release_workspace(ws)
+            if torch.is_grad_enabled() and (x2.requires_grad or any(p.requires_grad for p in self._param_list)):
+                return _EvalNoBackward.apply(y, x2, *self._param_list)
+            return y
+
+
+def weight_init(m):
+    """baselineModel.py:10-12: Kaiming-normal on every nn.Linear weight (biases untouched)."""
+    if isinstance(m, nn.Linear):
+        nn.init.kaiming_normal_(m.weight)

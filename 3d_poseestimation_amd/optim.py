@@ -1,0 +1,73 @@
+"""FlatAdamW: torch.optim.AdamW semantics over the lifter's flat arenas, one HIP launch.
+
+Replaces `torch.optim.AdamW(model_lift.parameters(), lr=lr)` + `optimizer_lift.step()`
+(/root/reference/phase1_lifting/train_1.py:39,96): decoupled weight decay 0.01 on every
+parameter, betas (0.9, 0.999), eps 1e-8, bias-corrected, in torch's single-tensor update
+order.  It is a torch.optim.Optimizer subclass (LR schedulers such as the reference's
+ReduceLROnPlateau, train_1.py:41, work unchanged) and its state_dict() has the stock
+AdamW structure (per-parameter 'step', 'exp_avg', 'exp_avg_sq'), so the reference's
+checkpoint envelope {'epoch','batch_size','model','optimizer'} (train_1.py:186) round-trips.
+"""
+import torch
+
+from . import _lib
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        if not hasattr(model, "flat_params"):
+            raise TypeError("FlatAdamW drives a 3d_poseestimation_amd LinearModel")
+        self._model = model
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        super().__init__(list(model._param_list), defaults)
+        self._t = 0
+        self._m = self._v = None
+        self._bound_arena = None
+
+    def _bind(self):
+        """(Re)create flat moment arenas next to the model's parameter arena and expose them
+        as per-parameter views in self.state (the stock AdamW layout)."""
+        model = self._model
+        flat = model.flat_params
+        if self._bound_arena is not None and self._bound_arena.data_ptr() == flat.data_ptr():
+            return
+        m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+        for s, p in zip(model._slots, model._param_list):
+            st = self.state[p]
+            mv = m[s.offset:s.offset + s.numel].view(s.shape)
+            vv = v[s.offset:s.offset + s.numel].view(s.shape)
+            if "exp_avg" in st:
+                mv.copy_(st["exp_avg"])
+                vv.copy_(st["exp_avg_sq"])
+                self._t = max(self._t, int(st["step"]))
+            st["exp_avg"], st["exp_avg_sq"] = mv, vv
+            st["step"] = torch.tensor(float(self._t))
+        self._m, self._v, self._bound_arena = m, v, flat
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._bound_arena = None          # loaded tensors are copies: re-bind into the arenas
+        self._t = 0
+        self._bind()
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        self._bind()
+        model = self._model
+        flat, grads = model.flat_params, model.flat_grads
+        _lib.require_device_tensor(flat, "parameters")
+        g = self.param_groups[0]
+        self._t += 1
+        with torch.cuda.device(flat.device):
+            rc = _lib.lib().pl_adamw_flat(
+                flat.data_ptr(), grads.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), flat.numel(),
+                float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                float(g["weight_decay"]), self._t, float(grad_scale), _lib.current_stream_ptr())
+        _lib.check(rc, "pl_adamw_flat")
+        for p in model._param_list:
+            self.state[p]["step"].fill_(float(self._t))
+        return loss

@@ -1,0 +1,99 @@
+"""Train / eval step and metrics of the lifter path, mirroring the reference script.
+
+  train_step        /root/reference/phase1_lifting/train_1.py:75-100
+  eval_step         /root/reference/phase1_lifting/train_1.py:112-145
+  loss_MPJPE        /root/reference/phase1_lifting/train_1.py:19-23
+  epoch_mpjpe_mm    /root/reference/phase1_lifting/train_1.py:100-104
+All arithmetic is in libposelift.so; tensors must live on the ROCm device.
+"""
+import torch
+
+from . import _lib
+
+
+class _MSEFn(torch.autograd.Function):
+    """nn.MSELoss(reduction='mean') with the gradient produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, pred, tgt):
+        _lib.require_device_tensor(pred, "pred")
+        _lib.require_device_tensor(tgt, "target")
+        if pred.shape != tgt.shape:
+            raise ValueError(f"MSE shapes differ: {tuple(pred.shape)} vs {tuple(tgt.shape)}")
+        n = pred.numel()
+        need = pred.requires_grad
+        dpred = torch.empty_like(pred) if need else None
+        loss = torch.empty((), dtype=torch.float32, device=pred.device)
+        scratch = torch.empty(_lib.lib().pl_mse_scratch_bytes(n), dtype=torch.uint8, device=pred.device)
+        with torch.cuda.device(pred.device):
+            rc = _lib.lib().pl_mse_fwd_bwd(pred.data_ptr(), tgt.data_ptr(), n, 1.0,
+                                           dpred.data_ptr() if need else None, loss.data_ptr(),
+                                           scratch.data_ptr(), _lib.current_stream_ptr())
+        _lib.check(rc, "pl_mse_fwd_bwd")
+        ctx.dpred = dpred
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        d = ctx.dpred
+        ctx.dpred = None
+        return (d.mul_(g) if d is not None else None), None
+
+
+def mse_loss(pred, tgt):
+    """torch.nn.MSELoss(reduction="mean")(pred, tgt)  (train_1.py:37,94)."""
+    return _MSEFn.apply(pred.contiguous(), tgt.contiguous())
+
+
+def loss_MPJPE(prediction, target, out=None):
+    """train_1.py:19-23: (B,J,3),(B,J,3) -> (J,) sum over the batch of per-joint L2 errors.
+    With `out`, accumulates into it (the reference's `train_metric_3d +=`)."""
+    prediction, target = prediction.detach().contiguous(), target.detach().contiguous()
+    _lib.require_device_tensor(prediction, "prediction")
+    _lib.require_device_tensor(target, "target")
+    B, J, d = target.shape
+    if d != 3 or prediction.shape != target.shape:
+        raise ValueError("loss_MPJPE expects two (B, J, 3) tensors")
+    metric = out if out is not None else torch.zeros(J, dtype=torch.float32, device=target.device)
+    scratch = torch.empty(_lib.lib().pl_mpjpe_scratch_bytes(B, J), dtype=torch.uint8, device=target.device)
+    with torch.cuda.device(target.device):
+        rc = _lib.lib().pl_mpjpe_accum(prediction.data_ptr(), target.data_ptr(), B, J, metric.data_ptr(),
+                                       scratch.data_ptr(), _lib.current_stream_ptr())
+    _lib.check(rc, "pl_mpjpe_accum")
+    return metric
+
+
+def epoch_mpjpe_mm(metric_sum, n_samples, num_of_joints=17, zero_centre=True):
+    """train_1.py:100-104 reproduced literally: /len(dataset), mean over joints 1..16,
+    then *(17/16)*1000 (mm) when the 17-joint root-centred layout is used."""
+    m = torch.mean((metric_sum / n_samples)[1:17])
+    if num_of_joints == 17 and zero_centre:
+        m = m * (17 / 16) * 1000
+    return m
+
+
+def train_step(model, optimizer, y1, y2, grad_sync=None):
+    """One train_1.py:75-100 step: zero_grad, forward, reshape (B,J,3), MSE(mean), backward,
+    [gradient all-reduce], optimizer.step.  Returns (loss, y2_hat) as device tensors -- the
+    caller decides when to pay the host sync the reference pays every step (train_1.py:98).
+    grad_sync: optional callable(model) -> grad_scale, e.g. dp.GradSync."""
+    optimizer.zero_grad()
+    y1, y2 = y1.float(), y2.float()
+    y2_hat = model(y1).reshape(y2.shape)
+    loss = mse_loss(y2_hat, y2)
+    loss.backward()
+    if grad_sync is not None:
+        optimizer.step(grad_scale=grad_sync(model))
+    else:
+        optimizer.step()
+    return loss, y2_hat
+
+
+@torch.no_grad()
+def eval_step(model, y1, y2, metric_out=None):
+    """train_1.py:112-145 body (model must be in eval mode): forward, MSE, loss_MPJPE."""
+    y1, y2 = y1.float(), y2.float()
+    y2_hat = model(y1).reshape(y2.shape)
+    loss = mse_loss(y2_hat, y2)
+    metric = loss_MPJPE(y2_hat, y2, out=metric_out)
+    return loss, metric, y2_hat

@@ -1,0 +1,146 @@
+/* poselift.h -- C ABI of the MI355X (gfx950) 2D->3D pose-lifting train path.
+ *
+ * The reference (RHnejad/3D_PoseEstimation) has no FFI: its hot path is a plain
+ * PyTorch nn.Module plus a script-level train step.  This header is therefore the
+ * boundary a maintainer binds with ctypes; every entry point
+ * names the reference lines whose computation it replaces.  All paths are relative
+ * to the reference root.
+ *
+ * Conventions
+ *   - plain C, POD arguments, no torch types; device pointers are hipMalloc'ed
+ *     (or torch-owned) fp32 unless stated; every tensor is dense row-major.
+ *   - the caller owns every buffer including the workspace; the library never
+ *     allocates or frees device memory and keeps no device-side global state.
+ *   - every call enqueues work on `stream` and returns; nothing synchronises.
+ *   - return value: PL_OK (0) or a negative PLStatus; pl_last_error() gives the
+ *     thread-local message.  Nothing throws across the ABI.
+ */
+#ifndef POSELIFT_H_
+#define POSELIFT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PL_VERSION 100 /* 0.1.0 */
+
+typedef enum PLStatus {
+  PL_OK = 0,
+  PL_EINVAL = -1,       /* null pointer / bad enum / misaligned arena            */
+  PL_ESHAPE = -2,       /* unsupported shape (hidden % 4 != 0, dims <= 0, ...)   */
+  PL_EDTYPE = -3,       /* unsupported compute dtype                             */
+  PL_EBATCH = -4,       /* B < 2 with training-mode BatchNorm (torch raises too) */
+  PL_EHIP = -5,         /* a HIP runtime call or launch failed                   */
+  PL_EWORKSPACE = -6    /* workspace pointer null or too small                   */
+} PLStatus;
+
+typedef enum PLDtype { PL_F32 = 0, PL_BF16 = 1 } PLDtype;
+
+/* Lifter descriptor: LinearModel(i_dim, o_dim, linear_size, num_stage, p_dropout, BN)
+ * phase1_lifting/baselineModel.py:50-85.
+ *
+ * params     flat fp32 parameter arena.  Tensors appear in the reference's
+ *            parameters() order -- per hidden layer: Linear.weight [out][in],
+ *            Linear.bias, BatchNorm.weight, BatchNorm.bias (BN tensors are present
+ *            even when bn == 0, as in the reference) -- then w2.weight, w2.bias.
+ *            Every tensor starts at a multiple of 64 floats: pl_param_offset().
+ * bn_running [n_hidden][2][hidden] fp32: running_mean then running_var per layer.
+ * bn_batches [n_hidden] int64 num_batches_tracked, or NULL.
+ */
+typedef struct PLDesc {
+  int32_t in_dim;      /* 34 = 17 joints x 2                                  */
+  int32_t hidden;      /* linear_size, multiple of 4                          */
+  int32_t out_dim;     /* 51 = 17 joints x 3                                  */
+  int32_t num_stage;   /* residual blocks; hidden layers = 1 + 2*num_stage    */
+  int32_t bn;          /* BN flag of the reference constructor                */
+  int32_t dtype;       /* PLDtype: arithmetic of the 1024-wide GEMMs          */
+  float p_dropout;     /* nn.Dropout p                                        */
+  float bn_eps;        /* 1e-5 (nn.BatchNorm1d default)                       */
+  float bn_momentum;   /* 0.1                                                 */
+  int32_t reserved;
+  float* params;
+  float* bn_running;
+  int64_t* bn_batches;
+} PLDesc;
+
+int pl_version(void);
+const char* pl_last_error(void);
+
+/* ---- arena layout (host only, no device work) ---------------------------------- */
+int64_t pl_num_hidden(const PLDesc* d);               /* 1 + 2*num_stage            */
+int64_t pl_param_tensors(const PLDesc* d);            /* 4*n_hidden + 2             */
+int64_t pl_param_offset(const PLDesc* d, int64_t i);  /* floats, multiple of 64     */
+int64_t pl_param_numel(const PLDesc* d, int64_t i);
+int64_t pl_param_arena_floats(const PLDesc* d);       /* padded arena length        */
+/* Workspace for B rows: saved activations, masks, BN statistics, gradient scratch. */
+size_t pl_workspace_bytes(const PLDesc* d, int64_t B);
+/* Debug/test view into the workspace.  which: 0 z (pre-BN GEMM output), 1 act (layer
+ * output incl. residual), 2 keep&relu bitmap, 3 batch mean, 4 batch rstd.           */
+int pl_workspace_view(const PLDesc* d, int64_t B, int which, int64_t layer,
+                      size_t* offset_bytes, size_t* size_bytes);
+
+/* ---- forward ------------------------------------------------------------------- */
+/* model.eval(); model(x)   phase1_lifting/baselineModel.py:87-102 under
+ * train_1.py:112-126 (BatchNorm on running statistics, Dropout = identity).
+ * x [B][in_dim], y [B][out_dim]. */
+int pl_lifter_fwd_eval(const PLDesc* d, const float* x, float* y, int64_t B,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* model.train(); model(x)  phase1_lifting/baselineModel.py:87-102 under train_1.py:86.
+ * Updates bn_running / bn_batches like nn.BatchNorm1d (momentum, unbiased running
+ * var).  Dropout keep decisions come from the Philox4x32-10 stream keyed by
+ * (seed, step, layer, element) documented in csrc/philox.h, or -- parity mode --
+ * from inject_keep: n_hidden bitmaps laid out like workspace view 2 (NULL = Philox).
+ * Saves what pl_lifter_bwd needs in the workspace. */
+int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, int64_t B,
+                        void* workspace, size_t workspace_bytes,
+                        uint64_t seed, uint64_t step, const uint64_t* inject_keep,
+                        void* stream);
+
+/* loss.backward() through the module (autograd of baselineModel.py:87-102).
+ * dy [B][out_dim]; flat_grads: arena shaped like d->params, OVERWRITTEN with the
+ * gradient of every parameter; dx [B][in_dim] or NULL (phase5_loop needs it,
+ * train_1.py does not). Must follow pl_lifter_fwd_train on the same workspace. */
+int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, int64_t B,
+                  void* workspace, size_t workspace_bytes, float* dx,
+                  float* flat_grads, void* stream);
+
+/* ---- loss / metric / optimiser -------------------------------------------------- */
+/* torch.nn.MSELoss(reduction="mean") + its backward  train_1.py:37,94-95.
+ * n elements; dpred = grad_scale * 2 (pred - tgt) / n; loss_out: 1 device float.
+ * scratch: >= pl_mse_scratch_bytes(n). dpred may be NULL (validation). */
+size_t pl_mse_scratch_bytes(int64_t n);
+int pl_mse_fwd_bwd(const float* pred, const float* tgt, int64_t n, float grad_scale,
+                   float* dpred, float* loss_out, void* scratch, void* stream);
+
+/* loss_MPJPE  train_1.py:19-23,100: metric[j] += sum_b ||pred[b][j] - tgt[b][j]||_2.
+ * pred/tgt [B][joints][3]; metric [joints] device fp32, accumulated in place. */
+size_t pl_mpjpe_scratch_bytes(int64_t B, int64_t joints);
+int pl_mpjpe_accum(const float* pred, const float* tgt, int64_t B, int64_t joints,
+                   float* metric, void* scratch, void* stream);
+
+/* torch.optim.AdamW.step  train_1.py:39,96 over one flat arena (p, g, m, v of n floats).
+ * t = 1-based step count; g is multiplied by grad_scale first (1/world_size after a
+ * sum all-reduce). */
+int pl_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay,
+                  int64_t t, float grad_scale, void* stream);
+
+/* ---- building blocks exported for tests ------------------------------------------ */
+/* C[M][N] = op(A) op(B) on the fp32 MFMA path.
+ * layout 0 (NT): A [M][K], B [N][K]   (forward  z = a W^T)
+ * layout 1 (NN): A [M][K], B [K][N]   (backward da = dz W)
+ * layout 2 (TN): A [K][M], B [K][N]   (backward dW = dz^T a)
+ * bias [N] or NULL is added to every row. split_k > 1 is allowed for layout 2 only and
+ * needs slab scratch of split_k*M*N floats (NULL otherwise). */
+int pl_gemm_f32(int layout, const float* A, const float* B, float* C, int64_t M,
+                int64_t N, int64_t K, const float* bias, int split_k, float* slabs,
+                void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSELIFT_H_ */

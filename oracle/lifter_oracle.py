@@ -82,8 +82,15 @@ def init_state(in_dim, out_dim, hidden, num_stage, rng, dtype=np.float32,
 # --------------------------------------------------------------------------
 # forward
 # --------------------------------------------------------------------------
-def _hidden_fwd(st, lin, bnp, a_in, train, use_bn, keep, p, dtype, update_running):
-    """Linear -> [BN] -> ReLU -> Dropout   (baselineModel.py:33-37 / 90-94)."""
+def _hidden_fwd(st, lin, bnp, a_in, train, use_bn, keep, p, dtype, update_running, on=None):
+    """Linear -> [BN] -> ReLU -> Dropout   (baselineModel.py:33-37 / 90-94).
+
+    on: optional boolean (B,H) "positive and kept" decisions taken from the implementation
+    under test.  ReLU is discontinuous in its derivative: a pre-activation within round-off
+    of zero may land on either side in two correct fp32 evaluations, and the sample then
+    enters or leaves whole rows of dW.  Forcing the decisions removes that from a comparison;
+    the caller checks separately that every forced decision that differs from the oracle's
+    own sits on such a round-off-sized pre-activation (cache['on_disagree'])."""
     W = st[lin + ".weight"].astype(dtype)
     b = st[lin + ".bias"].astype(dtype)
     z = a_in @ W.T + b
@@ -118,6 +125,16 @@ def _hidden_fwd(st, lin, bnp, a_in, train, use_bn, keep, p, dtype, update_runnin
     else:
         y = z
     rmask = y > 0
+    if on is not None:
+        scale = dtype(1)
+        if train and 0 < p < 1:
+            scale = dtype(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+        own = rmask if keep is None else (rmask & keep)
+        c["on_disagree"] = np.abs(y)[own != on]
+        c.update(keep=None, scale=scale, rmask=on, a_out=np.where(on, y * scale, dtype(0)))
+        # backward reads rmask (decision) and scale through the keep=None branch below
+        c["forced_scale"] = scale
+        return c["a_out"], c
     y = np.where(rmask, y, dtype(0))
     if train and p > 0:
         if p >= 1:
@@ -135,7 +152,7 @@ def _hidden_fwd(st, lin, bnp, a_in, train, use_bn, keep, p, dtype, update_runnin
 
 
 def forward(st, x, *, num_stage=2, train=False, use_bn=True, p_dropout=0.5,
-            keep_masks=None, dtype=np.float32, update_running=True):
+            keep_masks=None, dtype=np.float32, update_running=True, on_masks=None):
     """LinearModel.forward (baselineModel.py:87-102).
 
     keep_masks: list of 1+2*num_stage boolean (B,H) keep masks, required when
@@ -146,19 +163,22 @@ def forward(st, x, *, num_stage=2, train=False, use_bn=True, p_dropout=0.5,
     a = x.reshape(B, -1).astype(dtype)                       # nn.Flatten, :89
     names = hidden_layer_names(num_stage)
     need_masks = train and 0 < p_dropout < 1
-    if need_masks and keep_masks is None:
+    if need_masks and keep_masks is None and on_masks is None:
         raise ValueError("train-mode dropout needs explicit keep masks")
     caches = []
 
     def km(i):
-        return keep_masks[i] if need_masks else None
+        return keep_masks[i] if (need_masks and keep_masks is not None) else None
 
-    h, c = _hidden_fwd(st, *names[0], a, train, use_bn, km(0), p_dropout, dtype, update_running)
+    def om(i):
+        return on_masks[i] if on_masks is not None else None
+
+    h, c = _hidden_fwd(st, *names[0], a, train, use_bn, km(0), p_dropout, dtype, update_running, om(0))
     caches.append(c)
     for s in range(num_stage):                                # :97-98
         i1, i2 = 1 + 2 * s, 2 + 2 * s
-        y, c1 = _hidden_fwd(st, *names[i1], h, train, use_bn, km(i1), p_dropout, dtype, update_running)
-        y, c2 = _hidden_fwd(st, *names[i2], y, train, use_bn, km(i2), p_dropout, dtype, update_running)
+        y, c1 = _hidden_fwd(st, *names[i1], h, train, use_bn, km(i1), p_dropout, dtype, update_running, om(i1))
+        y, c2 = _hidden_fwd(st, *names[i2], y, train, use_bn, km(i2), p_dropout, dtype, update_running, om(i2))
         caches += [c1, c2]
         h = h + y                                             # :45
     W = st["w2.weight"].astype(dtype)
@@ -175,6 +195,8 @@ def _hidden_bwd(st, lin, bnp, c, g, use_bn, dtype):
     dy = np.where(c["rmask"], g, dtype(0))
     if c["keep"] is not None:
         dy = np.where(c["keep"], dy * c["scale"], dtype(0))
+    elif "forced_scale" in c:
+        dy = dy * c["forced_scale"]
     grads = {}
     B = dy.shape[0]
     if use_bn:

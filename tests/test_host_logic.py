@@ -1,0 +1,125 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol declared in
+include/poselift.h, the Python arena layout agrees with the C one, the module mirrors the
+reference's interface (names, order, shapes), and nothing computes without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, golden_state, load_golden
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as ge
+    return ge.build()          # compiles libposelift.so for gfx950 if missing (no GPU needed)
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    header = open(os.path.join(ROOT, "include", "poselift.h")).read()
+    declared = set(re.findall(r"\b(pl_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 18
+    raw = ctypes.CDLL(pkg._lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in include/poselift.h but not exported"
+    assert declared == set(pkg._lib.SIGNATURES), "ctypes signature table out of sync with the header"
+    assert pkg.lib().pl_version() == 100
+
+
+def test_python_layout_matches_c_layout(pkg):
+    for (i, h, o, s) in [(34, 1024, 51, 2), (34, 64, 51, 2), (51, 64, 34, 2), (34, 32, 51, 3), (10, 4, 3, 0)]:
+        d = pkg._lib.PLDesc(in_dim=i, hidden=h, out_dim=o, num_stage=s, bn=1, dtype=0, p_dropout=0.5,
+                            bn_eps=1e-5, bn_momentum=0.1)
+        slots, total = pkg.layout.param_slots(i, h, o, s)
+        L = pkg.lib()
+        assert L.pl_param_tensors(ctypes.byref(d)) == len(slots) == 4 * (1 + 2 * s) + 2
+        assert L.pl_param_arena_floats(ctypes.byref(d)) == total
+        for k, sl in enumerate(slots):
+            assert L.pl_param_offset(ctypes.byref(d), k) == sl.offset and sl.offset % 64 == 0
+            assert L.pl_param_numel(ctypes.byref(d), k) == sl.numel
+        assert L.pl_workspace_bytes(ctypes.byref(d), 64) > 0
+    assert pkg.lib().pl_param_offset(ctypes.byref(d), 999) < 0
+    assert b"out of range" in pkg.lib().pl_last_error()
+
+
+def test_module_mirrors_reference_interface(pkg):
+    g = load_golden("g2_train_nodrop_small.npz")          # state_dict recorded from the reference
+    ref_keys = list(golden_state(g))
+    m = pkg.LinearModel(34, 51, linear_size=64, num_stage=2, p_dropout=0.5, BN=True)
+    sd = m.state_dict()
+    assert list(sd) == ref_keys
+    for k in ref_keys:
+        assert tuple(sd[k].shape) == tuple(g["state:" + k].shape), k
+    assert sd["batch_norm1.num_batches_tracked"].dtype == torch.int64
+    full = pkg.LinearModel(34, 51)
+    assert len(list(full.parameters())) == 22
+    assert sum(p.numel() for p in full.parameters()) == 4_296_755
+    assert [n for n, _ in full.named_parameters()] == [s.name for s in full._slots]
+    # parameters are views into one arena; loading a checkpoint writes through to it
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in golden_state(g).items()})
+    s = m._slots[4]
+    assert torch.equal(m.flat_params[s.offset:s.offset + s.numel].view(s.shape), m.linear_stages[0].w1.weight)
+    assert m._arenas_intact()
+    np.testing.assert_array_equal(m.w2.bias.detach().numpy(), g["state:w2.bias"])
+    m2 = m.double().float()                                 # _apply re-flattens
+    assert m2._arenas_intact() and torch.equal(m2.w2.bias, torch.from_numpy(g["state:w2.bias"]))
+
+
+def test_same_seed_gives_reference_initialisation(pkg):
+    """The containers are stock nn.Linear objects created in the reference's order, so
+    torch.manual_seed(s) reproduces the reference's initial weights (values recorded from the
+    reference by tools/make_golden.py)."""
+    g = load_golden("g7_init_seed0.npz")
+    torch.manual_seed(0)
+    m = pkg.LinearModel(34, 51, p_dropout=0.5, linear_size=1024, BN=True)
+    sd = m.state_dict()
+    for k in [k[5:] for k in g if k.startswith("head:")]:
+        np.testing.assert_array_equal(sd[k].reshape(-1)[:16].numpy(), g["head:" + k])
+        assert abs(float(sd[k].double().sum()) - float(g["sum:" + k])) < 1e-6 * max(1.0, abs(float(g["sum:" + k])))
+
+
+def test_no_cpu_fallback(pkg):
+    m = pkg.LinearModel(34, 51, linear_size=64)
+    with pytest.raises(pkg.PoseliftError, match="no CPU path"):
+        m(torch.zeros(4, 17, 2))
+    with pytest.raises(pkg.PoseliftError):
+        pkg.mse_loss(torch.zeros(4, 3), torch.zeros(4, 3))
+    with pytest.raises(pkg.PoseliftError):
+        pkg.loss_MPJPE(torch.zeros(4, 17, 3), torch.zeros(4, 17, 3))
+    with pytest.raises(pkg.PoseliftError):
+        pkg.FlatAdamW(m).step()
+
+
+def test_bitmap_pack_roundtrip(pkg):
+    rng = np.random.default_rng(0)
+    for H in (32, 64, 256, 320, 1024):
+        keep = rng.random((9, H)) < 0.5
+        words = pkg.layout.pack_keep_bitmap(keep)
+        assert words.shape == (9, pkg.layout.bitmap_words_per_row(H)) and words.dtype == np.uint64
+        assert (pkg.layout.unpack_bitmap(words, H) == keep).all()
+    # documented bit position: column 256*q + 4*l + j  ->  word 4*q + j, bit l
+    keep = np.zeros((1, 512), bool)
+    keep[0, 256 + 4 * 5 + 2] = True
+    words = pkg.layout.pack_keep_bitmap(keep)
+    assert words[0, 4 + 2] == np.uint64(1) << np.uint64(5) and words.sum() == words[0, 6]
+
+
+def test_synthetic_batches_are_h36m_shaped(pkg, h36m_stats):
+    x, y = pkg.synth.synthetic_batch(2048, 1234)
+    assert x.shape == (2048, 17, 2) and y.shape == (2048, 17, 3) and x.dtype == torch.float32
+    assert float(x.min()) >= 0 and float(x.max()) <= 1 and torch.all(y[:, 0] == 0)
+    np.testing.assert_allclose(x.mean(0).numpy(), h36m_stats["mean_train_2d"], atol=0.02)
+    np.testing.assert_allclose(y.std(0).numpy()[1:], h36m_stats["std_train_3d"][1:], rtol=0.1)
+    x2, _ = pkg.synth.synthetic_batch(2048, 1234)
+    assert torch.equal(x, x2)
+
+
+def test_shard_rows_partitions_exactly(pkg):
+    for n, w in [(32768, 8), (4096, 1), (10, 4), (7, 8)]:
+        spans = [pkg.dp.shard_rows(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1

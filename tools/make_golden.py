@@ -193,8 +193,15 @@ def main():
     np.savez(os.path.join(OUT, "g5_mpjpe.npz"), pred=a, tgt=b, metric=metric.numpy(),
              epoch_mm=np.float64(epoch.item()))
 
-    # ---- G7: weight_init (baselineModel.py:10-12) leaves biases/BN alone ---------------
-    # (recorded as a property, not as values: kaiming_normal consumes the torch RNG)
+    # ---- G7: initial weights of the reference under torch.manual_seed(0) -----------------
+    torch.manual_seed(0)
+    m = ref.LinearModel(34, 51, p_dropout=0.5, linear_size=1024, BN=True)
+    rec = {}
+    for k, v in m.state_dict().items():
+        if v.dtype == torch.float32:
+            rec["head:" + k] = v.reshape(-1)[:16].numpy().copy()
+            rec["sum:" + k] = np.float64(v.double().sum().item())
+    np.savez(os.path.join(OUT, "g7_init_seed0.npz"), **rec)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
