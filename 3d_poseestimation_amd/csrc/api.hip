@@ -78,6 +78,16 @@ int tn_splits(int M, int N, int K) {
   return s < 1 ? 1 : s;
 }
 
+// Output layer y = h W^T + b with N = out_dim (51): only ceil(M/128) tiles, so the K = hidden
+// contraction is split over workgroups (slabs) until the chip is full, then reduced with the bias.
+int out_splits(int M, int N, int K) {
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int s = 256 / tiles;
+  const int kmax = K / 128;
+  if (s > kmax) s = kmax;
+  return s < 1 ? 1 : s;
+}
+
 // Workspace plan; every region starts on a 256-byte boundary.
 struct Ws {
   int L, G, RC;
@@ -125,6 +135,10 @@ Ws plan(const PLDesc* d, int64_t B) {
   need(H, d->in_dim);
   need(H, H);
   need(d->out_dim, H);
+  {
+    const int so = out_splits((int)B, d->out_dim, H);
+    if (so > 1) slab = std::max(slab, (size_t)so * B * d->out_dim * 4);
+  }
   w.slabs = take(slab);
   w.outpart = take((size_t)colsum_chunks((int)B) * d->out_dim * 4);
   w.total = o;
@@ -165,6 +179,20 @@ int check_ws(const Ws& w, void* ws, size_t bytes) {
   if (reinterpret_cast<uintptr_t>(ws) & 255) PL_FAIL(PL_EWORKSPACE, "workspace not 256-byte aligned");
   if (bytes < w.total) PL_FAIL(PL_EWORKSPACE, "workspace too small: %zu < %zu bytes", bytes, w.total);
   return PL_OK;
+}
+
+int gemm_out_layer(const float* h, const float* W, const float* bias, float* y, int M, int N, int K,
+                   float* slabs, hipStream_t s) {
+  GemmArgs g = {};
+  g.A = h; g.B = W; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
+  const int splits = out_splits(M, N, K);
+  if (splits > 1) {
+    g.C = slabs; g.split_k = splits;
+    PL_TRY(launch_gemm_f32(kNT, g, s));
+    return launch_reduce_slabs_bias(slabs, splits, M, N, bias, y, s);
+  }
+  g.C = y; g.bias = bias; g.split_k = 1;
+  return launch_gemm_f32(kNT, g, s);
 }
 
 // C[M][N] (+slab reduce) = A^T B with A [K][M], B [K][N]
@@ -263,10 +291,8 @@ extern "C" int pl_lifter_fwd_eval(const PLDesc* d, const float* x, float* y, int
     PL_TRY(launch_gemm_f32(kNT, g, s));
     a_in = g.C;
   }
-  GemmArgs g = {};
-  g.A = a_in; g.B = d->params + P.off[4 * w.L]; g.C = y; g.bias = d->params + P.off[4 * w.L + 1];
-  g.M = (int)B; g.N = d->out_dim; g.K = H; g.lda = H; g.ldb = H; g.ldc = d->out_dim; g.split_k = 1;
-  return launch_gemm_f32(kNT, g, s);
+  return gemm_out_layer(a_in, d->params + P.off[4 * w.L], d->params + P.off[4 * w.L + 1], y, (int)B,
+                        d->out_dim, H, f32(ws, w.slabs), s);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -309,10 +335,8 @@ extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, in
                            inject_keep ? inject_keep + (size_t)l * inj_stride : nullptr, s));
     a_in = f32(ws, w.act[l]);
   }
-  GemmArgs g = {};
-  g.A = a_in; g.B = d->params + P.off[4 * w.L]; g.C = y; g.bias = d->params + P.off[4 * w.L + 1];
-  g.M = (int)B; g.N = d->out_dim; g.K = H; g.lda = H; g.ldb = H; g.ldc = d->out_dim; g.split_k = 1;
-  return launch_gemm_f32(kNT, g, s);
+  return gemm_out_layer(a_in, d->params + P.off[4 * w.L], d->params + P.off[4 * w.L + 1], y, (int)B,
+                        d->out_dim, H, f32(ws, w.slabs), s);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -404,4 +428,13 @@ extern "C" int pl_gemm_f32(int layout, const float* A, const float* Bm, float* C
     return launch_reduce_slabs(slabs, split_k, M * N, C, s);
   }
   return launch_gemm_f32((GemmLayout)layout, g, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// measurement hook (bench.py): per-launch GEMM durations from HIP events on the launch stream
+// ---------------------------------------------------------------------------------------
+extern "C" int pl_prof_enable(int on) { return prof_enable(on); }
+extern "C" int pl_prof_read(double min_flops, double* ms_total, int64_t* launches, double* flops_total) {
+  if (!ms_total || !launches || !flops_total) PL_FAIL(PL_EINVAL, "pl_prof_read: null pointer");
+  return prof_read(min_flops, ms_total, launches, flops_total);
 }

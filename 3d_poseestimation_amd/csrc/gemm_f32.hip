@@ -24,6 +24,9 @@
 //     ReLU + skip, and training-mode BatchNorm partial statistics (column sum and M2 per
 //     64-row group, merged later with Chan's formula -- no E[z^2]-E[z]^2 cancellation).
 //   * blockIdx -> tile map gives each XCD (private 4 MiB L2) a contiguous band of M-tiles.
+#include <type_traits>
+#include <vector>
+
 #include "pl_internal.h"
 
 namespace pl {
@@ -38,60 +41,81 @@ constexpr int KS_LD = 128 + 4;            // 132 floats = 33 x 16 B
 constexpr int OP_FLOATS = 128 * KC_LD;    // 4608 >= 32*132
 constexpr int LDS_FLOATS = 4 * OP_FLOATS; // 2 operands x 2 buffers = 73,728 B
 
-// Global -> registers: 4 float4 per thread per operand tile.
-template <bool KS>
-__device__ __forceinline__ void load_tile(const float* __restrict__ base, int ld, int r0, int R,
-                                          int k0, int Kend, bool vec_ok, int tid,
-                                          float4 (&reg)[4]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + NTHR * i;
-    if (!KS) {
-      const int gr = r0 + (idx >> 3);
-      const int gk = k0 + (idx & 7) * 4;
-      const float* p = base + (size_t)gr * ld + gk;
-      if (vec_ok && gr < R && gk + 3 < Kend) {
-        reg[i] = *reinterpret_cast<const float4*>(p);
-      } else {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gr < R) {
-          if (gk + 0 < Kend) v.x = p[0];
-          if (gk + 1 < Kend) v.y = p[1];
-          if (gk + 2 < Kend) v.z = p[2];
-          if (gk + 3 < Kend) v.w = p[3];
-        }
-        reg[i] = v;
-      }
-    } else {
-      const int gk = k0 + (idx >> 5);
-      const int gr = r0 + (idx & 31) * 4;
-      const float* p = base + (size_t)gk * ld + gr;
-      if (vec_ok && gk < Kend && gr + 3 < R) {
-        reg[i] = *reinterpret_cast<const float4*>(p);
-      } else {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (gk < Kend) {
-          if (gr + 0 < R) v.x = p[0];
-          if (gr + 1 < R) v.y = p[1];
-          if (gr + 2 < R) v.z = p[2];
-          if (gr + 3 < R) v.w = p[3];
-        }
-        reg[i] = v;
-      }
+// Global -> registers: 4 float4 per thread per operand tile, held in NAMED registers (a
+// float4[4] passed by reference ends up in scratch memory under hipcc once scheduling
+// barriers are present).  EDGE=false is the hot path: whole tiles, 16-byte aligned rows, no
+// guards -- eight back-to-back global_load_dwordx4 per thread and K tile.
+struct Stage { float4 v0, v1, v2, v3; };
+
+template <bool KS, bool EDGE>
+__device__ __forceinline__ float4 load_one(const float* __restrict__ base, int ld, int r0, int R,
+                                           int k0, int Kend, bool vec_ok, int idx) {
+  if (!KS) {
+    const int gr = r0 + (idx >> 3);
+    const int gk = k0 + (idx & 7) * 4;
+    const float* p = base + (size_t)gr * ld + gk;
+    if (!EDGE || (vec_ok && gr < R && gk + 3 < Kend)) return *reinterpret_cast<const float4*>(p);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gr < R) {
+      if (gk + 0 < Kend) v.x = p[0];
+      if (gk + 1 < Kend) v.y = p[1];
+      if (gk + 2 < Kend) v.z = p[2];
+      if (gk + 3 < Kend) v.w = p[3];
     }
+    return v;
+  } else {
+    const int gk = k0 + (idx >> 5);
+    const int gr = r0 + (idx & 31) * 4;
+    const float* p = base + (size_t)gk * ld + gr;
+    if (!EDGE || (vec_ok && gk < Kend && gr + 3 < R)) return *reinterpret_cast<const float4*>(p);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gk < Kend) {
+      if (gr + 0 < R) v.x = p[0];
+      if (gr + 1 < R) v.y = p[1];
+      if (gr + 2 < R) v.z = p[2];
+      if (gr + 3 < R) v.w = p[3];
+    }
+    return v;
   }
 }
 
-template <bool KS>
-__device__ __forceinline__ void store_tile(float* __restrict__ s, int tid, const float4 (&reg)[4]) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = tid + NTHR * i;
-    if (!KS)
-      *reinterpret_cast<float4*>(s + (idx >> 3) * KC_LD + (idx & 7) * 4) = reg[i];
-    else
-      *reinterpret_cast<float4*>(s + (idx >> 5) * KS_LD + (idx & 31) * 4) = reg[i];
+template <bool KS, bool EDGE>
+__device__ __forceinline__ Stage load_tile(const float* __restrict__ base, int ld, int r0, int R,
+                                           int k0, int Kend, bool vec_ok, int tid) {
+  Stage s;
+  if (!EDGE) {
+    // wave-uniform tile origin (scalar registers) + per-thread 32-bit element offsets: the loads
+    // become `global_load_dwordx4 v, voff, s[base]` with no per-tile 64-bit address arithmetic
+    const float* t = KS ? base + (size_t)k0 * ld + r0 : base + (size_t)r0 * ld + k0;
+    const int o0 = KS ? (tid >> 5) * ld + (tid & 31) * 4 : (tid >> 3) * ld + (tid & 7) * 4;
+    const int step = KS ? 8 * ld : 32 * ld;     // 256 threads further on: +8 k rows / +32 rows
+    s.v0 = *reinterpret_cast<const float4*>(t + o0);
+    s.v1 = *reinterpret_cast<const float4*>(t + o0 + step);
+    s.v2 = *reinterpret_cast<const float4*>(t + o0 + 2 * step);
+    s.v3 = *reinterpret_cast<const float4*>(t + o0 + 3 * step);
+    return s;
   }
+  s.v0 = load_one<KS, EDGE>(base, ld, r0, R, k0, Kend, vec_ok, tid);
+  s.v1 = load_one<KS, EDGE>(base, ld, r0, R, k0, Kend, vec_ok, tid + NTHR);
+  s.v2 = load_one<KS, EDGE>(base, ld, r0, R, k0, Kend, vec_ok, tid + 2 * NTHR);
+  s.v3 = load_one<KS, EDGE>(base, ld, r0, R, k0, Kend, vec_ok, tid + 3 * NTHR);
+  return s;
+}
+
+template <bool KS>
+__device__ __forceinline__ void store_one(float* __restrict__ s, int idx, float4 v) {
+  if (!KS)
+    *reinterpret_cast<float4*>(s + (idx >> 3) * KC_LD + (idx & 7) * 4) = v;
+  else
+    *reinterpret_cast<float4*>(s + (idx >> 5) * KS_LD + (idx & 31) * 4) = v;
+}
+
+template <bool KS>
+__device__ __forceinline__ void store_tile(float* __restrict__ s, int tid, const Stage& g) {
+  store_one<KS>(s, tid, g.v0);
+  store_one<KS>(s, tid + NTHR, g.v1);
+  store_one<KS>(s, tid + 2 * NTHR, g.v2);
+  store_one<KS>(s, tid + 3 * NTHR, g.v3);
 }
 
 // Fragment fetch for one 8-wide k chunk: f[t][j] feeds MFMA j of 32x32 tile t.
@@ -111,7 +135,7 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ s, int row0,
   }
 }
 
-template <bool A_KS, bool B_KS>
+template <bool A_KS, bool B_KS, bool EDGE>
 __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];   // one static array (73,728 B)
 
@@ -150,44 +174,102 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  float4 ra[4], rb[4];
+  // ---- main loop -------------------------------------------------------------------------
+  // Three-stage operand pipeline + double-buffered fragments:
+  //   * tile kt is consumed from LDS buffer kt&1 while tile kt+1 (already in registers) is
+  //     written to the other buffer and tile kt+2 is in flight from L2/HBM;
+  //   * the fragments of 8-wide k chunk c+1 are fetched from LDS while the 16 MFMAs of chunk
+  //     c run (hipcc on its own issues them one MFMA ahead and exposes the ~300-cycle LDS
+  //     latency four times per tile: 72 % -> MFMA-bound);
+  //   * the one barrier per tile sits between chunk 2 and chunk 3: by then every wave has
+  //     fetched its last fragments of this buffer (so the next step may overwrite it) and
+  //     has long since written the other buffer (so chunk 3 can prefetch the next tile's
+  //     first fragments from it) -- the MFMA pipe never drains at a tile boundary.
+  float fa[2][2][4], fb[2][2][4];
+#define PL_FRAGS(set, buf, c8)                                        \
+  do {                                                                \
+    read_frag<A_KS>((buf), wm * 64, (c8), i, h, fa[set]);             \
+    read_frag<B_KS>((buf) + OP_FLOATS, wn * 64, (c8), i, h, fb[set]); \
+  } while (0)
+#define PL_MFMAS(set)                                                                           \
+  do {                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                               \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                               \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b)                                               \
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][a][j], fb[set][b][j], acc[a][b], 0, 0, 0); \
+  } while (0)
+
+  // Instruction mix of one steady-state step: 64 MFMAs (64 cycles each on the matrix pipe),
+  // 8 ds_write_b128, 8 global_load_dwordx4 and the fragment ds_reads.  Left in a lump between
+  // MFMA groups they idle the pipe ~700 cycles per tile; sched_group_barrier threads ONE of
+  // them into each MFMA shadow instead.
+  Stage ra, rb;
+  constexpr int NFR = (A_KS ? 8 : 2) + (B_KS ? 8 : 2);   // ds_read instructions per fragment set
+#define PL_SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
+  auto step = [&](const int kt, auto do_store, auto do_load, auto has_next) {
+    const float* cur = lds + (kt & 1) * 2 * OP_FLOATS;
+    float* nxt = lds + ((kt + 1) & 1) * 2 * OP_FLOATS;
+    if (do_store.value) {
+      store_tile<A_KS>(nxt, tid, ra);
+      store_tile<B_KS>(nxt + OP_FLOATS, tid, rb);
+    }
+    if (do_load.value) {
+      const int k0 = kbeg + (kt + 2) * BK;
+      ra = load_tile<A_KS, EDGE>(p.A, p.lda, m0, p.M, k0, kend, a_vec, tid);
+      rb = load_tile<B_KS, EDGE>(p.B, p.ldb, n0, p.N, k0, kend, b_vec, tid);
+    }
+    PL_FRAGS(1, cur, 1);
+    PL_MFMAS(0);
+    PL_FRAGS(0, cur, 2);
+    PL_MFMAS(1);
+    PL_FRAGS(1, cur, 3);
+    PL_MFMAS(0);
+    // ---- schedule of the region above (one basic block) ----
+    PL_SGB(0x100, NFR);                                     // fragments of chunk 1 first
+    if (do_store.value) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { PL_SGB(0x008, 1); PL_SGB(0x200, 1); }
+    } else {
+      PL_SGB(0x008, 8);
+    }
+    if (do_load.value) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { PL_SGB(0x008, 1); PL_SGB(0x020, 1); }
+    } else {
+      PL_SGB(0x008, 8);
+    }
+    PL_SGB(0x100, NFR); PL_SGB(0x008, 16);
+    PL_SGB(0x100, NFR); PL_SGB(0x008, 16);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next.value) PL_FRAGS(0, nxt, 0);
+    PL_MFMAS(1);
+    PL_SGB(0x100, NFR); PL_SGB(0x008, 16);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+
   if (nk > 0) {
-    load_tile<A_KS>(p.A, p.lda, m0, p.M, kbeg, kend, a_vec, tid, ra);
-    load_tile<B_KS>(p.B, p.ldb, n0, p.N, kbeg, kend, b_vec, tid, rb);
+    ra = load_tile<A_KS, EDGE>(p.A, p.lda, m0, p.M, kbeg, kend, a_vec, tid);
+    rb = load_tile<B_KS, EDGE>(p.B, p.ldb, n0, p.N, kbeg, kend, b_vec, tid);
     store_tile<A_KS>(lds, tid, ra);
     store_tile<B_KS>(lds + OP_FLOATS, tid, rb);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const float* As = lds + (kt & 1) * 2 * OP_FLOATS;
-    const float* Bs = As + OP_FLOATS;
-    const bool more = kt + 1 < nk;
-    if (more) {
-      const int k0 = kbeg + (kt + 1) * BK;
-      load_tile<A_KS>(p.A, p.lda, m0, p.M, k0, kend, a_vec, tid, ra);
-      load_tile<B_KS>(p.B, p.ldb, n0, p.N, k0, kend, b_vec, tid, rb);
-    }
-#pragma unroll
-    for (int c8 = 0; c8 < BK / 8; ++c8) {
-      float fa[2][4], fb[2][4];
-      read_frag<A_KS>(As, wm * 64, c8, i, h, fa);
-      read_frag<B_KS>(Bs, wn * 64, c8, i, h, fb);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 2; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][j], fb[b][j], acc[a][b], 0, 0, 0);
-    }
-    if (more) {
-      float* An = lds + ((kt + 1) & 1) * 2 * OP_FLOATS;
-      store_tile<A_KS>(An, tid, ra);
-      store_tile<B_KS>(An + OP_FLOATS, tid, rb);
+    if (nk > 1) {
+      ra = load_tile<A_KS, EDGE>(p.A, p.lda, m0, p.M, kbeg + BK, kend, a_vec, tid);
+      rb = load_tile<B_KS, EDGE>(p.B, p.ldb, n0, p.N, kbeg + BK, kend, b_vec, tid);
     }
     __syncthreads();
+    PL_FRAGS(0, lds, 0);
+    int kt = 0;
+    for (; kt + 2 < nk; ++kt) step(kt, T{}, T{}, T{});
+    if (kt + 1 < nk) { step(kt, T{}, F{}, T{}); ++kt; }
+    step(kt, F{}, F{}, F{});
   }
+#undef PL_SGB
+#undef PL_FRAGS
+#undef PL_MFMAS
 
   // ---- epilogue ----------------------------------------------------------------------------
   // acc[a][b][r]: row = m0 + wm*64 + a*32 + (r&3) + 8*(r>>2) + 4*h, col = n0 + wn*64 + b*32 + i
@@ -196,7 +278,7 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
   for (int b = 0; b < 2; ++b) {
     const int col = n0 + wn * 64 + b * 32 + i;
-    const bool cok = col < p.N;
+    const bool cok = !EDGE || col < p.N;
     float bias = 0.f, scale = 1.f, shift = 0.f;
     if (!plain && cok) {
       if (p.bias) bias = p.bias[col];
@@ -211,13 +293,13 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(GemmArgs p) {
         float v = acc[a][b][r];
         if (!plain) {
           v += bias;
-          if (p.addend && cok && row < p.M) v += p.addend[(size_t)row * p.ldc + col];
+          if (p.addend && cok && (!EDGE || row < p.M)) v += p.addend[(size_t)row * p.ldc + col];
           if (p.col_scale) v = fmaf(v, scale, shift);
           if (p.relu) v = fmaxf(v, 0.f);
-          if (p.resid && cok && row < p.M) v += p.resid[(size_t)row * p.ldc + col];
+          if (p.resid && cok && (!EDGE || row < p.M)) v += p.resid[(size_t)row * p.ldc + col];
         }
         acc[a][b][r] = v;
-        if (row < p.M) ssum += v;
+        if (!EDGE || row < p.M) ssum += v;
       }
     if (!plain && p.stat_sum) {
       // column statistics over this wavefront's 64 rows (both lane halves)
@@ -232,7 +314,7 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(GemmArgs p) {
         for (int r = 0; r < 16; ++r) {
           const int row = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
           const float d = acc[a][b][r] - mean;
-          if (row < p.M) m2 = fmaf(d, d, m2);
+          if (!EDGE || row < p.M) m2 = fmaf(d, d, m2);
         }
       m2 += __shfl_xor(m2, 32);
       if (h == 0 && cok) {
@@ -246,7 +328,7 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
-        if (cok && row < p.M) C[(size_t)row * p.ldc + col] = acc[a][b][r];
+        if (cok && (!EDGE || row < p.M)) C[(size_t)row * p.ldc + col] = acc[a][b][r];
       }
   }
 }
@@ -254,6 +336,48 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(GemmArgs p) {
 }  // namespace
 
 int gemm_stat_groups(int M) { return 2 * ((M + BM - 1) / BM); }
+
+// ---- measurement hook: HIP events around every GEMM launch, on the launch stream ------------
+namespace {
+struct ProfRec { hipEvent_t e0, e1; double flops; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_pool;     // events are created once and reused
+size_t g_prof_used = 0;
+}  // namespace
+
+int prof_enable(int on) {
+  g_prof_on = on != 0;
+  g_prof_used = 0;
+  return PL_OK;
+}
+
+int prof_read(double min_flops, double* ms_total, int64_t* launches, double* flops_total) {
+  double ms = 0, fl = 0;
+  int64_t n = 0;
+  for (size_t i = 0; i < g_prof_used; ++i) {
+    const ProfRec& r = g_prof_pool[i];
+    if (r.flops < min_flops) continue;
+    if (hipEventSynchronize(r.e1) != hipSuccess) PL_FAIL(PL_EHIP, "prof_read: event sync failed");
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) PL_FAIL(PL_EHIP, "prof_read: elapsed time failed");
+    ms += t; fl += r.flops; ++n;
+  }
+  *ms_total = ms; *launches = n; *flops_total = fl;
+  return PL_OK;
+}
+
+static ProfRec* prof_begin(const GemmArgs& a, hipStream_t s) {
+  if (!g_prof_on) return nullptr;
+  if (g_prof_used == g_prof_pool.size()) {
+    ProfRec r;
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return nullptr;
+    g_prof_pool.push_back(r);
+  }
+  ProfRec* r = &g_prof_pool[g_prof_used++];
+  r->flops = 2.0 * a.M * a.N * a.K;
+  (void)hipEventRecord(r->e0, s);
+  return r;
+}
 
 int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s) {
   if (!a.A || !a.B || !a.C) PL_FAIL(PL_EINVAL, "gemm_f32: null operand");
@@ -264,12 +388,25 @@ int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s) {
   const int splits = a.split_k > 1 ? a.split_k : 1;
   dim3 grid(tiles, 1, splits), block(NTHR);
   const size_t lds_bytes = 0;   // LDS is static
+  ProfRec* prof = prof_begin(a, s);
+  // hot path: whole 128x128x32 tiles in every split, 16-byte aligned rows
+  const int kper = splits > 1 ? (((a.K + splits - 1) / splits) + BK - 1) / BK * BK : a.K;
+  const bool whole = (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0) && (kper * splits == a.K || splits == 1) &&
+                     (a.lda % 4 == 0) && (a.ldb % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0) && ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0);
+#define PL_GEMM_LAUNCH(AKS, BKS)                                                                          \
+  do {                                                                                                    \
+    if (whole) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false>), grid, block, lds_bytes, s, a);      \
+    else hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, true>), grid, block, lds_bytes, s, a);             \
+  } while (0)
   switch (layout) {
-    case kNT: hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, lds_bytes, s, a); break;
-    case kNN: hipLaunchKernelGGL((gemm_f32_kernel<false, true>), grid, block, lds_bytes, s, a); break;
-    case kTN: hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, lds_bytes, s, a); break;
+    case kNT: PL_GEMM_LAUNCH(false, false); break;
+    case kNN: PL_GEMM_LAUNCH(false, true); break;
+    case kTN: PL_GEMM_LAUNCH(true, true); break;
     default: PL_FAIL(PL_EINVAL, "gemm_f32: bad layout %d", (int)layout);
   }
+#undef PL_GEMM_LAUNCH
+  if (prof) (void)hipEventRecord(prof->e1, s);
   PL_CHECK_LAUNCH("gemm_f32");
   return PL_OK;
 }

@@ -57,6 +57,8 @@ struct GemmArgs {
 
 int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s);
 int gemm_stat_groups(int M);  // number of 64-row groups the stats epilogue emits
+int prof_enable(int on);
+int prof_read(double min_flops, double* ms_total, int64_t* launches, double* flops_total);
 
 // ---------------------------------------------------------------------------------
 // streaming kernels (elementwise.hip)
@@ -90,6 +92,9 @@ int launch_bn_bwd_dz(const float* g, const uint64_t* bits, const float* z, const
 
 // out[i] = sum_s slabs[s*n + i]
 int launch_reduce_slabs(const float* slabs, int nslab, int64_t n, float* out, hipStream_t s);
+// out[r][c] = bias[c] + sum_s slabs[s][r][c]
+int launch_reduce_slabs_bias(const float* slabs, int nslab, int rows, int cols, const float* bias,
+                             float* out, hipStream_t s);
 // partial column sums of X[rows][cols] -> part[RC][cols], RC = colsum_chunks(rows)
 int colsum_chunks(int rows);
 int launch_colsum_partial(const float* X, int rows, int cols, float* part, hipStream_t s);

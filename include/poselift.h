@@ -140,6 +140,13 @@ int pl_gemm_f32(int layout, const float* A, const float* B, float* C, int64_t M,
                 int64_t N, int64_t K, const float* bias, int split_k, float* slabs,
                 void* stream);
 
+/* ---- measurement hook (bench.py; not part of the reference interface) ------------------ */
+/* While enabled, every GEMM launch is bracketed by two HIP events recorded on the launch
+ * stream.  pl_prof_read waits for them and sums the durations of the launches whose
+ * algorithmic work 2*M*N*K is >= min_flops.  Enabling resets the record.  Not capturable. */
+int pl_prof_enable(int on);
+int pl_prof_read(double min_flops, double* ms_total, int64_t* launches, double* flops_total);
+
 #ifdef __cplusplus
 }
 #endif
