@@ -363,7 +363,10 @@ extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, i
   const float* h_last = f32(ws, w.act[w.L - 1]);
   PL_TRY(gemm_tn_reduced(dy, O, h_last, H, grads + P.off[4 * w.L], O, H, Bi, slabs, s));
   PL_TRY(launch_colsum_partial(dy, Bi, O, f32(ws, w.outpart), s));
-  PL_TRY(launch_reduce_slabs(f32(ws, w.outpart), colsum_chunks(Bi), O, grads + P.off[4 * w.L + 1], s));
+  // bias gradients = column sums of partials; all of them are reduced by ONE launch at the end
+  std::vector<const float*> jpart; std::vector<float*> jout; std::vector<int> jR, jH;
+  jpart.push_back(f32(ws, w.outpart)); jout.push_back(grads + P.off[4 * w.L + 1]);
+  jR.push_back(colsum_chunks(Bi)); jH.push_back(O);
   {
     GemmArgs g = {};
     g.A = dy; g.B = W5; g.C = GA; g.M = Bi; g.N = H; g.K = O; g.lda = O; g.ldb = H; g.ldc = H; g.split_k = 1;
@@ -377,6 +380,8 @@ extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, i
     const uint64_t* bits = u64(ws, w.bits[l]);
     const float* z = f32(ws, w.z[l]);
     if (d->bn) {
+      // (pass 1 was tried inside the producing GEMM's epilogue: +17 us per GEMM for the 7.5 us
+      //  kernel it removed -- every tile finishes at once, so epilogue work is pure tail)
       PL_TRY(launch_bn_bwd_reduce(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), kscale, Bi, H,
                                   f32(ws, w.stat_a), f32(ws, w.stat_b), s));
       PL_TRY(launch_bn_bwd_finalize(f32(ws, w.stat_a), f32(ws, w.stat_b), w.RC, Bi, H, ly.gamma,
@@ -387,23 +392,31 @@ extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, i
     }
     PL_TRY(launch_bn_bwd_dz(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), f32(ws, w.coef), kscale,
                             d->bn, Bi, H, DZ, f32(ws, w.dbpart[l]), s));
-    PL_TRY(launch_reduce_slabs(f32(ws, w.dbpart[l]), w.RC, H, ly.gb, s));
+    jpart.push_back(f32(ws, w.dbpart[l])); jout.push_back(ly.gb); jR.push_back(w.RC); jH.push_back(H);
     const float* a_in = l == 0 ? x : f32(ws, w.act[l - 1]);
-    PL_TRY(gemm_tn_reduced(DZ, H, a_in, ly.K, ly.gW, H, ly.K, Bi, slabs, s));
     if (l > 0) {
-      // da_in = dz W ; a residual block's first Linear also receives the skip gradient (in GA)
+      // da_in = dz W and dW = dz^T a_in share dz and are independent: ONE launch.  A residual
+      // block's first Linear also receives the skip gradient (in GA, added in the epilogue).
       GemmArgs g = {};
       g.A = DZ; g.B = ly.W; g.M = Bi; g.N = H; g.K = H; g.lda = H; g.ldb = H; g.ldc = H; g.split_k = 1;
       if (l % 2 == 1) { g.C = GA; g.addend = GA; } else { g.C = GB; }
-      PL_TRY(launch_gemm_f32(kNN, g, s));
-    } else if (dx) {
+      GemmArgs t = {};
+      t.A = DZ; t.B = a_in; t.M = H; t.N = H; t.K = Bi; t.lda = H; t.ldb = H; t.ldc = H;
+      const int splits = tn_splits(H, H, Bi);
+      t.split_k = splits; t.C = splits > 1 ? slabs : ly.gW;
+      PL_TRY(launch_gemm_f32_pair(g, t, s));
+      if (splits > 1) PL_TRY(launch_reduce_slabs(slabs, splits, (int64_t)H * H, ly.gW, s));
+    } else {
+      PL_TRY(gemm_tn_reduced(DZ, H, a_in, ly.K, ly.gW, H, ly.K, Bi, slabs, s));
+    }
+    if (l == 0 && dx) {
       GemmArgs g = {};
       g.A = DZ; g.B = ly.W; g.C = dx; g.M = Bi; g.N = d->in_dim; g.K = H; g.lda = H; g.ldb = d->in_dim;
       g.ldc = d->in_dim; g.split_k = 1;
       PL_TRY(launch_gemm_f32(kNN, g, s));
     }
   }
-  return PL_OK;
+  return launch_reduce_rows_multi(jpart.data(), jR.data(), jH.data(), jout.data(), (int)jpart.size(), s);
 }
 
 // ---------------------------------------------------------------------------------------

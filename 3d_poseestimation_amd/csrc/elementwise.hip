@@ -317,14 +317,38 @@ __global__ void reduce_slabs_bias_kernel(const float* __restrict__ slabs, int ns
   }
 }
 
-__global__ void colsum_partial_kernel(const float* __restrict__ X, int rows, int cols, int rpc,
-                                      float* __restrict__ part) {
+// block = 4 row-lanes x 64 column-lanes; fixed-order combine through LDS
+__global__ __launch_bounds__(NTHR) void colsum_partial_kernel(const float* __restrict__ X, int rows,
+                                                              int cols, int rpc, float* __restrict__ part) {
+  __shared__ float sm[4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int r0 = blockIdx.x * rpc, r1 = min(rows, r0 + rpc);
-  for (int c = threadIdx.x; c < cols; c += blockDim.x) {
+  for (int c0 = 0; c0 < cols; c0 += 64) {
+    const int c = c0 + cl;
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += X[(size_t)r * cols + c];
-    part[(size_t)blockIdx.x * cols + c] = s;
+    if (c < cols)
+      for (int r = r0 + rl; r < r1; r += 4) s += X[(size_t)r * cols + c];
+    sm[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) part[(size_t)blockIdx.x * cols + c] = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
+    __syncthreads();
   }
+}
+
+// several independent reduce_rows problems in one launch: blockIdx.y = job
+struct RowJobs { const float* part[8]; float* out[8]; int R[8]; int H[8]; };
+__global__ __launch_bounds__(NTHR) void reduce_rows_multi_kernel(RowJobs j) {
+  __shared__ float red[RPARTS][RCOLS];
+  const int job = blockIdx.y;
+  const int R = j.R[job], H = j.H[job];
+  const float* __restrict__ part = j.part[job];
+  const int cl = threadIdx.x & (RCOLS - 1), p = threadIdx.x / RCOLS;
+  const int c = blockIdx.x * RCOLS + cl;
+  float a = 0.f;
+  if (c < H)
+    for (int k = p; k < R; k += RPARTS) a += part[(size_t)k * H + c];
+  const float t = parts_sum(a, red, cl, p);
+  if (p == 0 && c < H) j.out[job][c] = t;
 }
 
 __global__ void bn_fold_eval_kernel(const float* __restrict__ bias, const float* __restrict__ gamma,
@@ -554,6 +578,22 @@ int launch_reduce_slabs_bias(const float* slabs, int nslab, int rows, int cols, 
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(reduce_slabs_bias_kernel, dim3(blocks), dim3(NTHR), 0, s, slabs, nslab, n, cols, bias, out);
   PL_CHECK_LAUNCH("reduce_slabs_bias");
+  return PL_OK;
+}
+
+int launch_reduce_rows_multi(const float* const* part, const int* R, const int* H, float* const* out, int njobs,
+                             hipStream_t s) {
+  for (int base = 0; base < njobs; base += 8) {
+    RowJobs j = {};
+    const int n = njobs - base < 8 ? njobs - base : 8;
+    int maxH = 0;
+    for (int k = 0; k < n; ++k) {
+      j.part[k] = part[base + k]; j.out[k] = out[base + k]; j.R[k] = R[base + k]; j.H[k] = H[base + k];
+      if (H[base + k] > maxH) maxH = H[base + k];
+    }
+    hipLaunchKernelGGL(reduce_rows_multi_kernel, dim3((maxH + RCOLS - 1) / RCOLS, n), dim3(NTHR), 0, s, j);
+    PL_CHECK_LAUNCH("reduce_rows_multi");
+  }
   return PL_OK;
 }
 

@@ -23,7 +23,8 @@
 //   * epilogue, all in registers: bias, residual-gradient addend, eval-mode BN fold +
 //     ReLU + skip, and training-mode BatchNorm partial statistics (column sum and M2 per
 //     64-row group, merged later with Chan's formula -- no E[z^2]-E[z]^2 cancellation).
-//   * blockIdx -> tile map gives each XCD (private 4 MiB L2) a contiguous band of M-tiles.
+//   * blockIdx -> (K slice, tile) map gives each XCD (private 4 MiB L2) a contiguous band of
+//     M-tiles of one K slice.
 #include <type_traits>
 #include <vector>
 
@@ -136,19 +137,25 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ s, int row0,
 }
 
 template <bool A_KS, bool B_KS, bool EDGE>
-__global__ __launch_bounds__(NTHR) void gemm_f32_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];   // one static array (73,728 B)
-
+__device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id, const int nwork,
+                                          float* __restrict__ lds) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
 
   // ---- tile id: XCD-aware remap (blocks b and b+8 share an XCD) ------------------------
+  // The grid is 1-D over (K slice, tile), slice-major.  Workgroups b and b+8 share an XCD, so
+  // the remap hands each XCD a contiguous run of work items: a band of M tiles x all N tiles
+  // of ONE K slice (its operand panels then sit in that XCD's L2 once; a first version mapped
+  // slices to blockIdx.z and every XCD streamed ALL of K: 4.5x the algorithmic bytes).
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int ntiles = gridDim.x;
-  int t = blockIdx.x;
-  if ((ntiles & 7) == 0) t = (t & 7) * (ntiles >> 3) + (t >> 3);
+  const int splits = p.split_k > 1 ? p.split_k : 1;
+  const int ntiles = nwork / splits;
+  int w = block_id;
+  if ((nwork & 7) == 0) w = (w & 7) * (nwork >> 3) + (w >> 3);
+  const int slice = w / ntiles;
+  const int t = w - slice * ntiles;
   const int m0 = (t / tiles_n) * BM;
   const int n0 = (t % tiles_n) * BN;
 
@@ -157,9 +164,9 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(GemmArgs p) {
   float* C = p.C;
   if (p.split_k > 1) {
     const int per = (((p.K + p.split_k - 1) / p.split_k) + BK - 1) / BK * BK;
-    kbeg = blockIdx.z * per;
+    kbeg = slice * per;
     kend = min(p.K, kbeg + per);
-    C += (size_t)blockIdx.z * p.M * p.ldc;
+    C += (size_t)slice * p.M * p.ldc;
   }
   const int nk = kend > kbeg ? (kend - kbeg + BK - 1) / BK : 0;
 
@@ -333,6 +340,25 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(GemmArgs p) {
   }
 }
 
+template <bool A_KS, bool B_KS, bool EDGE>
+__global__ __launch_bounds__(NTHR) void gemm_f32_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];   // one static array (73,728 B)
+  gemm_body<A_KS, B_KS, EDGE>(p, blockIdx.x, gridDim.x, lds);
+}
+
+// Two independent whole-tile GEMMs in ONE launch: workgroups [0, n0) run the NN problem
+// (da = dz W), the rest the TN problem (dW = dz^T a, split-K slabs).  Both read the same dz;
+// with 256 + 256 workgroups every CU hosts one of each (2 x 73.7 KB LDS, 2 waves per SIMD), so
+// one GEMM's prologue / epilogue-store / barrier bubbles are filled by the other's MFMAs, and
+// a launch boundary plus its dirty-L2 write-back disappears.
+__global__ __launch_bounds__(NTHR) void gemm_f32_dual_kernel(GemmArgs p0, GemmArgs p1, int n0) {
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+  if ((int)blockIdx.x < n0)
+    gemm_body<false, true, false>(p0, blockIdx.x, n0, lds);
+  else
+    gemm_body<true, true, false>(p1, blockIdx.x - n0, gridDim.x - n0, lds);
+}
+
 }  // namespace
 
 int gemm_stat_groups(int M) { return 2 * ((M + BM - 1) / BM); }
@@ -379,6 +405,35 @@ static ProfRec* prof_begin(const GemmArgs& a, hipStream_t s) {
   return r;
 }
 
+// hot path: whole 128x128x32 tiles in every split, 16-byte aligned rows
+static bool whole_tiles(const GemmArgs& a) {
+  const int splits = a.split_k > 1 ? a.split_k : 1;
+  const int kper = splits > 1 ? (((a.K + splits - 1) / splits) + BK - 1) / BK * BK : a.K;
+  return (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0) && (kper * splits == a.K || splits == 1) &&
+         (a.lda % 4 == 0) && (a.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0) &&
+         ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0);
+}
+
+static int grid_of(const GemmArgs& a) {
+  return ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * (a.split_k > 1 ? a.split_k : 1);
+}
+
+// da = dz W (NN) and dW = dz^T a (TN) in one launch; falls back to two launches off the hot path
+int launch_gemm_f32_pair(const GemmArgs& nn, const GemmArgs& tn, hipStream_t s) {
+  const int g0 = grid_of(nn), g1 = grid_of(tn);
+  if (!whole_tiles(nn) || !whole_tiles(tn) || (g0 & 7) || (g1 & 7)) {
+    PL_TRY(launch_gemm_f32(kNN, nn, s));
+    return launch_gemm_f32(kTN, tn, s);
+  }
+  GemmArgs both = nn;                 // profiling record: one launch, the work of two
+  ProfRec* prof = prof_begin(both, s);
+  if (prof) prof->flops += 2.0 * tn.M * tn.N * tn.K;
+  hipLaunchKernelGGL(gemm_f32_dual_kernel, dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
+  if (prof) (void)hipEventRecord(prof->e1, s);
+  PL_CHECK_LAUNCH("gemm_f32_dual");
+  return PL_OK;
+}
+
 int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s) {
   if (!a.A || !a.B || !a.C) PL_FAIL(PL_EINVAL, "gemm_f32: null operand");
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) PL_FAIL(PL_ESHAPE, "gemm_f32: bad shape %dx%dx%d", a.M, a.N, a.K);
@@ -386,14 +441,10 @@ int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s) {
   if (a.col_scale && !a.col_shift) PL_FAIL(PL_EINVAL, "gemm_f32: scale without shift");
   const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   const int splits = a.split_k > 1 ? a.split_k : 1;
-  dim3 grid(tiles, 1, splits), block(NTHR);
+  dim3 grid(tiles * splits), block(NTHR);
   const size_t lds_bytes = 0;   // LDS is static
   ProfRec* prof = prof_begin(a, s);
-  // hot path: whole 128x128x32 tiles in every split, 16-byte aligned rows
-  const int kper = splits > 1 ? (((a.K + splits - 1) / splits) + BK - 1) / BK * BK : a.K;
-  const bool whole = (a.M % BM == 0) && (a.N % BN == 0) && (a.K % BK == 0) && (kper * splits == a.K || splits == 1) &&
-                     (a.lda % 4 == 0) && (a.ldb % 4 == 0) &&
-                     ((reinterpret_cast<uintptr_t>(a.A) & 15) == 0) && ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0);
+  const bool whole = whole_tiles(a);
 #define PL_GEMM_LAUNCH(AKS, BKS)                                                                          \
   do {                                                                                                    \
     if (whole) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false>), grid, block, lds_bytes, s, a);      \

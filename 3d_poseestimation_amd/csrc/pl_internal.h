@@ -56,6 +56,7 @@ struct GemmArgs {
 };
 
 int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s);
+int launch_gemm_f32_pair(const GemmArgs& nn, const GemmArgs& tn, hipStream_t s);
 int gemm_stat_groups(int M);  // number of 64-row groups the stats epilogue emits
 int prof_enable(int on);
 int prof_read(double min_flops, double* ms_total, int64_t* launches, double* flops_total);
@@ -92,6 +93,9 @@ int launch_bn_bwd_dz(const float* g, const uint64_t* bits, const float* z, const
 
 // out[i] = sum_s slabs[s*n + i]
 int launch_reduce_slabs(const float* slabs, int nslab, int64_t n, float* out, hipStream_t s);
+// njobs independent out[c] = sum_r part[r][c] reductions in one launch
+int launch_reduce_rows_multi(const float* const* part, const int* R, const int* H, float* const* out, int njobs,
+                             hipStream_t s);
 // out[r][c] = bias[c] + sum_s slabs[s][r][c]
 int launch_reduce_slabs_bias(const float* slabs, int nslab, int rows, int cols, const float* bias,
                              float* out, hipStream_t s);

@@ -25,7 +25,7 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("POSELIFT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, rank=rank, world_size=world,
@@ -33,6 +33,13 @@ def init_from_env(backend=None):
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local, world
+
+
+def local_device(local_rank):
+    """cuda device of this rank: LOCAL_RANK, folded onto the visible devices (a 1-GPU box can
+    rehearse a multi-rank job with POSELIFT_DIST_BACKEND=gloo, all ranks on cuda:0)."""
+    n = torch.cuda.device_count()
+    return torch.device("cuda", local_rank % max(n, 1))
 
 
 def shard_rows(n_rows, rank, world):

@@ -105,7 +105,7 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the lifter has no CPU path")
-    dev = torch.device("cuda", local)
+    dev = pkg.dp.local_device(local)
     torch.cuda.set_device(dev)
     L = pkg.lib()
 
