@@ -136,7 +136,29 @@ __device__ __forceinline__ void read_frag(const float* __restrict__ s, int row0,
   }
 }
 
-template <bool A_KS, bool B_KS, bool EDGE>
+// bf16 arithmetic on the same fp32 LDS images (PL_BF16 mode): a lane of v_mfma_f32_32x32x16_bf16
+// holds A[row = lane&31][k = 8h .. 8h+7]; the 8 floats are fetched (2 x b128 from a KC image,
+// 8 x b32 from a KS image) and rounded to bf16 (RNE, v_cvt_pk_bf16_f32) on the way to the MFMA.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+template <bool KS>
+__device__ __forceinline__ bf16x8 read_frag_bf16(const float* __restrict__ s, int row, int s16, int h) {
+  float f[8];
+  if (!KS) {
+    const float4 u = *reinterpret_cast<const float4*>(s + row * KC_LD + s16 * 16 + 8 * h);
+    const float4 v = *reinterpret_cast<const float4*>(s + row * KC_LD + s16 * 16 + 8 * h + 4);
+    f[0] = u.x; f[1] = u.y; f[2] = u.z; f[3] = u.w; f[4] = v.x; f[5] = v.y; f[6] = v.z; f[7] = v.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = s[(s16 * 16 + 8 * h + j) * KS_LD + row];
+  }
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)f[j];
+  return r;
+}
+
+template <bool A_KS, bool B_KS, bool EDGE, bool BF = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id, const int nwork,
                                           float* __restrict__ lds) {
   const int tid = threadIdx.x;
@@ -255,6 +277,42 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
     PL_SGB(0x100, NFR); PL_SGB(0x008, 16);
     __builtin_amdgcn_sched_barrier(0);
   };
+  // PL_BF16 variant of one pipeline step: the 32-wide fp32 tile is two 16-deep bf16 MFMA steps
+  // (2 x 4 MFMAs of 32 cycles: this loop is bound by staging bytes from L2, not by the pipe).
+  bf16x8 ba[2][2], bb[2][2];
+#define PL_FRAGS_BF(set, buf, s16)                                                   \
+  do {                                                                               \
+    _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) {                               \
+      ba[set][t2] = read_frag_bf16<A_KS>((buf), wm * 64 + t2 * 32 + i, (s16), h);    \
+      bb[set][t2] = read_frag_bf16<B_KS>((buf) + OP_FLOATS, wn * 64 + t2 * 32 + i, (s16), h); \
+    }                                                                                \
+  } while (0)
+#define PL_MFMAS_BF(set)                                                                    \
+  do {                                                                                      \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                           \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b)                                           \
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ba[set][a], bb[set][b], acc[a][b], 0, 0, 0); \
+  } while (0)
+  auto step_bf = [&](const int kt, auto do_store, auto do_load, auto has_next) {
+    const float* cur = lds + (kt & 1) * 2 * OP_FLOATS;
+    float* nxt = lds + ((kt + 1) & 1) * 2 * OP_FLOATS;
+    if (do_store.value) {
+      store_tile<A_KS>(nxt, tid, ra);
+      store_tile<B_KS>(nxt + OP_FLOATS, tid, rb);
+    }
+    if (do_load.value) {
+      const int k0 = kbeg + (kt + 2) * BK;
+      ra = load_tile<A_KS, EDGE>(p.A, p.lda, m0, p.M, k0, kend, a_vec, tid);
+      rb = load_tile<B_KS, EDGE>(p.B, p.ldb, n0, p.N, k0, kend, b_vec, tid);
+    }
+    PL_FRAGS_BF(1, cur, 1);
+    PL_MFMAS_BF(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next.value) PL_FRAGS_BF(0, nxt, 0);
+    PL_MFMAS_BF(1);
+  };
   using T = std::true_type;
   using F = std::false_type;
 
@@ -268,12 +326,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
       rb = load_tile<B_KS, EDGE>(p.B, p.ldb, n0, p.N, kbeg + BK, kend, b_vec, tid);
     }
     __syncthreads();
-    PL_FRAGS(0, lds, 0);
     int kt = 0;
-    for (; kt + 2 < nk; ++kt) step(kt, T{}, T{}, T{});
-    if (kt + 1 < nk) { step(kt, T{}, F{}, T{}); ++kt; }
-    step(kt, F{}, F{}, F{});
+    if (BF) {
+      PL_FRAGS_BF(0, lds, 0);
+      for (; kt + 2 < nk; ++kt) step_bf(kt, T{}, T{}, T{});
+      if (kt + 1 < nk) { step_bf(kt, T{}, F{}, T{}); ++kt; }
+      step_bf(kt, F{}, F{}, F{});
+    } else {
+      PL_FRAGS(0, lds, 0);
+      for (; kt + 2 < nk; ++kt) step(kt, T{}, T{}, T{});
+      if (kt + 1 < nk) { step(kt, T{}, F{}, T{}); ++kt; }
+      step(kt, F{}, F{}, F{});
+    }
   }
+#undef PL_FRAGS_BF
+#undef PL_MFMAS_BF
 #undef PL_SGB
 #undef PL_FRAGS
 #undef PL_MFMAS
@@ -340,10 +407,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
   }
 }
 
-template <bool A_KS, bool B_KS, bool EDGE>
+template <bool A_KS, bool B_KS, bool EDGE, bool BF = false>
 __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];   // one static array (73,728 B)
-  gemm_body<A_KS, B_KS, EDGE>(p, blockIdx.x, gridDim.x, lds);
+  gemm_body<A_KS, B_KS, EDGE, BF>(p, blockIdx.x, gridDim.x, lds);
 }
 
 // Two independent whole-tile GEMMs in ONE launch: workgroups [0, n0) run the NN problem
@@ -351,12 +418,13 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(GemmArgs p) {
 // with 256 + 256 workgroups every CU hosts one of each (2 x 73.7 KB LDS, 2 waves per SIMD), so
 // one GEMM's prologue / epilogue-store / barrier bubbles are filled by the other's MFMAs, and
 // a launch boundary plus its dirty-L2 write-back disappears.
+template <bool BF>
 __global__ __launch_bounds__(NTHR) void gemm_f32_dual_kernel(GemmArgs p0, GemmArgs p1, int n0) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   if ((int)blockIdx.x < n0)
-    gemm_body<false, true, false>(p0, blockIdx.x, n0, lds);
+    gemm_body<false, true, false, BF>(p0, blockIdx.x, n0, lds);
   else
-    gemm_body<true, true, false>(p1, blockIdx.x - n0, gridDim.x - n0, lds);
+    gemm_body<true, true, false, BF>(p1, blockIdx.x - n0, gridDim.x - n0, lds);
 }
 
 }  // namespace
@@ -428,7 +496,9 @@ int launch_gemm_f32_pair(const GemmArgs& nn, const GemmArgs& tn, hipStream_t s) 
   GemmArgs both = nn;                 // profiling record: one launch, the work of two
   ProfRec* prof = prof_begin(both, s);
   if (prof) prof->flops += 2.0 * tn.M * tn.N * tn.K;
-  hipLaunchKernelGGL(gemm_f32_dual_kernel, dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
+  if (nn.bf16 != tn.bf16) PL_FAIL(PL_EINVAL, "gemm pair: mixed arithmetic");
+  if (nn.bf16) hipLaunchKernelGGL(gemm_f32_dual_kernel<true>, dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
+  else hipLaunchKernelGGL(gemm_f32_dual_kernel<false>, dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
   if (prof) (void)hipEventRecord(prof->e1, s);
   PL_CHECK_LAUNCH("gemm_f32_dual");
   return PL_OK;
@@ -447,7 +517,8 @@ int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s) {
   const bool whole = whole_tiles(a);
 #define PL_GEMM_LAUNCH(AKS, BKS)                                                                          \
   do {                                                                                                    \
-    if (whole) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false>), grid, block, lds_bytes, s, a);      \
+    if (whole && a.bf16) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false, true>), grid, block, lds_bytes, s, a); \
+    else if (whole) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false>), grid, block, lds_bytes, s, a);      \
     else hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, true>), grid, block, lds_bytes, s, a);             \
   } while (0)
   switch (layout) {

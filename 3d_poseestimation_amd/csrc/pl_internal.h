@@ -53,6 +53,8 @@ struct GemmArgs {
   const float* col_shift;
   int relu;                 // v = max(v, 0)
   const float* resid;       // [M][ldc] v += resid[row][col] after relu (may alias C)
+  int bf16;                 // PL_BF16 mode: operands rounded to bf16 on the way to the MFMA
+                            // (whole-tile problems only; edge problems stay fp32)
 };
 
 int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s);

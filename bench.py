@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_POSE = 25_618_432          # 2 x 12,809,216 MAC, GEMMs only, fwd+bwd
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MATRIX_TFLOPS = 2516.0    # dense bf16 MFMA peak (the 2:1-sparsity figure is NOT used)
 BATCH = 4096
 
 
@@ -42,6 +43,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (default: BASELINE config 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
+    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
+                    help="GEMM arithmetic of the headline run (fp32 is the parity-gated mode)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the bf16-mode and PyTorch-eager side measurements")
     return ap.parse_args()
 
 
@@ -95,6 +99,58 @@ def cpu_baseline(batch, budget_s=20.0):
             "ms_per_step": round(1e3 * dt / n, 2)}
 
 
+def side_measurements(pkg, a, dev, x_eval, y_oracle):
+    """Reported beside the headline: the other GEMM arithmetic mode of this
+    library, and stock PyTorch-ROCm eager of the same module (oracle/torch_twin.py on the GPU) in
+    fp32 and under bf16 autocast.  Same batch size, same step, 60 timed steps each."""
+    import torch
+    from oracle import lifter_oracle as orc
+    from oracle.torch_twin import TwinLifter, twin_train_step
+    res = {}
+
+    def timed(step, n=60, warm=10):
+        for _ in range(warm):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        return a.batch * n / (time.perf_counter() - t0)
+
+    other = "bf16" if a.dtype == "fp32" else "fp32"
+    torch.manual_seed(0)
+    m = pkg.LinearModel(34, 51, compute_dtype=other).to(dev).train()
+    opt = pkg.FlatAdamW(m, lr=1e-4)
+    xb, yb = pkg.synth.synthetic_batch(a.batch, 99, dev)
+    v = timed(lambda: pkg.train_step(m, opt, xb, yb))
+    m.eval()
+    with torch.no_grad():
+        ye = m(x_eval).cpu().numpy()
+    st = {k: t.detach().cpu().numpy() for k, t in m.state_dict().items()}
+    yo, _ = orc.forward(st, x_eval.cpu().numpy(), num_stage=2, train=False)
+    res[f"this_library_{other}"] = {"poses_per_s": round(v, 1), "mpjpe_mm_eval_fwd_vs_oracle": float(f"{orc.mpjpe_mm(ye, yo):.3e}")}
+    del m, opt
+
+    for name, autocast in (("pytorch_rocm_eager_fp32", False), ("pytorch_rocm_eager_bf16_autocast", True)):
+        torch.manual_seed(0)
+        tw = TwinLifter(34, 51).to(dev).train()
+        topt = torch.optim.AdamW(tw.parameters(), lr=1e-4)
+
+        def step():
+            if autocast:
+                topt.zero_grad()
+                with torch.autocast("cuda", dtype=torch.bfloat16):
+                    pred = tw(xb).reshape(a.batch, -1, 3)
+                torch.nn.functional.mse_loss(pred.float(), yb).backward()
+                topt.step()
+            else:
+                twin_train_step(tw, topt, xb, yb)
+        res[name] = {"poses_per_s": round(timed(step), 1)}
+        del tw, topt
+    return res
+
+
 def main():
     a = parse()
     import torch
@@ -110,7 +166,8 @@ def main():
     L = pkg.lib()
 
     torch.manual_seed(0)                                    # same initial weights on every rank
-    model = pkg.LinearModel(34, 51, linear_size=1024, num_stage=2, p_dropout=0.5, BN=True).to(dev).train()
+    model = pkg.LinearModel(34, 51, linear_size=1024, num_stage=2, p_dropout=0.5, BN=True,
+                            compute_dtype=a.dtype).to(dev).train()
     model.manual_seed(1234 + rank)                          # own dropout stream per rank
     opt = pkg.FlatAdamW(model, lr=1e-4)                     # train_1.py:39 (weight_decay 0.01)
     sync = pkg.dp.GradSync() if world > 1 else None
@@ -147,9 +204,11 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath):
                 traffic = json.load(open(tpath)).get("gemm_f32_hbm_bytes_per_launch")
-            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MATRIX_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MATRIX_TFLOPS, 4), "traffic": traffic,
-                        "kernel": "gemm_f32_kernel (fp32 MFMA, 4096x1024x1024 per launch, 12 launches/step)",
+            peak = PEAK_F32_MATRIX_TFLOPS if a.dtype == "fp32" else PEAK_BF16_MATRIX_TFLOPS
+            roofline = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak,
+                        "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                        "kernel": "gemm_f32_kernel / gemm_f32_dual_kernel (%s MFMA; 4096x1024x1024 forward launches "
+                                  "and dX+dW dual launches: 12 GEMMs in 8 launches per step)" % a.dtype,
                         "flop_per_launch": fl.value / n_l.value, "avg_launch_us": round(avg_ms * 1e3, 2),
                         "launches_timed": n_l.value}
     if world > 1:
@@ -190,19 +249,24 @@ def main():
             "metric": "poses/sec fwd+bwd, 17-joint lifting batch 4096; MPJPE vs ref",
             "value": round(value, 1), "unit": "poses/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if a.dtype == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1] shape at the parity-gated precision: phase1_lifting "
                                    "LinearModel 34-1024-2x(1024-1024)-51, BN+ReLU+Dropout(0.5), one train_1.py "
                                    "step = zero_grad+forward+MSE+backward+AdamW"
                                    + ("+RCCL grad all-reduce" if world > 1 else ""),
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
-                       "parallelism": f"dp{world}", "gemm_arith": "fp32 MFMA (v_mfma_f32_32x32x2_f32)"},
+                       "parallelism": f"dp{world}",
+                       "gemm_arith": "fp32 MFMA (v_mfma_f32_32x32x2_f32)" if a.dtype == "fp32"
+                       else "bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate and storage"},
             "step_tflops": round(value * FLOP_PER_POSE / 1e12, 2),
-            "step_frac_of_f32_matrix_peak": round(value * FLOP_PER_POSE / 1e12 / (PEAK_F32_MATRIX_TFLOPS * world), 4),
+            "step_frac_of_matrix_peak": round(value * FLOP_PER_POSE / 1e12 / (
+                (PEAK_F32_MATRIX_TFLOPS if a.dtype == "fp32" else PEAK_BF16_MATRIX_TFLOPS) * world), 4),
             "fwd_bwd_only_poses_per_s_per_gpu": round(a.batch * nfb / dt_fb, 1),
             "mpjpe_mm_eval_fwd_vs_oracle": float(f"{mpjpe:.3e}"),
             "roofline": roofline,
         }
+        if world == 1 and not a.no_extras:
+            out["other_modes"] = side_measurements(pkg, a, dev, x, y_orc)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.batch)
         print(json.dumps(out), flush=True)
