@@ -138,6 +138,9 @@ Ws plan(const PLDesc* d, int64_t B) {
   {
     const int so = out_splits((int)B, d->out_dim, H);
     if (so > 1) slab = std::max(slab, (size_t)so * B * d->out_dim * 4);
+    // partials of the skinny-layer kernels (skinny.hip)
+    slab = std::max(slab, (size_t)skinny_chunks((int)B) * std::max(d->in_dim, d->out_dim) * H * 4);
+    slab = std::max(slab, skinny_narrow_out_part_floats((int)B, H) * 4);
   }
   w.slabs = take(slab);
   w.outpart = take((size_t)colsum_chunks((int)B) * d->out_dim * 4);
@@ -183,6 +186,7 @@ int check_ws(const Ws& w, void* ws, size_t bytes) {
 
 int gemm_out_layer(const float* h, const float* W, const float* bias, float* y, int M, int N, int K,
                    float* slabs, hipStream_t s) {
+  if (skinny_narrow_out_supported(K, N)) return launch_skinny_narrow_out(h, W, bias, y, M, K, N, slabs, s);
   GemmArgs g = {};
   g.A = h; g.B = W; g.M = M; g.N = N; g.K = K; g.lda = K; g.ldb = K; g.ldc = N;
   const int splits = out_splits(M, N, K);
@@ -321,12 +325,18 @@ extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, in
     g.M = (int)B; g.N = H; g.K = ly.K; g.lda = ly.K; g.ldb = ly.K; g.ldc = H; g.split_k = 1;
     g.bf16 = d->dtype == PL_BF16;
     if (d->bn) { g.stat_sum = f32(ws, w.stat_a); g.stat_m2 = f32(ws, w.stat_b); }
-    PL_TRY(launch_gemm_f32(kNT, g, s));
+    int groups = w.G;
+    if (l == 0 && skinny_supported(ly.K, H)) {
+      groups = skinny_stat_groups((int)B);
+      PL_TRY(launch_skinny_wide_out(a_in, ly.W, ly.b, g.C, (int)B, ly.K, H, false, g.stat_sum, g.stat_m2, s));
+    } else {
+      PL_TRY(launch_gemm_f32(kNT, g, s));
+    }
     const float *scale = nullptr, *shift = nullptr;
     if (d->bn) {
       float* sc = f32(ws, w.scale) + (size_t)l * H;
       float* sh = f32(ws, w.shift) + (size_t)l * H;
-      PL_TRY(launch_bn_finalize(g.stat_sum, g.stat_m2, w.G, (int)B, H, ly.gamma, ly.beta, d->bn_eps,
+      PL_TRY(launch_bn_finalize(g.stat_sum, g.stat_m2, groups, (int)B, H, ly.gamma, ly.beta, d->bn_eps,
                                 d->bn_momentum, ly.rm, ly.rv, ly.nbt, f32(ws, w.mean[l]),
                                 f32(ws, w.rstd[l]), sc, sh, s));
       scale = sc; shift = sh;
@@ -363,7 +373,11 @@ extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, i
   // final Linear (LinearModel.w2): dW = dy^T h, db = sum dy, g = dy W
   const float* W5 = d->params + P.off[4 * w.L];
   const float* h_last = f32(ws, w.act[w.L - 1]);
-  PL_TRY(gemm_tn_reduced(dy, O, h_last, H, grads + P.off[4 * w.L], O, H, Bi, slabs, s));
+  if (skinny_supported(O, H)) {
+    PL_TRY(launch_skinny_wide_in(dy, h_last, grads + P.off[4 * w.L], Bi, O, H, false, slabs, s));
+  } else {
+    PL_TRY(gemm_tn_reduced(dy, O, h_last, H, grads + P.off[4 * w.L], O, H, Bi, slabs, s));
+  }
   PL_TRY(launch_colsum_partial(dy, Bi, O, f32(ws, w.outpart), s));
   // bias gradients = column sums of partials; all of them are reduced by ONE launch at the end
   std::vector<const float*> jpart; std::vector<float*> jout; std::vector<int> jR, jH;
@@ -372,7 +386,11 @@ extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, i
   {
     GemmArgs g = {};
     g.A = dy; g.B = W5; g.C = GA; g.M = Bi; g.N = H; g.K = O; g.lda = O; g.ldb = H; g.ldc = H; g.split_k = 1;
-    PL_TRY(launch_gemm_f32(kNN, g, s));
+    if (skinny_supported(O, H)) {
+      PL_TRY(launch_skinny_wide_out(dy, W5, nullptr, GA, Bi, O, H, true, nullptr, nullptr, s));
+    } else {
+      PL_TRY(launch_gemm_f32(kNN, g, s));
+    }
   }
 
   for (int l = w.L - 1; l >= 0; --l) {
@@ -410,6 +428,8 @@ extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, i
       t.split_k = splits; t.C = splits > 1 ? slabs : ly.gW;
       PL_TRY(launch_gemm_f32_pair(g, t, s));
       if (splits > 1) PL_TRY(launch_reduce_slabs(slabs, splits, (int64_t)H * H, ly.gW, s));
+    } else if (skinny_supported(ly.K, H)) {
+      PL_TRY(launch_skinny_wide_in(a_in, DZ, ly.gW, Bi, ly.K, H, true, slabs, s));
     } else {
       PL_TRY(gemm_tn_reduced(DZ, H, a_in, ly.K, ly.gW, H, ly.K, Bi, slabs, s));
     }

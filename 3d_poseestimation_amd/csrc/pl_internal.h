@@ -110,4 +110,19 @@ int launch_bn_fold_eval(const float* bias, const float* gamma, const float* beta
                         hipStream_t s);
 int launch_fill(float* p, int64_t n, float v, hipStream_t s);
 
+// ---------------------------------------------------------------------------------
+// skinny layers (skinny.hip): 34 -> H and H -> 51, MFMA straight from registers
+// ---------------------------------------------------------------------------------
+bool skinny_supported(int K, int H);           // narrow dimension specialised (34, 51), H % 128 == 0
+int skinny_chunks(int B);                      // row tasks (64 rows each)
+int skinny_stat_groups(int B);                 // 64-row BN statistics groups it emits
+int launch_skinny_wide_out(const float* X, const float* W, const float* bias, float* out, int B, int K,
+                           int H, bool w_transposed, float* stat_sum, float* stat_m2, hipStream_t s);
+int launch_skinny_wide_in(const float* X, const float* D, float* out, int B, int K, int H,
+                          bool out_transposed, float* part, hipStream_t s);
+bool skinny_narrow_out_supported(int H, int N);
+size_t skinny_narrow_out_part_floats(int B, int H);
+int launch_skinny_narrow_out(const float* h, const float* W, const float* bias, float* y, int B, int H,
+                             int N, float* part, hipStream_t s);
+
 }  // namespace pl

@@ -1,0 +1,297 @@
+// The two skinny Linear layers of the lifter: 34 -> H (LinearModel.w1, baselineModel.py:67,90) and
+// H -> 51 (LinearModel.w2, :77,100), forward and backward.  One side of each GEMM is only 34 / 51
+// wide, so a 128x128 LDS-tiled MFMA tile is mostly padding (the generic kernel's guarded edge path
+// takes 24-32 us per call).  Each of these ops is really ONE pass over a (B x H) activation
+// (16.8 MB, ~3.5 us at HBM rate) with ~0.3-0.5 GFLOP attached.
+//
+// Design: MFMA straight from registers, no LDS operand tiles, one wavefront = one independent
+// task (a 32-column strip x a 64-row group), 2048 tasks = 8 per CU.  v_mfma_f32_32x32x2_f32
+// wants A[i][k], B[k][j] with i/j = lane&31 and k = lane>>5: the wide tensor is always the
+// operand whose 32 lanes run along its contiguous (column) dimension, so its loads and stores
+// are 128-byte segments; the narrow operand is small enough to live in L1/L2.
+// (Two earlier VALU designs -- narrow operand through scalar loads, then through broadcast LDS
+// reads -- ran 26-67 us per call: one wave per SIMD with 34-52-long dependent FMA chains.)
+#include "pl_internal.h"
+
+namespace pl {
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int NTHR = 256;
+constexpr int RG = 64;     // rows per task = one 64-row BatchNorm statistics group (2048 tasks at B=4096:
+                           // 8 waves per CU; with 128-row tasks the kernels were load-latency bound)
+
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// out[r][c] = bias[c] + sum_k X[r][k] * w_c[k]      X: [B][K] narrow, out: [B][H] wide
+//   WT = false: w_c[k] = W[c*K + k]   (forward of the input layer: W is [H][K])
+//   WT = true : w_c[k] = W[k*H + c]   (backward of the output layer: g = dy W5, W5 is [K][H])
+// STATS: BatchNorm partial statistics (sum, M2 about the group mean) per 64-row group.
+// The workgroup's four waves take four neighbouring column strips of the SAME row group, so the
+// 64 narrow rows are staged once in LDS (coalesced) and read back as MFMA A fragments.
+template <int K, bool WT, bool STATS>
+__global__ __launch_bounds__(NTHR) void skinny_wide_out_kernel(
+    const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
+    float* __restrict__ out, int B, int H, float* __restrict__ stat_sum, float* __restrict__ stat_m2) {
+  constexpr int KS = (K + 1) / 2;            // MFMA steps, 2 k each
+  constexpr int KL = 2 * KS + 1;             // LDS row stride (odd: conflict-free column reads)
+  __shared__ float xs[RG * KL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int strips4 = H / 128;               // workgroups per row group (4 strips of 32 each)
+  const int rg = blockIdx.x / strips4;
+  const int c = ((blockIdx.x % strips4) * 4 + wave) * 32 + j;
+  const int r_base = rg * RG;
+  for (int e = threadIdx.x; e < RG * K; e += NTHR) {
+    const int r = e / K, k = e - r * K;
+    xs[r * KL + k] = (r_base + r < B) ? X[(size_t)(r_base + r) * K + k] : 0.f;
+  }
+  if (K & 1)
+    for (int r = threadIdx.x; r < RG; r += NTHR) xs[r * KL + K] = 0.f;
+  __syncthreads();
+  float wb[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int k = 2 * s + h;
+    wb[s] = (k < K) ? (WT ? W[(size_t)k * H + c] : W[(size_t)c * K + k]) : 0.f;
+  }
+  const float b = bias ? bias[c] : 0.f;
+#pragma unroll 1
+  for (int g2 = 0; g2 < RG / 64; ++g2) {
+    const int g0 = r_base + g2 * 64;
+    if (g0 >= B) break;
+    f32x16 acc[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      const float* xr = xs + (g2 * 64 + t * 32 + j) * KL + h;
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[2 * s], wb[s], acc[t], 0, 0, 0);
+    }
+    float ssum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = g0 + t * 32 + acc_row(r, h);
+        const float v = acc[t][r] + b;
+        acc[t][r] = v;
+        if (row < B) {
+          out[(size_t)row * H + c] = v;
+          ssum += v;
+        }
+      }
+    if (STATS) {
+      ssum += __shfl_xor(ssum, 32);
+      const int cnt = min(64, B - g0);
+      const float mean = ssum / (float)cnt;
+      float m2 = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float dv = acc[t][r] - mean;
+          if (g0 + t * 32 + acc_row(r, h) < B) m2 = fmaf(dv, dv, m2);
+        }
+      m2 += __shfl_xor(m2, 32);
+      if (h == 0) {
+        stat_sum[(size_t)(g0 >> 6) * H + c] = ssum;
+        stat_m2[(size_t)(g0 >> 6) * H + c] = m2;
+      }
+    }
+  }
+}
+
+// part[chunk][k][c] = sum_{r in chunk} X[r][k] * D[r][c]     X: [B][K] narrow, D: [B][H] wide
+// (dW0^T = x^T dz0 and dW5 = dy^T h).  MFMA rows = k (two 32-row tiles, zero beyond K), columns =
+// a 32-wide strip of D, contraction over the chunk's 64 rows: both operands are read in 128-byte
+// row segments.
+template <int K>
+__global__ __launch_bounds__(NTHR) void skinny_wide_in_kernel(const float* __restrict__ X,
+                                                              const float* __restrict__ D, int B, int H,
+                                                              float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int strips4 = H / 128;
+  const int ch = blockIdx.x / strips4;
+  const int c = ((blockIdx.x % strips4) * 4 + wave) * 32 + j;
+  const int r_base = ch * RG;
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const bool k1ok = 32 + j < K;              // second k tile: rows 32..63 of the output
+#pragma unroll 16
+  for (int s = 0; s < RG / 2; ++s) {
+    const int r = r_base + 2 * s + h;
+    const bool ok = r < B;
+    const float d = ok ? D[(size_t)r * H + c] : 0.f;
+    const float a0 = ok ? X[(size_t)r * K + j] : 0.f;
+    const float a1 = (ok && k1ok) ? X[(size_t)r * K + 32 + j] : 0.f;
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, d, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, d, acc[1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = t * 32 + acc_row(r, h);
+      if (k < K) part[((size_t)ch * K + k) * H + c] = acc[t][r];
+    }
+}
+
+// out = sum over chunks of part[chunk][i], i = k*H + c; TRANS writes out[c*K + k] (dW0 is [H][K]).
+// block = 16 outputs x 16 chunk-parts, fixed-order combine through LDS.
+template <bool TRANS>
+__global__ __launch_bounds__(NTHR) void skinny_reduce_kernel(const float* __restrict__ part, int nchunk,
+                                                             int K, int H, float* __restrict__ out) {
+  __shared__ float red[16][16];
+  const int il = threadIdx.x & 15, p = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + il;
+  const int n = K * H;
+  float a = 0.f;
+  if (i < n)
+    for (int s = p; s < nchunk; s += 16) a += part[(size_t)s * n + i];
+  red[p][il] = a;
+  __syncthreads();
+  if (p == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][il];
+    if (TRANS) {
+      const int k = i / H, c = i - k * H;
+      out[(size_t)c * K + k] = t;
+    } else {
+      out[i] = t;
+    }
+  }
+}
+
+// part[split][r][n] = sum_{k in split} h[r][k] * W[n][k]   h: [B][H] wide (read once), n < N <= 64
+// MFMA rows = 32 rows of h, columns = two 32-wide tiles of output features, contraction over a
+// 1/splits slice of H.  Both operands are k-contiguous: a lane fetches 4 consecutive k with one
+// 16-byte load and feeds 4 MFMAs (any k order shared by A and B is a valid contraction order).
+__global__ __launch_bounds__(NTHR) void skinny_narrow_out_kernel(const float* __restrict__ hmat,
+                                                                 const float* __restrict__ W, int B, int H,
+                                                                 int N, int splits, float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int task = blockIdx.x * 4 + wave;
+  const int rt = task / splits, sp = task - rt * splits;
+  if (rt * 32 >= B) return;
+  const int kper = H / splits;
+  const int row = min(rt * 32 + j, B - 1);
+  const float* __restrict__ ap = hmat + (size_t)row * H + sp * kper + 4 * h;
+  const float* __restrict__ b0p = W + (size_t)min(j, N - 1) * H + sp * kper + 4 * h;
+  const float* __restrict__ b1p = W + (size_t)min(32 + j, N - 1) * H + sp * kper + 4 * h;
+  const bool ok0 = j < N, ok1 = 32 + j < N;
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+  for (int k = 0; k < kper; k += 8) {
+    const float4 a = *reinterpret_cast<const float4*>(ap + k);
+    const float4 b0 = ok0 ? *reinterpret_cast<const float4*>(b0p + k) : zero;
+    const float4 b1 = ok1 ? *reinterpret_cast<const float4*>(b1p + k) : zero;
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int orow = rt * 32 + acc_row(r, h);
+      if (orow < B) part[((size_t)sp * B + orow) * 64 + t * 32 + j] = acc[t][r];
+    }
+}
+
+// y[r][n] = bias[n] + sum_s part[s][r][n]   (n < N of the 64 padded columns)
+__global__ __launch_bounds__(NTHR) void skinny_narrow_out_reduce_kernel(const float* __restrict__ part,
+                                                                        int splits, int B, int N,
+                                                                        const float* __restrict__ bias,
+                                                                        float* __restrict__ y) {
+  const int64_t i = (int64_t)blockIdx.x * NTHR + threadIdx.x;      // i = r*64 + n
+  if (i >= (int64_t)B * 64) return;
+  const int n = (int)(i & 63);
+  if (n >= N) return;
+  float a = bias ? bias[n] : 0.f;
+  for (int s = 0; s < splits; ++s) a += part[(size_t)s * B * 64 + i];
+  y[(size_t)(i >> 6) * N + n] = a;
+}
+
+}  // namespace
+
+bool skinny_supported(int K, int H) { return (K == 34 || K == 51) && H % 128 == 0; }
+int skinny_chunks(int B) { return (B + RG - 1) / RG; }           // row tasks
+int skinny_stat_groups(int B) { return (B + 63) / 64; }
+
+// forward of the input layer (+ BN statistics)  /  g = dy W5 (transposed weights, no bias)
+int launch_skinny_wide_out(const float* X, const float* W, const float* bias, float* out, int B, int K,
+                           int H, bool w_transposed, float* stat_sum, float* stat_m2, hipStream_t s) {
+  if (!skinny_supported(K, H)) PL_FAIL(PL_ESHAPE, "skinny_wide_out: K=%d H=%d not specialised", K, H);
+  dim3 grid(skinny_chunks(B) * (H / 128)), block(NTHR);
+#define PL_SK(KK, WT, ST) hipLaunchKernelGGL((skinny_wide_out_kernel<KK, WT, ST>), grid, block, 0, s, X, W, bias, out, B, H, stat_sum, stat_m2)
+  const bool st = stat_sum != nullptr;
+  if (K == 34 && !w_transposed) { if (st) PL_SK(34, false, true); else PL_SK(34, false, false); }
+  else if (K == 34) { if (st) PL_SK(34, true, true); else PL_SK(34, true, false); }
+  else if (K == 51 && !w_transposed) { if (st) PL_SK(51, false, true); else PL_SK(51, false, false); }
+  else { if (st) PL_SK(51, true, true); else PL_SK(51, true, false); }
+#undef PL_SK
+  PL_CHECK_LAUNCH("skinny_wide_out");
+  return PL_OK;
+}
+
+// out = X^T D, X [B][K], D [B][H]; out is [K][H] or, transposed, [H][K]; part: chunks*K*H floats
+int launch_skinny_wide_in(const float* X, const float* D, float* out, int B, int K, int H,
+                          bool out_transposed, float* part, hipStream_t s) {
+  if (!skinny_supported(K, H)) PL_FAIL(PL_ESHAPE, "skinny_wide_in: K=%d H=%d not specialised", K, H);
+  const int nc = skinny_chunks(B);
+  dim3 grid(nc * (H / 128)), block(NTHR);
+  if (K == 34) hipLaunchKernelGGL((skinny_wide_in_kernel<34>), grid, block, 0, s, X, D, B, H, part);
+  else hipLaunchKernelGGL((skinny_wide_in_kernel<51>), grid, block, 0, s, X, D, B, H, part);
+  PL_CHECK_LAUNCH("skinny_wide_in");
+  const int n = K * H;
+  if (out_transposed)
+    hipLaunchKernelGGL((skinny_reduce_kernel<true>), dim3((n + 15) / 16), block, 0, s, part, nc, K, H, out);
+  else
+    hipLaunchKernelGGL((skinny_reduce_kernel<false>), dim3((n + 15) / 16), block, 0, s, part, nc, K, H, out);
+  PL_CHECK_LAUNCH("skinny_reduce");
+  return PL_OK;
+}
+
+int skinny_narrow_out_splits(int B, int H) {
+  int s = 8;
+  while (s > 1 && (H % (8 * s) != 0)) s >>= 1;
+  return s;
+}
+bool skinny_narrow_out_supported(int H, int N) { return N <= 64 && H % 8 == 0; }
+size_t skinny_narrow_out_part_floats(int B, int H) { return (size_t)skinny_narrow_out_splits(B, H) * B * 64; }
+
+int launch_skinny_narrow_out(const float* h, const float* W, const float* bias, float* y, int B, int H,
+                             int N, float* part, hipStream_t s) {
+  if (!skinny_narrow_out_supported(H, N)) PL_FAIL(PL_ESHAPE, "skinny_narrow_out: H=%d N=%d", H, N);
+  const int splits = skinny_narrow_out_splits(B, H);
+  const int tasks = ((B + 31) / 32) * splits;
+  hipLaunchKernelGGL(skinny_narrow_out_kernel, dim3((tasks + 3) / 4), dim3(NTHR), 0, s, h, W, B, H, N, splits,
+                     part);
+  PL_CHECK_LAUNCH("skinny_narrow_out");
+  const int64_t n = (int64_t)B * 64;
+  hipLaunchKernelGGL(skinny_narrow_out_reduce_kernel, dim3((unsigned)((n + NTHR - 1) / NTHR)), dim3(NTHR), 0, s,
+                     part, splits, B, N, bias, y);
+  PL_CHECK_LAUNCH("skinny_narrow_out_reduce");
+  return PL_OK;
+}
+
+}  // namespace pl
