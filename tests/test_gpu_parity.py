@@ -414,6 +414,64 @@ def test_full_size_properties(pkg, full):
     assert torch.allclose(g2, 2 * g1, rtol=1e-5, atol=1e-9)
 
 
+# ---------------------------------------------------------------------------- ragged / odd shapes
+@pytest.mark.parametrize("B,H,S,i_dim,o_dim,bn,dtype", [
+    (2, 64, 2, 34, 51, True, "fp32"),        # smallest batch BatchNorm accepts
+    (3, 128, 1, 34, 51, True, "fp32"),
+    (63, 128, 2, 34, 51, True, "fp32"),      # one short statistics group
+    (65, 256, 2, 34, 51, True, "fp32"),      # 64 + 1 rows
+    (100, 64, 2, 51, 34, True, "fp32"),      # the phase5 projector LinearModel(51, 34, linear_size=64)
+    (129, 1024, 2, 34, 51, True, "fp32"),    # full width, ragged rows: whole-tile GEMMs fall back to edge path
+    (1000, 128, 3, 34, 51, False, "fp32"),   # no BatchNorm, three stages
+    (4097, 1024, 2, 34, 51, True, "fp32"),   # max bench size + 1
+    (200, 36, 0, 20, 7, True, "fp32"),       # generic dims: nothing specialised applies
+    (384, 256, 2, 34, 51, True, "bf16"),     # bf16 arithmetic, whole tiles
+    (300, 256, 2, 34, 51, True, "bf16"),     # bf16 requested but ragged -> fp32 edge arithmetic
+])
+def test_ragged_shapes_vs_oracle(pkg, B, H, S, i_dim, o_dim, bn, dtype):
+    torch.manual_seed(B + H)
+    m = pkg.LinearModel(i_dim, o_dim, linear_size=H, num_stage=S, p_dropout=0.5, BN=bn,
+                        compute_dtype=dtype).to(DEV).train()
+    st = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(B)
+    x = torch.rand(B, i_dim, generator=g).to(DEV).requires_grad_(True)
+    t = (torch.rand(B, o_dim, generator=g) - 0.5).to(DEV)
+    m.manual_seed(17, step=2)
+    pred = m(x)
+    loss = pkg.mse_loss(pred, t)
+    loss.backward()
+    L = 1 + 2 * S
+    masks = [philox.dropout_keep_mask(17, 3, l, B, H, 0.5) for l in range(L)]
+    xn = x.detach().cpu().numpy()
+    opred, cache = orc.forward(st, xn, num_stage=S, train=True, use_bn=bn, p_dropout=0.5, keep_masks=masks,
+                               on_masks=_gpu_decisions(pkg, m, L, H))
+    bf = dtype == "bf16" and B % 128 == 0
+    for c in cache["layers"]:
+        d = c["on_disagree"]
+        assert d.size <= (0.02 if bf else 1e-3) * c["z"].size + 2 and (d.size == 0 or d.max() < (0.2 if bf else 1e-3))
+    oloss, dpred = orc.mse_loss(opred, t.cpu().numpy())
+    ograds, odx = orc.backward(st, cache, dpred)
+    tol = 5e-2 if bf else 2e-4
+    scale = np.abs(opred).max()
+    _close(pred.detach().cpu().numpy() / scale, opred / scale, 0, 3e-2 if bf else 2e-5)
+    _close(loss.item(), oloss, 2e-2 if bf else 2e-5, 0)
+    got = _grads(m)
+    for k, v in ograds.items():
+        if bn and k.endswith(".bias") and "batch_norm" not in k and k != "w2.bias":
+            continue
+        rel = np.linalg.norm((got[k] - v).astype(np.float64)) / (np.linalg.norm(v.astype(np.float64)) + 1e-30)
+        assert rel < tol, (k, rel)
+    rel = np.linalg.norm((x.grad.cpu().numpy() - odx).astype(np.float64)) / np.linalg.norm(odx.astype(np.float64))
+    assert rel < tol, ("dx", rel)
+    # eval forward on the same ragged batch
+    m.eval()
+    with torch.no_grad():
+        ye = m(x.detach()).cpu().numpy()
+    st2 = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    yo, _ = orc.forward(st2, xn, num_stage=S, train=False, use_bn=bn)
+    _close(ye / scale, yo / scale, 0, 3e-2 if bf else 2e-5)
+
+
 # ---------------------------------------------------------------------------- bf16 arithmetic mode
 def test_bf16_mode_train_and_eval_vs_oracle(pkg):
     """PL_BF16: the 1024-wide GEMMs round their operands to bf16 (fp32 accumulate, fp32 storage).
