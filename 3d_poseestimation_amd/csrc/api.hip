@@ -354,8 +354,12 @@ extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, in
 // ---------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------
-extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, int64_t B, void* ws,
-                             size_t ws_bytes, float* dx, float* grads, void* stream) {
+// Backward over the output layer (if do_output) and hidden layers l_hi .. l_lo (descending).
+// The gradient flowing between two calls lives in the workspace (GA/GB), so the pass can be cut
+// at any layer boundary: the data-parallel driver all-reduces the first half's gradients while
+// the second half is still computing.
+static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B, void* ws, size_t ws_bytes,
+                    float* dx, float* grads, void* stream, bool do_output, int l_hi, int l_lo) {
   PL_TRY(check_desc(d, true));
   if (!x || !dy || !grads) PL_FAIL(PL_EINVAL, "pl_lifter_bwd: null x/dy/flat_grads");
   if (B <= 0) PL_FAIL(PL_ESHAPE, "pl_lifter_bwd: B=%lld", (long long)B);
@@ -369,7 +373,10 @@ extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, i
   float* GA = f32(ws, w.ga);
   float* GB = f32(ws, w.gb);
   float* DZ = f32(ws, w.dz);
+  // bias gradients = column sums of partials; all of them are reduced by ONE launch at the end
+  std::vector<const float*> jpart; std::vector<float*> jout; std::vector<int> jR, jH;
 
+  if (do_output) {
   // final Linear (LinearModel.w2): dW = dy^T h, db = sum dy, g = dy W
   const float* W5 = d->params + P.off[4 * w.L];
   const float* h_last = f32(ws, w.act[w.L - 1]);
@@ -379,8 +386,6 @@ extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, i
     PL_TRY(gemm_tn_reduced(dy, O, h_last, H, grads + P.off[4 * w.L], O, H, Bi, slabs, s));
   }
   PL_TRY(launch_colsum_partial(dy, Bi, O, f32(ws, w.outpart), s));
-  // bias gradients = column sums of partials; all of them are reduced by ONE launch at the end
-  std::vector<const float*> jpart; std::vector<float*> jout; std::vector<int> jR, jH;
   jpart.push_back(f32(ws, w.outpart)); jout.push_back(grads + P.off[4 * w.L + 1]);
   jR.push_back(colsum_chunks(Bi)); jH.push_back(O);
   {
@@ -392,8 +397,9 @@ extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, i
       PL_TRY(launch_gemm_f32(kNN, g, s));
     }
   }
+  }  // do_output
 
-  for (int l = w.L - 1; l >= 0; --l) {
+  for (int l = l_hi; l >= l_lo; --l) {
     const Layer ly = layer_of(d, P, grads, l);
     // gradient w.r.t. this layer's activation: GA for layer 0 and even layers, GB for odd ones
     const float* gin = (l % 2 == 1) ? GB : GA;
@@ -440,7 +446,25 @@ extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, i
       PL_TRY(launch_gemm_f32(kNN, g, s));
     }
   }
+  if (jpart.empty()) return PL_OK;
   return launch_reduce_rows_multi(jpart.data(), jR.data(), jH.data(), jout.data(), (int)jpart.size(), s);
+}
+
+extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, int64_t B, void* ws,
+                             size_t ws_bytes, float* dx, float* grads, void* stream) {
+  if (!d) PL_FAIL(PL_EINVAL, "descriptor is NULL");
+  return bwd_impl(d, x, dy, B, ws, ws_bytes, dx, grads, stream, true, 2 * d->num_stage, 0);
+}
+
+extern "C" int64_t pl_bwd_split_layer(const PLDesc* d) { return d ? (int64_t)d->num_stage + 1 : PL_EINVAL; }
+
+extern "C" int pl_lifter_bwd_part(const PLDesc* d, const float* x, const float* dy, int64_t B, void* ws,
+                                  size_t ws_bytes, float* dx, float* grads, int part, void* stream) {
+  if (!d) PL_FAIL(PL_EINVAL, "descriptor is NULL");
+  const int L = 1 + 2 * d->num_stage, split = d->num_stage + 1;
+  if (part == 0) return bwd_impl(d, x, dy, B, ws, ws_bytes, nullptr, grads, stream, true, L - 1, split);
+  if (part == 1) return bwd_impl(d, x, dy, B, ws, ws_bytes, dx, grads, stream, false, split - 1, 0);
+  PL_FAIL(PL_EINVAL, "pl_lifter_bwd_part: part=%d", part);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -58,6 +58,7 @@ class GradSync:
 
     def __init__(self, group=None, bucket_bytes=None):
         self.group, self.bucket_bytes = group, bucket_bytes
+        self._pending = []
 
     def world(self):
         return dist.get_world_size(self.group) if dist.is_initialized() else 1
@@ -76,7 +77,21 @@ class GradSync:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return 1.0 / world
 
+    # ---- overlapped form: LinearModel.set_grad_sync(self) makes backward call launch_bucket()
+    #      as soon as a contiguous part of the gradient arena is final -------------------------
+    def launch_bucket(self, flat_slice):
+        if self.world() > 1:
+            self._pending.append(dist.all_reduce(flat_slice, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
     def __call__(self, model):
+        """Scale to apply to the summed gradients.  Waits for buckets launched during backward;
+        if backward launched none (no overlap attached, or gradient accumulation) the whole arena
+        is reduced here."""
+        if self._pending:
+            for w in self._pending:
+                w.wait()
+            self._pending = []
+            return 1.0 / self.world()
         return self.reduce_flat(model.flat_grads)
 
 

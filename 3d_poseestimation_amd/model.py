@@ -86,6 +86,7 @@ class LinearModel(nn.Module):
         self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self._step = 0
         self._inject_keep = None
+        self._grad_sync = None
         self._flat = self._flat_grad = self._flat_grad_tmp = None
         self._ws_pool, self._ws_token = {}, 0
         self._flatten()
@@ -153,6 +154,11 @@ class LinearModel(nn.Module):
         """Key of the Philox dropout stream (csrc/philox.h); give each DP rank its own."""
         self._seed, self._step = int(seed) & 0xFFFFFFFFFFFFFFFF, int(step)
         return self
+
+    def set_grad_sync(self, sync):
+        """Attach a dp.GradSync: backward then all-reduces the upper layers' gradients while the
+        lower layers are still being computed (see pl_lifter_bwd_part)."""
+        self._grad_sync = sync
 
     def debug_inject_keep(self, keep_bitmaps):
         """Parity mode: the next training forward takes its dropout keep decisions from
@@ -225,10 +231,19 @@ class LinearModel(nn.Module):
         else:
             target = self.flat_grads
         dx = torch.empty_like(x2) if need_dx else None
-        rc = _lib.lib().pl_lifter_bwd(
-            ctypes.byref(self._desc), x2.data_ptr(), gy.data_ptr(), B, ws["buf"].data_ptr(), ws["bytes"],
-            dx.data_ptr() if need_dx else None, target.data_ptr(), _lib.current_stream_ptr())
-        _lib.check(rc, "pl_lifter_bwd")
+        args = (ctypes.byref(self._desc), x2.data_ptr(), gy.data_ptr(), B, ws["buf"].data_ptr(), ws["bytes"],
+                dx.data_ptr() if need_dx else None, target.data_ptr())
+        sync = self._grad_sync
+        if sync is not None and not accumulate and sync.world() > 1:
+            # data-parallel overlap: the tail of the arena (output layer + upper hidden layers) is
+            # final after part 0 and is all-reduced while part 1 computes the rest
+            split = self._slots[4 * _lib.lib().pl_bwd_split_layer(ctypes.byref(self._desc))].offset
+            _lib.check(_lib.lib().pl_lifter_bwd_part(*args, 0, _lib.current_stream_ptr()), "pl_lifter_bwd_part(0)")
+            sync.launch_bucket(target[split:])
+            _lib.check(_lib.lib().pl_lifter_bwd_part(*args, 1, _lib.current_stream_ptr()), "pl_lifter_bwd_part(1)")
+            sync.launch_bucket(target[:split])
+        else:
+            _lib.check(_lib.lib().pl_lifter_bwd(*args, _lib.current_stream_ptr()), "pl_lifter_bwd")
         if accumulate:
             for s, p in zip(self._slots, self._param_list):
                 gview = target[s.offset:s.offset + s.numel].view(s.shape)

@@ -171,6 +171,7 @@ def main():
     model.manual_seed(1234 + rank)                          # own dropout stream per rank
     opt = pkg.FlatAdamW(model, lr=1e-4)                     # train_1.py:39 (weight_decay 0.01)
     sync = pkg.dp.GradSync() if world > 1 else None
+    model.set_grad_sync(sync)                               # all-reduce overlapped with the backward tail
     pool = [pkg.synth.synthetic_batch(a.batch, 1234 + 1000 * rank + i, dev) for i in range(8)]
     torch.cuda.synchronize()
 

@@ -108,6 +108,16 @@ int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, int64_t B,
                   void* workspace, size_t workspace_bytes, float* dx,
                   float* flat_grads, void* stream);
 
+/* The same backward cut in two at a layer boundary (data-parallel overlap, no reference
+ * counterpart): part 0 = output layer + hidden layers [split, n_hidden), part 1 = hidden layers
+ * [0, split) (+ dx), split = pl_bwd_split_layer() = num_stage + 1.  After part 0 the gradients of
+ * every tensor from pl_param_offset(d, 4*split) to the end of the arena are final, so their
+ * all-reduce can run while part 1 computes.  part 0 then part 1 == pl_lifter_bwd, bit for bit. */
+int64_t pl_bwd_split_layer(const PLDesc* d);
+int pl_lifter_bwd_part(const PLDesc* d, const float* x, const float* dy, int64_t B,
+                       void* workspace, size_t workspace_bytes, float* dx,
+                       float* flat_grads, int part, void* stream);
+
 /* ---- loss / metric / optimiser -------------------------------------------------- */
 /* torch.nn.MSELoss(reduction="mean") + its backward  train_1.py:37,94-95.
  * n elements; dpred = grad_scale * 2 (pred - tgt) / n; loss_out: 1 device float.
