@@ -6,5 +6,5 @@ alias module at the repository root.
 from ._lib import PoseliftError, lib  # noqa: F401
 from .model import Linear, LinearModel, weight_init  # noqa: F401
 from .optim import FlatAdamW  # noqa: F401
-from .train import epoch_mpjpe_mm, eval_step, loss_MPJPE, mse_loss, train_step  # noqa: F401
+from .train import epoch_mpjpe_mm, eval_step, flip_pose, loss_MPJPE, mse_loss, train_step  # noqa: F401
 from . import dp, layout, synth  # noqa: F401

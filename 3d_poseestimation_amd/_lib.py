@@ -51,10 +51,11 @@ SIGNATURES = {
     "pl_mpjpe_accum": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P, _P]),
     "pl_adamw_flat": (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_float, _c.c_float, _c.c_float,
                                  _c.c_float, _c.c_float, _c.c_int64, _c.c_float, _P]),
+    "pl_flip_pose": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P]),
     "pl_gemm_f32": (_c.c_int, [_c.c_int, _P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P,
                                _c.c_int, _P, _P]),
     "pl_prof_enable": (_c.c_int, [_c.c_int]),
-    "pl_prof_read": (_c.c_int, [_c.c_double, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64),
+    "pl_prof_read": (_c.c_int, [_c.c_double, _c.c_double, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64),
                                 _c.POINTER(_c.c_double)]),
 }
 

@@ -495,7 +495,8 @@ extern "C" int pl_gemm_f32(int layout, const float* A, const float* Bm, float* C
 // measurement hook (bench.py): per-launch GEMM durations from HIP events on the launch stream
 // ---------------------------------------------------------------------------------------
 extern "C" int pl_prof_enable(int on) { return prof_enable(on); }
-extern "C" int pl_prof_read(double min_flops, double* ms_total, int64_t* launches, double* flops_total) {
+extern "C" int pl_prof_read(double min_flops, double max_flops, double* ms_total, int64_t* launches,
+                            double* flops_total) {
   if (!ms_total || !launches || !flops_total) PL_FAIL(PL_EINVAL, "pl_prof_read: null pointer");
-  return prof_read(min_flops, ms_total, launches, flops_total);
+  return prof_read(min_flops, max_flops, ms_total, launches, flops_total);
 }

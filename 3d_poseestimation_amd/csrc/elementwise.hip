@@ -435,6 +435,24 @@ __global__ void mpjpe_final_kernel(const float* __restrict__ part, int np, int J
   }
 }
 
+// ---- flip_pose (phase3_direct/my_HybrIK/utils.py:372-396) -----------------------------------
+// horizontal flip of (B, 17, D) poses: x -> 1-x (D = 2, image-normalised) or -x (D = 3), then
+// left joints [4,5,6,11,12,13] <-> right joints [1,2,3,14,15,16]
+__global__ void flip_pose_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int d = (int)(i % D);
+  const int64_t bj = i / D;
+  const int j = (int)(bj % 17);
+  const int64_t b = bj / 17;
+  // source joint of destination joint j
+  const int src = (j >= 1 && j <= 3) ? j + 3 : (j >= 4 && j <= 6) ? j - 3
+                : (j >= 11 && j <= 13) ? j + 3 : (j >= 14 && j <= 16) ? j - 3 : j;
+  float v = in[(b * 17 + src) * D + d];
+  if (d == 0) v = (D == 2) ? 1.0f - v : -v;
+  out[i] = v;
+}
+
 // ---- flat AdamW (torch single-tensor update order) ----------------------------------------
 struct AdamWK {
   float decay;       // 1 - lr*wd
@@ -709,5 +727,15 @@ extern "C" int pl_adamw_flat(float* p, const float* g, float* m, float* v, int64
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(NTHR), 0, (hipStream_t)stream, p, g, m, v, n, k, vec);
   PL_CHECK_LAUNCH("adamw");
+  return PL_OK;
+}
+
+extern "C" int pl_flip_pose(const float* in, float* out, int64_t B, int64_t joints, int64_t D, void* stream) {
+  if (!in || !out || in == out) PL_FAIL(PL_EINVAL, "pl_flip_pose: null or aliased pointers");
+  if (B <= 0 || joints != 17 || (D != 2 && D != 3)) PL_FAIL(PL_ESHAPE, "pl_flip_pose: expects (B, 17, 2|3)");
+  const int64_t n = B * joints * D;
+  hipLaunchKernelGGL(flip_pose_kernel, dim3((unsigned)((n + NTHR - 1) / NTHR)), dim3(NTHR), 0, (hipStream_t)stream,
+                     in, out, n, (int)D);
+  PL_CHECK_LAUNCH("flip_pose");
   return PL_OK;
 }

@@ -445,12 +445,12 @@ int prof_enable(int on) {
   return PL_OK;
 }
 
-int prof_read(double min_flops, double* ms_total, int64_t* launches, double* flops_total) {
+int prof_read(double min_flops, double max_flops, double* ms_total, int64_t* launches, double* flops_total) {
   double ms = 0, fl = 0;
   int64_t n = 0;
   for (size_t i = 0; i < g_prof_used; ++i) {
     const ProfRec& r = g_prof_pool[i];
-    if (r.flops < min_flops) continue;
+    if (r.flops < min_flops || r.flops > max_flops) continue;
     if (hipEventSynchronize(r.e1) != hipSuccess) PL_FAIL(PL_EHIP, "prof_read: event sync failed");
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) PL_FAIL(PL_EHIP, "prof_read: elapsed time failed");

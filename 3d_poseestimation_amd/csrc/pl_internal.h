@@ -61,7 +61,7 @@ int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s);
 int launch_gemm_f32_pair(const GemmArgs& nn, const GemmArgs& tn, hipStream_t s);
 int gemm_stat_groups(int M);  // number of 64-row groups the stats epilogue emits
 int prof_enable(int on);
-int prof_read(double min_flops, double* ms_total, int64_t* launches, double* flops_total);
+int prof_read(double min_flops, double max_flops, double* ms_total, int64_t* launches, double* flops_total);
 
 // ---------------------------------------------------------------------------------
 // streaming kernels (elementwise.hip)

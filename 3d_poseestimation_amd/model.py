@@ -129,6 +129,19 @@ class LinearModel(nn.Module):
             bn_eps=float(self.batch_norm1.eps), bn_momentum=float(self.batch_norm1.momentum), reserved=0,
             params=flat.data_ptr(), bn_running=running.data_ptr(), bn_batches=batches.data_ptr())
 
+    # ctypes descriptors and device workspaces are rebuilt, not copied (copy.deepcopy / torch.save(model))
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        for k in ("_desc", "_ws_pool", "_flat_grad", "_flat_grad_tmp", "_grad_sync", "last_workspace", "_inject_keep"):
+            st.pop(k, None)
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self._grad_sync = self._inject_keep = None
+        self._ws_pool, self._ws_token = {}, 0
+        self._flatten()
+
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         self._flatten()

@@ -63,6 +63,21 @@ def loss_MPJPE(prediction, target, out=None):
     return metric
 
 
+def flip_pose(data):
+    """utils.py:372-396: horizontal flip of (N, 17, 2|3) poses (x -> 1-x or -x, left/right joints
+    swapped).  The flip-TTA of train_1.py:128-134 is `(flip_pose(model(flip_pose(x))) + model(x)) / 2`."""
+    data = data.contiguous()
+    _lib.require_device_tensor(data, "data")
+    if data.dim() != 3 or data.shape[1] != 17 or data.shape[2] not in (2, 3):
+        raise ValueError("flip_pose expects (N, 17, 2) or (N, 17, 3)")
+    out = torch.empty_like(data)
+    with torch.cuda.device(data.device):
+        rc = _lib.lib().pl_flip_pose(data.data_ptr(), out.data_ptr(), data.shape[0], 17, data.shape[2],
+                                     _lib.current_stream_ptr())
+    _lib.check(rc, "pl_flip_pose")
+    return out
+
+
 def epoch_mpjpe_mm(metric_sum, n_samples, num_of_joints=17, zero_centre=True):
     """train_1.py:100-104 reproduced literally: /len(dataset), mean over joints 1..16,
     then *(17/16)*1000 (mm) when the 17-joint root-centred layout is used."""

@@ -132,6 +132,11 @@ size_t pl_mpjpe_scratch_bytes(int64_t B, int64_t joints);
 int pl_mpjpe_accum(const float* pred, const float* tgt, int64_t B, int64_t joints,
                    float* metric, void* scratch, void* stream);
 
+/* flip_pose  phase3_direct/my_HybrIK/utils.py:372-396 (used by train_1.py:89-92,128-134 when Flip):
+ * out = horizontal flip of in, both [B][17][D], D = 2 (x -> 1-x) or 3 (x -> -x), left/right joints
+ * [4,5,6,11,12,13] <-> [1,2,3,14,15,16] swapped.  Out of place. */
+int pl_flip_pose(const float* in, float* out, int64_t B, int64_t joints, int64_t D, void* stream);
+
 /* torch.optim.AdamW.step  train_1.py:39,96 over one flat arena (p, g, m, v of n floats).
  * t = 1-based step count; g is multiplied by grad_scale first (1/world_size after a
  * sum all-reduce). */
@@ -153,9 +158,11 @@ int pl_gemm_f32(int layout, const float* A, const float* B, float* C, int64_t M,
 /* ---- measurement hook (bench.py; not part of the reference interface) ------------------ */
 /* While enabled, every GEMM launch is bracketed by two HIP events recorded on the launch
  * stream.  pl_prof_read waits for them and sums the durations of the launches whose
- * algorithmic work 2*M*N*K is >= min_flops.  Enabling resets the record.  Not capturable. */
+ * algorithmic work (2*M*N*K, summed over both problems of a dual launch) lies in
+ * [min_flops, max_flops].  Enabling resets the record.  Not capturable. */
 int pl_prof_enable(int on);
-int pl_prof_read(double min_flops, double* ms_total, int64_t* launches, double* flops_total);
+int pl_prof_read(double min_flops, double max_flops, double* ms_total, int64_t* launches,
+                 double* flops_total);
 
 #ifdef __cplusplus
 }

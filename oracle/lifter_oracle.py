@@ -308,3 +308,18 @@ def train_step(st, opt, x, y, *, num_stage=2, use_bn=True, p_dropout=0.5,
         st[k], opt["m"][k], opt["v"][k] = adamw_step(
             st[k], g.astype(st[k].dtype), opt["m"][k], opt["v"][k], opt["t"], lr=lr, wd=wd)
     return loss, pred, grads
+
+
+def flip_pose(data):
+    """flip_pose restated from the text of /root/reference/phase3_direct/my_HybrIK/utils.py:372-396
+    (that module imports cv2/seaborn and cannot be imported here): x -> 1-x for 2-D
+    image-normalised keypoints, x -> -x for 3-D, then left joints [4,5,6,11,12,13] and right joints
+    [1,2,3,14,15,16] trade places."""
+    left, right = [4, 5, 6, 11, 12, 13], [1, 2, 3, 14, 15, 16]
+    out = np.array(data, copy=True)
+    if out.shape[-1] == 2:
+        out[..., 0] = 1 - out[..., 0]
+    elif out.shape[-1] == 3:
+        out[..., 0] *= -1
+    out[..., left + right, :] = out[..., right + left, :]
+    return out

@@ -519,6 +519,17 @@ def test_bf16_mode_train_and_eval_vs_oracle(pkg):
     assert orc.mpjpe_mm(ye, yo) < 20.0
 
 
+def test_flip_pose_vs_oracle(pkg):
+    rng = np.random.default_rng(4)
+    for D in (2, 3):
+        a = rng.random((77, 17, D)).astype(np.float32)
+        got = pkg.flip_pose(_t(a)).cpu().numpy()
+        assert np.array_equal(got, orc.flip_pose(a))
+        assert np.allclose(pkg.flip_pose(_t(got)).cpu().numpy(), a, atol=1e-7)      # an involution
+    with pytest.raises(ValueError):
+        pkg.flip_pose(torch.zeros(4, 16, 3, device=DEV))
+
+
 # ---------------------------------------------------------------------------- API behaviour
 def test_errors_are_loud(pkg):
     m = pkg.LinearModel(34, 51, linear_size=64).to(DEV).train()

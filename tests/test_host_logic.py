@@ -123,3 +123,38 @@ def test_shard_rows_partitions_exactly(pkg):
         assert spans[0][0] == 0 and spans[-1][1] == n
         assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
         assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+
+
+def test_deepcopy_and_pickle_rebuild_the_arenas(pkg, tmp_path):
+    import copy
+    torch.manual_seed(3)
+    m = pkg.LinearModel(34, 51, linear_size=64)
+    for clone in (copy.deepcopy(m), torch.load(_save(m, tmp_path / "m.pt"), weights_only=False)):
+        assert clone._arenas_intact() and clone.flat_params.data_ptr() != m.flat_params.data_ptr()
+        assert all(torch.equal(a, b) for a, b in zip(clone.state_dict().values(), m.state_dict().values()))
+        with torch.no_grad():
+            clone.w2.bias.add_(1.0)                     # writes through to the clone's own arena only
+        s = clone._slots[-1]
+        assert torch.equal(clone.flat_params[s.offset:s.offset + s.numel], clone.w2.bias)
+        assert not torch.equal(clone.w2.bias, m.w2.bias)
+
+
+def _save(obj, path):
+    torch.save(obj, path)        # a file this test wrote itself
+    return path
+
+
+def test_reduce_lr_on_plateau_drives_flat_adamw(pkg):
+    """train_1.py:41,106: ReduceLROnPlateau(factor .7, patience 3, cooldown 2, min_lr 5e-6) stepped with
+    the last batch's loss.  (verbose=True of the reference is a TypeError on torch 2.10: dropped.)"""
+    m = pkg.LinearModel(34, 51, linear_size=64)
+    opt = pkg.FlatAdamW(m, lr=1e-4)
+    sch = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.7, patience=3, cooldown=2, min_lr=5e-6)
+    lrs = []
+    for _ in range(12):
+        sch.step(1.0)                                    # a loss that never improves
+        lrs.append(opt.param_groups[0]["lr"])
+    assert lrs[3] == pytest.approx(1e-4) and lrs[4] == pytest.approx(7e-5) and min(lrs) >= 5e-6
+    assert lrs[-1] < lrs[4]
+    sd = opt.state_dict()
+    assert sd["param_groups"][0]["lr"] == lrs[-1] and len(sd["param_groups"][0]["params"]) == 22
