@@ -7,4 +7,5 @@ from ._lib import PoseliftError, lib  # noqa: F401
 from .model import Linear, LinearModel, weight_init  # noqa: F401
 from .optim import FlatAdamW  # noqa: F401
 from .train import epoch_mpjpe_mm, eval_step, flip_pose, loss_MPJPE, mse_loss, train_step  # noqa: F401
+from .heads import soft_argmax_2d, soft_argmax_3d  # noqa: F401
 from . import dp, layout, synth  # noqa: F401

@@ -52,6 +52,9 @@ SIGNATURES = {
     "pl_adamw_flat": (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_float, _c.c_float, _c.c_float,
                                  _c.c_float, _c.c_float, _c.c_int64, _c.c_float, _P]),
     "pl_flip_pose": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P]),
+    "pl_softargmax_fwd": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _P, _P, _P]),
+    "pl_softargmax_bwd": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,
+                                     _P, _P]),
     "pl_gemm_f32": (_c.c_int, [_c.c_int, _P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P,
                                _c.c_int, _P, _P]),
     "pl_prof_enable": (_c.c_int, [_c.c_int]),

@@ -1,0 +1,55 @@
+"""Fused softmax + integral soft-argmax heads, computed by libposelift.so.
+
+soft_argmax_3d  = the tail of Model_3D.forward   /root/reference/phase4_joined/Model.py:94-133
+soft_argmax_2d  = the tail of Model_2D.forward   /root/reference/phase5_loop/Model_2d.py:96-134
+Both take the final 1x1-conv output of the reference model and are differentiable; the normalised
+heat-map (17.8 MB per frame in 3-D) is never materialised.
+"""
+import torch
+
+from . import _lib
+
+
+class _SoftArgmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, BJ, D, H, W, ncoord, centred):
+        _lib.require_device_tensor(logits, "heat-map logits")
+        coords = torch.empty(BJ, ncoord, dtype=torch.float32, device=logits.device)
+        stats = torch.empty(BJ, 5, dtype=torch.float32, device=logits.device)
+        with torch.cuda.device(logits.device):
+            rc = _lib.lib().pl_softargmax_fwd(logits.data_ptr(), BJ, D, H, W, ncoord, centred, coords.data_ptr(),
+                                              stats.data_ptr(), _lib.current_stream_ptr())
+        _lib.check(rc, "pl_softargmax_fwd")
+        ctx.save_for_backward(logits, stats)
+        ctx.dims = (BJ, D, H, W, ncoord, centred)
+        return coords
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, stats = ctx.saved_tensors
+        BJ, D, H, W, ncoord, centred = ctx.dims
+        g = g.contiguous()
+        dl = torch.empty_like(logits)
+        with torch.cuda.device(logits.device):
+            rc = _lib.lib().pl_softargmax_bwd(logits.data_ptr(), stats.data_ptr(), g.data_ptr(), BJ, D, H, W, ncoord,
+                                              centred, dl.data_ptr(), _lib.current_stream_ptr())
+        _lib.check(rc, "pl_softargmax_bwd")
+        return dl, None, None, None, None, None, None
+
+
+def soft_argmax_3d(out, num_joints=17, depth_dim=64):
+    """(B, num_joints*depth_dim, H, W) logits -> (B, num_joints*3) coordinates in (-1, 1), (x, y, z) per joint."""
+    B, C, H, W = out.shape
+    if C != num_joints * depth_dim:
+        raise ValueError(f"expected {num_joints * depth_dim} channels, got {C}")
+    x = out.contiguous().float()
+    return _SoftArgmaxFn.apply(x, B * num_joints, depth_dim, H, W, 3, 1).reshape(B, num_joints * 3)
+
+
+def soft_argmax_2d(out, num_joints=17):
+    """(B, num_joints, H, W) logits -> (B, num_joints*2) coordinates in (0, 1), (x, y) per joint."""
+    B, C, H, W = out.shape
+    if C != num_joints:
+        raise ValueError(f"expected {num_joints} channels, got {C}")
+    x = out.contiguous().float()
+    return _SoftArgmaxFn.apply(x, B * num_joints, 1, H, W, 2, 0).reshape(B, num_joints * 2)

@@ -155,6 +155,19 @@ int pl_gemm_f32(int layout, const float* A, const float* B, float* C, int64_t M,
                 int64_t N, int64_t K, const float* bias, int split_k, float* slabs,
                 void* stream);
 
+/* ---- next row N1: fused softmax + integral soft-argmax ----------------------------------- */
+/* Tail of Model_3D.forward  phase4_joined/Model.py:94-133 (ncoord 3, centred 1: (E/dim - 0.5)*2)
+ * and of Model_2D.forward  phase5_loop/Model_2d.py:96-134 (ncoord 2, D 1, centred 0: E/dim).
+ * logits [BJ][D][H][W] (BJ = batch*joints, W % 4 == 0): softmax over the D*H*W voxels of each
+ * (batch, joint), then the expectation of the w / h / d index.  coords [BJ][ncoord] in (x, y, z)
+ * order; stats [BJ][5] = {max, sum exp, Ex, Ey, Ez} is what the backward needs.
+ * Backward: dlogits [BJ][D][H][W] from gcoords [BJ][ncoord]; re-reads logits, materialises nothing. */
+int pl_softargmax_fwd(const float* logits, int64_t BJ, int64_t D, int64_t H, int64_t W, int ncoord,
+                      int centred, float* coords, float* stats, void* stream);
+int pl_softargmax_bwd(const float* logits, const float* stats, const float* gcoords, int64_t BJ,
+                      int64_t D, int64_t H, int64_t W, int ncoord, int centred, float* dlogits,
+                      void* stream);
+
 /* ---- measurement hook (bench.py; not part of the reference interface) ------------------ */
 /* While enabled, every GEMM launch is bracketed by two HIP events recorded on the launch
  * stream.  pl_prof_read waits for them and sums the durations of the launches whose

@@ -519,6 +519,34 @@ def test_bf16_mode_train_and_eval_vs_oracle(pkg):
     assert orc.mpjpe_mm(ye, yo) < 20.0
 
 
+def test_eval_forward_is_graph_capturable(pkg):
+    """The library only enqueues on the caller's stream (no allocation, no sync), so a forward can be
+    captured into a HIP graph and replayed on new inputs."""
+    torch.manual_seed(0)
+    m = pkg.LinearModel(34, 51, linear_size=256).to(DEV).eval()
+    x = torch.rand(512, 17, 2, device=DEV)
+    with torch.no_grad():
+        want = m(x).clone()                               # also allocates the workspace up front
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            m(x)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        xs = x.clone()
+        with torch.cuda.graph(g):
+            ys = m(xs)
+        x2 = torch.rand(512, 17, 2, device=DEV)
+        xs.copy_(x2)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(ys, m(x2))
+        xs.copy_(x)
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(ys, want)
+
+
 def test_flip_pose_vs_oracle(pkg):
     rng = np.random.default_rng(4)
     for D in (2, 3):
