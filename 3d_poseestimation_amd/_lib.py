@@ -11,7 +11,7 @@ import torch  # noqa: F401  (loads torch's bundled HIP runtime first so the libr
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libposelift.so")
 
-PL_F32, PL_BF16 = 0, 1
+PL_F32, PL_BF16, PL_BF16X6 = 0, 1, 2
 
 
 class PLDesc(ctypes.Structure):

@@ -32,7 +32,8 @@ int check_desc(const PLDesc* d, bool need_arenas) {
   if (d->in_dim <= 0 || d->out_dim <= 0 || d->hidden <= 0 || d->num_stage < 0)
     PL_FAIL(PL_ESHAPE, "bad dims in=%d hidden=%d out=%d stages=%d", d->in_dim, d->hidden, d->out_dim, d->num_stage);
   if (d->hidden % 4 != 0) PL_FAIL(PL_ESHAPE, "hidden=%d must be a multiple of 4", d->hidden);
-  if (d->dtype != PL_F32 && d->dtype != PL_BF16) PL_FAIL(PL_EDTYPE, "dtype %d is not a PLDtype", d->dtype);
+  if (d->dtype != PL_F32 && d->dtype != PL_BF16 && d->dtype != PL_BF16X6)
+    PL_FAIL(PL_EDTYPE, "dtype %d is not a PLDtype", d->dtype);
   if (!(d->p_dropout >= 0.f && d->p_dropout <= 1.f)) PL_FAIL(PL_EINVAL, "p_dropout=%f outside [0,1]", d->p_dropout);
   if (need_arenas) {
     if (!d->params) PL_FAIL(PL_EINVAL, "params arena is NULL");
@@ -288,7 +289,7 @@ extern "C" int pl_lifter_fwd_eval(const PLDesc* d, const float* x, float* y, int
     GemmArgs g = {};
     g.A = a_in; g.B = ly.W; g.C = f32(ws, w.act[l]);
     g.M = (int)B; g.N = H; g.K = ly.K; g.lda = ly.K; g.ldb = ly.K; g.ldc = H; g.split_k = 1;
-    g.bf16 = d->dtype == PL_BF16;
+    g.arith = d->dtype;
     g.col_scale = f32(ws, w.scale) + (size_t)l * H;
     g.col_shift = f32(ws, w.shift) + (size_t)l * H;
     g.relu = 1;
@@ -323,7 +324,7 @@ extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, in
     GemmArgs g = {};
     g.A = a_in; g.B = ly.W; g.C = f32(ws, w.z[l]); g.bias = ly.b;
     g.M = (int)B; g.N = H; g.K = ly.K; g.lda = ly.K; g.ldb = ly.K; g.ldc = H; g.split_k = 1;
-    g.bf16 = d->dtype == PL_BF16;
+    g.arith = d->dtype;
     if (d->bn) { g.stat_sum = f32(ws, w.stat_a); g.stat_m2 = f32(ws, w.stat_b); }
     int groups = w.G;
     if (l == 0 && skinny_supported(ly.K, H)) {
@@ -426,9 +427,9 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
       GemmArgs g = {};
       g.A = DZ; g.B = ly.W; g.M = Bi; g.N = H; g.K = H; g.lda = H; g.ldb = H; g.ldc = H; g.split_k = 1;
       if (l % 2 == 1) { g.C = GA; g.addend = GA; } else { g.C = GB; }
-      g.bf16 = d->dtype == PL_BF16;
+      g.arith = d->dtype;
       GemmArgs t = {};
-      t.bf16 = g.bf16;
+      t.arith = g.arith;
       t.A = DZ; t.B = a_in; t.M = H; t.N = H; t.K = Bi; t.lda = H; t.ldb = H; t.ldc = H;
       const int splits = tn_splits(H, H, Bi);
       t.split_k = splits; t.C = splits > 1 ? slabs : ly.gW;

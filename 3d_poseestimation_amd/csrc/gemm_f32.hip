@@ -158,7 +158,35 @@ __device__ __forceinline__ bf16x8 read_frag_bf16(const float* __restrict__ s, in
   return r;
 }
 
-template <bool A_KS, bool B_KS, bool EDGE, bool BF = false>
+// PL_BF16X6: fp32-grade products from bf16 MFMAs.  Each fp32 operand is split into three bf16
+// pieces (8 + 8 + 8 = 24 mantissa bits: x = x0 + x1 + x2 exactly), and a*b is accumulated as the six
+// products a0b0, a0b1, a1b0, a0b2, a1b1, a2b0 (every bf16 x bf16 product is exact in the fp32
+// accumulator; the three dropped terms are below 2^-24 |ab|).  Six MFMAs at 16x the fp32 rate.
+template <bool KS>
+__device__ __forceinline__ void read_frag_raw(const float* __restrict__ s, int row, int s16, int h,
+                                              float (&f)[8]) {
+  if (!KS) {
+    const float4 u = *reinterpret_cast<const float4*>(s + row * KC_LD + s16 * 16 + 8 * h);
+    const float4 v = *reinterpret_cast<const float4*>(s + row * KC_LD + s16 * 16 + 8 * h + 4);
+    f[0] = u.x; f[1] = u.y; f[2] = u.z; f[3] = u.w; f[4] = v.x; f[5] = v.y; f[6] = v.z; f[7] = v.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = s[(s16 * 16 + 8 * h + j) * KS_LD + row];
+  }
+}
+
+__device__ __forceinline__ void split3(const float (&f)[8], bf16x8 (&p)[3]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 x0 = (__bf16)f[j];
+    const float r1 = f[j] - (float)x0;
+    const __bf16 x1 = (__bf16)r1;
+    const float r2 = r1 - (float)x1;
+    p[0][j] = x0; p[1][j] = x1; p[2][j] = (__bf16)r2;
+  }
+}
+
+template <bool A_KS, bool B_KS, bool EDGE, int AR = 0>
 __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id, const int nwork,
                                           float* __restrict__ lds) {
   const int tid = threadIdx.x;
@@ -313,6 +341,50 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
     if (has_next.value) PL_FRAGS_BF(0, nxt, 0);
     PL_MFMAS_BF(1);
   };
+  // PL_BF16X6 variant: raw fp32 fragments are double-buffered; each is split into three bf16
+  // planes right before its 24 MFMAs.
+  float xa[2][2][8], xb[2][2][8];
+#define PL_FRAGS_X6(set, buf, s16)                                                       \
+  do {                                                                                   \
+    _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) {                                   \
+      read_frag_raw<A_KS>((buf), wm * 64 + t2 * 32 + i, (s16), h, xa[set][t2]);          \
+      read_frag_raw<B_KS>((buf) + OP_FLOATS, wn * 64 + t2 * 32 + i, (s16), h, xb[set][t2]); \
+    }                                                                                    \
+  } while (0)
+#define PL_MF(aa, bb, ia, ib) acc[aa][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[aa][ia], b3[bb][ib], acc[aa][bb], 0, 0, 0)
+#define PL_MFMAS_X6(set)                                               \
+  do {                                                                 \
+    bf16x8 a3[2][3], b3[2][3];                                         \
+    _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) {                 \
+      split3(xa[set][t2], a3[t2]);                                     \
+      split3(xb[set][t2], b3[t2]);                                     \
+    }                                                                  \
+    _Pragma("unroll") for (int aa = 0; aa < 2; ++aa)                   \
+    _Pragma("unroll") for (int bb = 0; bb < 2; ++bb) {                 \
+      PL_MF(aa, bb, 2, 0); PL_MF(aa, bb, 1, 1); PL_MF(aa, bb, 0, 2);   \
+      PL_MF(aa, bb, 1, 0); PL_MF(aa, bb, 0, 1); PL_MF(aa, bb, 0, 0);   \
+    }                                                                  \
+  } while (0)
+  auto step_x6 = [&](const int kt, auto do_store, auto do_load, auto has_next) {
+    const float* cur = lds + (kt & 1) * 2 * OP_FLOATS;
+    float* nxt = lds + ((kt + 1) & 1) * 2 * OP_FLOATS;
+    if (do_store.value) {
+      store_tile<A_KS>(nxt, tid, ra);
+      store_tile<B_KS>(nxt + OP_FLOATS, tid, rb);
+    }
+    if (do_load.value) {
+      const int k0 = kbeg + (kt + 2) * BK;
+      ra = load_tile<A_KS, EDGE>(p.A, p.lda, m0, p.M, k0, kend, a_vec, tid);
+      rb = load_tile<B_KS, EDGE>(p.B, p.ldb, n0, p.N, k0, kend, b_vec, tid);
+    }
+    PL_FRAGS_X6(1, cur, 1);
+    PL_MFMAS_X6(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_next.value) PL_FRAGS_X6(0, nxt, 0);
+    PL_MFMAS_X6(1);
+  };
   using T = std::true_type;
   using F = std::false_type;
 
@@ -327,7 +399,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
     }
     __syncthreads();
     int kt = 0;
-    if (BF) {
+    if (AR == 2) {
+      PL_FRAGS_X6(0, lds, 0);
+      for (; kt + 2 < nk; ++kt) step_x6(kt, T{}, T{}, T{});
+      if (kt + 1 < nk) { step_x6(kt, T{}, F{}, T{}); ++kt; }
+      step_x6(kt, F{}, F{}, F{});
+    } else if (AR == 1) {
       PL_FRAGS_BF(0, lds, 0);
       for (; kt + 2 < nk; ++kt) step_bf(kt, T{}, T{}, T{});
       if (kt + 1 < nk) { step_bf(kt, T{}, F{}, T{}); ++kt; }
@@ -341,6 +418,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
   }
 #undef PL_FRAGS_BF
 #undef PL_MFMAS_BF
+#undef PL_FRAGS_X6
+#undef PL_MFMAS_X6
+#undef PL_MF
 #undef PL_SGB
 #undef PL_FRAGS
 #undef PL_MFMAS
@@ -407,10 +487,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
   }
 }
 
-template <bool A_KS, bool B_KS, bool EDGE, bool BF = false>
+template <bool A_KS, bool B_KS, bool EDGE, int AR = 0>
 __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];   // one static array (73,728 B)
-  gemm_body<A_KS, B_KS, EDGE, BF>(p, blockIdx.x, gridDim.x, lds);
+  gemm_body<A_KS, B_KS, EDGE, AR>(p, blockIdx.x, gridDim.x, lds);
 }
 
 // Two independent whole-tile GEMMs in ONE launch: workgroups [0, n0) run the NN problem
@@ -418,13 +498,13 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(GemmArgs p) {
 // with 256 + 256 workgroups every CU hosts one of each (2 x 73.7 KB LDS, 2 waves per SIMD), so
 // one GEMM's prologue / epilogue-store / barrier bubbles are filled by the other's MFMAs, and
 // a launch boundary plus its dirty-L2 write-back disappears.
-template <bool BF>
+template <int AR>
 __global__ __launch_bounds__(NTHR) void gemm_f32_dual_kernel(GemmArgs p0, GemmArgs p1, int n0) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   if ((int)blockIdx.x < n0)
-    gemm_body<false, true, false, BF>(p0, blockIdx.x, n0, lds);
+    gemm_body<false, true, false, AR>(p0, blockIdx.x, n0, lds);
   else
-    gemm_body<true, true, false, BF>(p1, blockIdx.x - n0, gridDim.x - n0, lds);
+    gemm_body<true, true, false, AR>(p1, blockIdx.x - n0, gridDim.x - n0, lds);
 }
 
 }  // namespace
@@ -496,9 +576,10 @@ int launch_gemm_f32_pair(const GemmArgs& nn, const GemmArgs& tn, hipStream_t s) 
   GemmArgs both = nn;                 // profiling record: one launch, the work of two
   ProfRec* prof = prof_begin(both, s);
   if (prof) prof->flops += 2.0 * tn.M * tn.N * tn.K;
-  if (nn.bf16 != tn.bf16) PL_FAIL(PL_EINVAL, "gemm pair: mixed arithmetic");
-  if (nn.bf16) hipLaunchKernelGGL(gemm_f32_dual_kernel<true>, dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
-  else hipLaunchKernelGGL(gemm_f32_dual_kernel<false>, dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
+  if (nn.arith != tn.arith) PL_FAIL(PL_EINVAL, "gemm pair: mixed arithmetic");
+  if (nn.arith == 2) hipLaunchKernelGGL(gemm_f32_dual_kernel<2>, dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
+  else if (nn.arith == 1) hipLaunchKernelGGL(gemm_f32_dual_kernel<1>, dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
+  else hipLaunchKernelGGL(gemm_f32_dual_kernel<0>, dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
   if (prof) (void)hipEventRecord(prof->e1, s);
   PL_CHECK_LAUNCH("gemm_f32_dual");
   return PL_OK;
@@ -517,7 +598,8 @@ int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s) {
   const bool whole = whole_tiles(a);
 #define PL_GEMM_LAUNCH(AKS, BKS)                                                                          \
   do {                                                                                                    \
-    if (whole && a.bf16) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false, true>), grid, block, lds_bytes, s, a); \
+    if (whole && a.arith == 2) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false, 2>), grid, block, lds_bytes, s, a); \
+    else if (whole && a.arith == 1) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false, 1>), grid, block, lds_bytes, s, a); \
     else if (whole) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false>), grid, block, lds_bytes, s, a);      \
     else hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, true>), grid, block, lds_bytes, s, a);             \
   } while (0)

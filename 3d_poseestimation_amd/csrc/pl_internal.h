@@ -53,7 +53,8 @@ struct GemmArgs {
   const float* col_shift;
   int relu;                 // v = max(v, 0)
   const float* resid;       // [M][ldc] v += resid[row][col] after relu (may alias C)
-  int bf16;                 // PL_BF16 mode: operands rounded to bf16 on the way to the MFMA
+  int arith;                // 0 fp32 MFMA; 1 PL_BF16: operands rounded to bf16 on the way to the MFMA;
+                            // 2 PL_BF16X6: three-way bf16 split, six MFMAs, fp32-grade products
                             // (whole-tile problems only; edge problems stay fp32)
 };
 

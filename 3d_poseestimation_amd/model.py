@@ -81,7 +81,7 @@ class LinearModel(nn.Module):
         self.linear_stages = nn.ModuleList(Linear(linear_size, p_dropout, BN) for _ in range(num_stage))
         self.w2 = nn.Linear(linear_size, o_dim)
         self.BN = BN
-        self.compute_dtype = {"fp32": _lib.PL_F32, "bf16": _lib.PL_BF16}[compute_dtype]
+        self.compute_dtype = {"fp32": _lib.PL_F32, "bf16": _lib.PL_BF16, "bf16x6": _lib.PL_BF16X6}[compute_dtype]
         self._slots, self._arena_floats = param_slots(i_dim, linear_size, o_dim, num_stage)
         self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self._step = 0

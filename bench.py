@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (default: BASELINE config 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
-    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--dtype", choices=["fp32", "bf16", "bf16x6"], default="fp32",
                     help="GEMM arithmetic of the headline run (fp32 is the parity-gated mode)")
     ap.add_argument("--no-extras", action="store_true", help="skip the bf16-mode and PyTorch-eager side measurements")
     return ap.parse_args()
@@ -118,19 +118,22 @@ def side_measurements(pkg, a, dev, x_eval, y_oracle):
         torch.cuda.synchronize()
         return a.batch * n / (time.perf_counter() - t0)
 
-    other = "bf16" if a.dtype == "fp32" else "fp32"
-    torch.manual_seed(0)
-    m = pkg.LinearModel(34, 51, compute_dtype=other).to(dev).train()
-    opt = pkg.FlatAdamW(m, lr=1e-4)
     xb, yb = pkg.synth.synthetic_batch(a.batch, 99, dev)
-    v = timed(lambda: pkg.train_step(m, opt, xb, yb))
-    m.eval()
-    with torch.no_grad():
-        ye = m(x_eval).cpu().numpy()
-    st = {k: t.detach().cpu().numpy() for k, t in m.state_dict().items()}
-    yo, _ = orc.forward(st, x_eval.cpu().numpy(), num_stage=2, train=False)
-    res[f"this_library_{other}"] = {"poses_per_s": round(v, 1), "mpjpe_mm_eval_fwd_vs_oracle": float(f"{orc.mpjpe_mm(ye, yo):.3e}")}
-    del m, opt
+    for other in ("fp32", "bf16x6", "bf16"):
+        if other == a.dtype:
+            continue
+        torch.manual_seed(0)
+        m = pkg.LinearModel(34, 51, compute_dtype=other).to(dev).train()
+        opt = pkg.FlatAdamW(m, lr=1e-4)
+        v = timed(lambda: pkg.train_step(m, opt, xb, yb))
+        m.eval()
+        with torch.no_grad():
+            ye = m(x_eval).cpu().numpy()
+        st = {k: t.detach().cpu().numpy() for k, t in m.state_dict().items()}
+        yo, _ = orc.forward(st, x_eval.cpu().numpy(), num_stage=2, train=False)
+        res[f"this_library_{other}"] = {"poses_per_s": round(v, 1),
+                                        "mpjpe_mm_eval_fwd_vs_oracle": float(f"{orc.mpjpe_mm(ye, yo):.3e}")}
+        del m, opt
 
     for name, autocast in (("pytorch_rocm_eager_fp32", False), ("pytorch_rocm_eager_bf16_autocast", True)):
         torch.manual_seed(0)
@@ -265,7 +268,8 @@ def main():
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}",
                        "gemm_arith": "fp32 MFMA (v_mfma_f32_32x32x2_f32)" if a.dtype == "fp32"
-                       else "bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate and storage"},
+                       else "bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate and storage"
+                       + (", three-way operand split x 6 products (fp32-grade)" if a.dtype == "bf16x6" else "")},
             "step_tflops": round(value * FLOP_PER_POSE / 1e12, 2),
             "step_frac_of_matrix_peak": round(value * FLOP_PER_POSE / 1e12 / (
                 (PEAK_F32_MATRIX_TFLOPS if a.dtype == "fp32" else PEAK_BF16_MATRIX_TFLOPS) * world), 4),

@@ -135,12 +135,19 @@ def test_gemm_tn_split_k(pkg, M, N, K, splits):
 
 
 # ---------------------------------------------------------------------------- golden vectors
-def test_g1_eval_forward_vs_reference(pkg):
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x6"])
+def test_g1_eval_forward_vs_reference(pkg, dtype):
+    """The BASELINE.json gate.  bf16x6 (three-way bf16 split, six MFMAs per product) must meet it
+    too; the batch is tiled to 128 rows so that its whole-tile MFMA path is the one that runs."""
     g = load_golden("g1_eval_full.npz")
     st = orc.init_state(34, 51, 1024, 2, rng=np.random.default_rng(int(g["weight_seed"])), nontrivial_bn=True)
-    m = _model_from_state(pkg, st, 1024, 2, 0.5, True).eval()
+    m = pkg.LinearModel(34, 51, linear_size=1024, compute_dtype=dtype).to(DEV)
+    m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in st.items()})
+    m.eval()
     with torch.no_grad():
-        y = m(_t(g["x"])).cpu().numpy()
+        y = m(_t(np.concatenate([g["x"], g["x"]]))).cpu().numpy()
+    assert np.array_equal(y[:64], y[64:])
+    y = y[:64]
     assert orc.mpjpe_mm(y, g["y"]) < 1e-3            # BASELINE.json parity gate, reference fp32 forward
     assert orc.mpjpe_mm(y, g["y_fp64"]) < 1e-3       # and against the reference run in fp64
 
@@ -556,6 +563,38 @@ def test_flip_pose_vs_oracle(pkg):
         assert np.allclose(pkg.flip_pose(_t(got)).cpu().numpy(), a, atol=1e-7)      # an involution
     with pytest.raises(ValueError):
         pkg.flip_pose(torch.zeros(4, 16, 3, device=DEV))
+
+
+def test_bf16x6_mode_is_fp32_grade(pkg):
+    """PL_BF16X6 at the bench size: train fwd/bwd against the oracle with the fp32 tolerances."""
+    torch.manual_seed(0)
+    B, H = 1024, 1024
+    m = pkg.LinearModel(34, 51, linear_size=H, p_dropout=0.5, compute_dtype="bf16x6").to(DEV).train()
+    st = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    x, y = pkg.synth.synthetic_batch(B, 31, DEV)
+    m.manual_seed(8, step=0)
+    pred = m(x).reshape(B, 17, 3)
+    pkg.mse_loss(pred, y).backward()
+    masks = [philox.dropout_keep_mask(8, 1, l, B, H, 0.5) for l in range(5)]
+    p64, _ = orc.forward({k: v.copy() for k, v in st.items()}, x.cpu().numpy(), num_stage=2, train=True,
+                         p_dropout=0.5, keep_masks=masks, dtype=np.float64)
+    opred, cache = orc.forward(st, x.cpu().numpy(), num_stage=2, train=True, p_dropout=0.5, keep_masks=masks,
+                               on_masks=_gpu_decisions(pkg, m, 5, H))
+    _assert_decisions_consistent(cache)
+    _assert_train_fwd(pred.detach().cpu().numpy(), opred, p64)
+    _, dpred = orc.mse_loss(opred, y.cpu().numpy().reshape(B, -1))
+    ograds, _ = orc.backward(st, cache, dpred)
+    got = _grads(m)
+    for k, v in ograds.items():
+        pre_bn_bias = k.endswith(".bias") and "batch_norm" not in k and k != "w2.bias"
+        scale = np.abs(ograds[k[:-4] + "weight"]).max() if pre_bn_bias else np.abs(v).max()
+        _close(got[k] / scale, v / scale, 0, 2e-3 if pre_bn_bias else 1e-3 if k == "w1.weight" else 5e-5)
+    m.eval()
+    with torch.no_grad():
+        ye = m(x).cpu().numpy()
+    st2 = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    yo64, _ = orc.forward(st2, x.cpu().numpy(), num_stage=2, train=False, dtype=np.float64)
+    assert orc.mpjpe_mm(ye, yo64) < 1e-3
 
 
 # ---------------------------------------------------------------------------- API behaviour
