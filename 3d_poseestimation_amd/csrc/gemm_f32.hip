@@ -342,7 +342,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
     PL_MFMAS_BF(1);
   };
   // PL_BF16X6 variant: raw fp32 fragments are double-buffered; each is split into three bf16
-  // planes right before its 24 MFMAs.
+  // planes right before its 24 MFMAs.  Measured at B=4096: 60 us per forward GEMM against 41 us in
+  // PL_BF16 mode (whose loop is bound by staging 32 KB of fp32 operands per K tile from L2, ~10.7
+  // TB/s chip-wide) and 77 us on the fp32 MFMA.  The extra 19 us is the wave's VALU ISSUE port:
+  // ~450 split instructions per tile at 4 cycles each exceed the 1,536 cycles of matrix work, and a
+  // lone wave per SIMD issues one instruction at a time -- weaving the split into the MFMA shadows
+  // (sched_group_barrier) produced the intended ISA and changed nothing.  Next lever: 8-wave
+  // workgroups (two waves per SIMD share the issue port) or splitting once per element at staging.
   float xa[2][2][8], xb[2][2][8];
 #define PL_FRAGS_X6(set, buf, s16)                                                       \
   do {                                                                                   \
