@@ -57,6 +57,8 @@ SIGNATURES = {
                                      _P, _P]),
     "pl_gemm_f32": (_c.c_int, [_c.c_int, _P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P,
                                _c.c_int, _P, _P]),
+    "pl_gemm_arith": (_c.c_int, [_c.c_int, _c.c_int, _P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P,
+                                 _c.c_int, _P, _P]),
     "pl_prof_enable": (_c.c_int, [_c.c_int]),
     "pl_prof_read": (_c.c_int, [_c.c_double, _c.c_double, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64),
                                 _c.POINTER(_c.c_double)]),

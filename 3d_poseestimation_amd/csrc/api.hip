@@ -473,7 +473,13 @@ extern "C" int pl_lifter_bwd_part(const PLDesc* d, const float* x, const float* 
 // ---------------------------------------------------------------------------------------
 extern "C" int pl_gemm_f32(int layout, const float* A, const float* Bm, float* C, int64_t M, int64_t N,
                            int64_t K, const float* bias, int split_k, float* slabs, void* stream) {
+  return pl_gemm_arith(layout, PL_F32, A, Bm, C, M, N, K, bias, split_k, slabs, stream);
+}
+
+extern "C" int pl_gemm_arith(int layout, int arith, const float* A, const float* Bm, float* C, int64_t M,
+                             int64_t N, int64_t K, const float* bias, int split_k, float* slabs, void* stream) {
   if (layout < 0 || layout > 2) PL_FAIL(PL_EINVAL, "pl_gemm_f32: layout %d", layout);
+  if (arith < 0 || arith > 2) PL_FAIL(PL_EDTYPE, "pl_gemm_arith: arith %d", arith);
   if (M <= 0 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX)
     PL_FAIL(PL_ESHAPE, "pl_gemm_f32: bad shape");
   GemmArgs g = {};
@@ -482,6 +488,7 @@ extern "C" int pl_gemm_f32(int layout, const float* A, const float* Bm, float* C
   g.ldb = layout == kNT ? (int)K : (int)N;
   g.ldc = (int)N;
   g.split_k = 1;
+  g.arith = arith;
   hipStream_t s = (hipStream_t)stream;
   if (split_k > 1) {
     if (layout != kTN || !slabs || bias) PL_FAIL(PL_EINVAL, "pl_gemm_f32: split_k needs layout 2, slabs and no bias");

@@ -25,6 +25,7 @@
 //     64-row group, merged later with Chan's formula -- no E[z^2]-E[z]^2 cancellation).
 //   * blockIdx -> (K slice, tile) map gives each XCD (private 4 MiB L2) a contiguous band of
 //     M-tiles of one K slice.
+#include <stdlib.h>
 #include <type_traits>
 #include <vector>
 
@@ -46,7 +47,7 @@ constexpr int LDS_FLOATS = 4 * OP_FLOATS; // 2 operands x 2 buffers = 73,728 B
 // float4[4] passed by reference ends up in scratch memory under hipcc once scheduling
 // barriers are present).  EDGE=false is the hot path: whole tiles, 16-byte aligned rows, no
 // guards -- eight back-to-back global_load_dwordx4 per thread and K tile.
-struct Stage { float4 v0, v1, v2, v3; };
+struct Stage { float4 v0, v1, v2, v3; };   // NT = 256 threads use all four, NT = 512 the first two
 
 template <bool KS, bool EDGE>
 __device__ __forceinline__ float4 load_one(const float* __restrict__ base, int ld, int r0, int R,
@@ -80,7 +81,7 @@ __device__ __forceinline__ float4 load_one(const float* __restrict__ base, int l
   }
 }
 
-template <bool KS, bool EDGE>
+template <bool KS, bool EDGE, int NT>
 __device__ __forceinline__ Stage load_tile(const float* __restrict__ base, int ld, int r0, int R,
                                            int k0, int Kend, bool vec_ok, int tid) {
   Stage s;
@@ -89,17 +90,21 @@ __device__ __forceinline__ Stage load_tile(const float* __restrict__ base, int l
     // become `global_load_dwordx4 v, voff, s[base]` with no per-tile 64-bit address arithmetic
     const float* t = KS ? base + (size_t)k0 * ld + r0 : base + (size_t)r0 * ld + k0;
     const int o0 = KS ? (tid >> 5) * ld + (tid & 31) * 4 : (tid >> 3) * ld + (tid & 7) * 4;
-    const int step = KS ? 8 * ld : 32 * ld;     // 256 threads further on: +8 k rows / +32 rows
+    const int step = KS ? (NT / 32) * ld : (NT / 8) * ld;   // NT threads further on: +NT/32 k rows / +NT/8 rows
     s.v0 = *reinterpret_cast<const float4*>(t + o0);
     s.v1 = *reinterpret_cast<const float4*>(t + o0 + step);
-    s.v2 = *reinterpret_cast<const float4*>(t + o0 + 2 * step);
-    s.v3 = *reinterpret_cast<const float4*>(t + o0 + 3 * step);
+    if (NT == 256) {
+      s.v2 = *reinterpret_cast<const float4*>(t + o0 + 2 * step);
+      s.v3 = *reinterpret_cast<const float4*>(t + o0 + 3 * step);
+    }
     return s;
   }
   s.v0 = load_one<KS, EDGE>(base, ld, r0, R, k0, Kend, vec_ok, tid);
-  s.v1 = load_one<KS, EDGE>(base, ld, r0, R, k0, Kend, vec_ok, tid + NTHR);
-  s.v2 = load_one<KS, EDGE>(base, ld, r0, R, k0, Kend, vec_ok, tid + 2 * NTHR);
-  s.v3 = load_one<KS, EDGE>(base, ld, r0, R, k0, Kend, vec_ok, tid + 3 * NTHR);
+  s.v1 = load_one<KS, EDGE>(base, ld, r0, R, k0, Kend, vec_ok, tid + NT);
+  if (NT == 256) {
+    s.v2 = load_one<KS, EDGE>(base, ld, r0, R, k0, Kend, vec_ok, tid + 2 * NT);
+    s.v3 = load_one<KS, EDGE>(base, ld, r0, R, k0, Kend, vec_ok, tid + 3 * NT);
+  }
   return s;
 }
 
@@ -111,20 +116,22 @@ __device__ __forceinline__ void store_one(float* __restrict__ s, int idx, float4
     *reinterpret_cast<float4*>(s + (idx >> 5) * KS_LD + (idx & 31) * 4) = v;
 }
 
-template <bool KS>
+template <bool KS, int NT>
 __device__ __forceinline__ void store_tile(float* __restrict__ s, int tid, const Stage& g) {
   store_one<KS>(s, tid, g.v0);
-  store_one<KS>(s, tid + NTHR, g.v1);
-  store_one<KS>(s, tid + 2 * NTHR, g.v2);
-  store_one<KS>(s, tid + 3 * NTHR, g.v3);
+  store_one<KS>(s, tid + NT, g.v1);
+  if (NT == 256) {
+    store_one<KS>(s, tid + 2 * NT, g.v2);
+    store_one<KS>(s, tid + 3 * NT, g.v3);
+  }
 }
 
 // Fragment fetch for one 8-wide k chunk: f[t][j] feeds MFMA j of 32x32 tile t.
-template <bool KS>
+template <bool KS, int NTILE>
 __device__ __forceinline__ void read_frag(const float* __restrict__ s, int row0, int c8, int i,
-                                          int h, float (&f)[2][4]) {
+                                          int h, float (&f)[NTILE][4]) {
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
+  for (int t = 0; t < NTILE; ++t) {
     if (!KS) {
       const float4 v =
           *reinterpret_cast<const float4*>(s + (row0 + t * 32 + i) * KC_LD + c8 * 8 + 4 * h);
@@ -186,13 +193,20 @@ __device__ __forceinline__ void split3(const float (&f)[8], bf16x8 (&p)[3]) {
   }
 }
 
-template <bool A_KS, bool B_KS, bool EDGE, int AR = 0>
+// NW = 4 wavefronts (2x2, 64x64 per wave) is what ships.  NW = 8 (2x4, 64x32 per wave, 512 threads) is
+// kept compilable: it was built for the VALU-heavy PL_BF16X6 arithmetic on the theory that two
+// waves per SIMD would share the instruction issue port, and measured SLOWER (forward 62 vs 59 us; the
+// dual launch 127 vs 106 us because its two halves no longer fit one CU together).
+template <bool A_KS, bool B_KS, bool EDGE, int AR = 0, int NW = 4>
 __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id, const int nwork,
                                           float* __restrict__ lds) {
+  constexpr int NT = 64 * NW;               // threads
+  constexpr int NB = NW == 4 ? 2 : 1;       // 32-column MFMA tiles per wave
+  constexpr int WCOLS = 32 * NB;            // columns per wave
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = NW == 4 ? wave >> 1 : wave >> 2, wn = NW == 4 ? wave & 1 : wave & 3;
 
   // ---- tile id: XCD-aware remap (blocks b and b+8 share an XCD) ------------------------
   // The grid is 1-D over (K slice, tile), slice-major.  Workgroups b and b+8 share an XCD, so
@@ -223,11 +237,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
   const bool a_vec = ((p.lda & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.A) & 15) == 0);
   const bool b_vec = ((p.ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.B) & 15) == 0);
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][NB];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < NB; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -242,17 +256,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
   //     fetched its last fragments of this buffer (so the next step may overwrite it) and
   //     has long since written the other buffer (so chunk 3 can prefetch the next tile's
   //     first fragments from it) -- the MFMA pipe never drains at a tile boundary.
-  float fa[2][2][4], fb[2][2][4];
-#define PL_FRAGS(set, buf, c8)                                        \
-  do {                                                                \
-    read_frag<A_KS>((buf), wm * 64, (c8), i, h, fa[set]);             \
-    read_frag<B_KS>((buf) + OP_FLOATS, wn * 64, (c8), i, h, fb[set]); \
+  float fa[2][2][4], fb[2][NB][4];
+#define PL_FRAGS(set, buf, c8)                                                  \
+  do {                                                                          \
+    read_frag<A_KS, 2>((buf), wm * 64, (c8), i, h, fa[set]);                    \
+    read_frag<B_KS, NB>((buf) + OP_FLOATS, wn * WCOLS, (c8), i, h, fb[set]);    \
   } while (0)
 #define PL_MFMAS(set)                                                                           \
   do {                                                                                          \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                               \
     _Pragma("unroll") for (int a = 0; a < 2; ++a)                                               \
-    _Pragma("unroll") for (int b = 0; b < 2; ++b)                                               \
+    _Pragma("unroll") for (int b = 0; b < NB; ++b)                                              \
       acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][a][j], fb[set][b][j], acc[a][b], 0, 0, 0); \
   } while (0)
 
@@ -261,19 +275,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
   // MFMA groups they idle the pipe ~700 cycles per tile; sched_group_barrier threads ONE of
   // them into each MFMA shadow instead.
   Stage ra, rb;
-  constexpr int NFR = (A_KS ? 8 : 2) + (B_KS ? 8 : 2);   // ds_read instructions per fragment set
+  constexpr int NFR = (A_KS ? 8 : 2) + (B_KS ? 4 * NB : NB);   // ds_read instructions per fragment set
 #define PL_SGB(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
   auto step = [&](const int kt, auto do_store, auto do_load, auto has_next) {
     const float* cur = lds + (kt & 1) * 2 * OP_FLOATS;
     float* nxt = lds + ((kt + 1) & 1) * 2 * OP_FLOATS;
     if (do_store.value) {
-      store_tile<A_KS>(nxt, tid, ra);
-      store_tile<B_KS>(nxt + OP_FLOATS, tid, rb);
+      store_tile<A_KS, NT>(nxt, tid, ra);
+      store_tile<B_KS, NT>(nxt + OP_FLOATS, tid, rb);
     }
     if (do_load.value) {
       const int k0 = kbeg + (kt + 2) * BK;
-      ra = load_tile<A_KS, EDGE>(p.A, p.lda, m0, p.M, k0, kend, a_vec, tid);
-      rb = load_tile<B_KS, EDGE>(p.B, p.ldb, n0, p.N, k0, kend, b_vec, tid);
+      ra = load_tile<A_KS, EDGE, NT>(p.A, p.lda, m0, p.M, k0, kend, a_vec, tid);
+      rb = load_tile<B_KS, EDGE, NT>(p.B, p.ldb, n0, p.N, k0, kend, b_vec, tid);
     }
     PL_FRAGS(1, cur, 1);
     PL_MFMAS(0);
@@ -285,53 +299,53 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
     PL_SGB(0x100, NFR);                                     // fragments of chunk 1 first
     if (do_store.value) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { PL_SGB(0x008, 1); PL_SGB(0x200, 1); }
+      for (int q = 0; q < 4 * NB; ++q) { PL_SGB(0x008, 1); PL_SGB(0x200, 1); }
     } else {
-      PL_SGB(0x008, 8);
+      PL_SGB(0x008, 4 * NB);
     }
     if (do_load.value) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { PL_SGB(0x008, 1); PL_SGB(0x020, 1); }
+      for (int q = 0; q < 4 * NB; ++q) { PL_SGB(0x008, 1); PL_SGB(0x020, 1); }
     } else {
-      PL_SGB(0x008, 8);
+      PL_SGB(0x008, 4 * NB);
     }
-    PL_SGB(0x100, NFR); PL_SGB(0x008, 16);
-    PL_SGB(0x100, NFR); PL_SGB(0x008, 16);
+    PL_SGB(0x100, NFR); PL_SGB(0x008, 8 * NB);
+    PL_SGB(0x100, NFR); PL_SGB(0x008, 8 * NB);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     if (has_next.value) PL_FRAGS(0, nxt, 0);
     PL_MFMAS(1);
-    PL_SGB(0x100, NFR); PL_SGB(0x008, 16);
+    PL_SGB(0x100, NFR); PL_SGB(0x008, 8 * NB);
     __builtin_amdgcn_sched_barrier(0);
   };
   // PL_BF16 variant of one pipeline step: the 32-wide fp32 tile is two 16-deep bf16 MFMA steps
   // (2 x 4 MFMAs of 32 cycles: this loop is bound by staging bytes from L2, not by the pipe).
-  bf16x8 ba[2][2], bb[2][2];
+  bf16x8 ba[2][2], bb[2][NB];
 #define PL_FRAGS_BF(set, buf, s16)                                                   \
   do {                                                                               \
-    _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) {                               \
+    _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2)                                 \
       ba[set][t2] = read_frag_bf16<A_KS>((buf), wm * 64 + t2 * 32 + i, (s16), h);    \
-      bb[set][t2] = read_frag_bf16<B_KS>((buf) + OP_FLOATS, wn * 64 + t2 * 32 + i, (s16), h); \
-    }                                                                                \
+    _Pragma("unroll") for (int t2 = 0; t2 < NB; ++t2)                                \
+      bb[set][t2] = read_frag_bf16<B_KS>((buf) + OP_FLOATS, wn * WCOLS + t2 * 32 + i, (s16), h); \
   } while (0)
 #define PL_MFMAS_BF(set)                                                                    \
   do {                                                                                      \
     _Pragma("unroll") for (int a = 0; a < 2; ++a)                                           \
-    _Pragma("unroll") for (int b = 0; b < 2; ++b)                                           \
+    _Pragma("unroll") for (int b = 0; b < NB; ++b)                                          \
       acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ba[set][a], bb[set][b], acc[a][b], 0, 0, 0); \
   } while (0)
   auto step_bf = [&](const int kt, auto do_store, auto do_load, auto has_next) {
     const float* cur = lds + (kt & 1) * 2 * OP_FLOATS;
     float* nxt = lds + ((kt + 1) & 1) * 2 * OP_FLOATS;
     if (do_store.value) {
-      store_tile<A_KS>(nxt, tid, ra);
-      store_tile<B_KS>(nxt + OP_FLOATS, tid, rb);
+      store_tile<A_KS, NT>(nxt, tid, ra);
+      store_tile<B_KS, NT>(nxt + OP_FLOATS, tid, rb);
     }
     if (do_load.value) {
       const int k0 = kbeg + (kt + 2) * BK;
-      ra = load_tile<A_KS, EDGE>(p.A, p.lda, m0, p.M, k0, kend, a_vec, tid);
-      rb = load_tile<B_KS, EDGE>(p.B, p.ldb, n0, p.N, k0, kend, b_vec, tid);
+      ra = load_tile<A_KS, EDGE, NT>(p.A, p.lda, m0, p.M, k0, kend, a_vec, tid);
+      rb = load_tile<B_KS, EDGE, NT>(p.B, p.ldb, n0, p.N, k0, kend, b_vec, tid);
     }
     PL_FRAGS_BF(1, cur, 1);
     PL_MFMAS_BF(0);
@@ -347,26 +361,25 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
   // TB/s chip-wide) and 77 us on the fp32 MFMA.  The extra 19 us is the wave's VALU ISSUE port:
   // ~450 split instructions per tile at 4 cycles each exceed the 1,536 cycles of matrix work, and a
   // lone wave per SIMD issues one instruction at a time -- weaving the split into the MFMA shadows
-  // (sched_group_barrier) produced the intended ISA and changed nothing.  Next lever: 8-wave
-  // workgroups (two waves per SIMD share the issue port) or splitting once per element at staging.
-  float xa[2][2][8], xb[2][2][8];
+  // (sched_group_barrier) produced the intended ISA and changed nothing, and neither did 8-wave
+  // workgroups (two waves per SIMD).  Untried: splitting once per element at staging (bf16 planes in
+  // LDS), which halves the split work and the LDS fragment bytes for k-contiguous operands.
+  float xa[2][2][8], xb[2][NB][8];
 #define PL_FRAGS_X6(set, buf, s16)                                                       \
   do {                                                                                   \
-    _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) {                                   \
+    _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2)                                     \
       read_frag_raw<A_KS>((buf), wm * 64 + t2 * 32 + i, (s16), h, xa[set][t2]);          \
-      read_frag_raw<B_KS>((buf) + OP_FLOATS, wn * 64 + t2 * 32 + i, (s16), h, xb[set][t2]); \
-    }                                                                                    \
+    _Pragma("unroll") for (int t2 = 0; t2 < NB; ++t2)                                    \
+      read_frag_raw<B_KS>((buf) + OP_FLOATS, wn * WCOLS + t2 * 32 + i, (s16), h, xb[set][t2]); \
   } while (0)
 #define PL_MF(aa, bb, ia, ib) acc[aa][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[aa][ia], b3[bb][ib], acc[aa][bb], 0, 0, 0)
 #define PL_MFMAS_X6(set)                                               \
   do {                                                                 \
-    bf16x8 a3[2][3], b3[2][3];                                         \
-    _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) {                 \
-      split3(xa[set][t2], a3[t2]);                                     \
-      split3(xb[set][t2], b3[t2]);                                     \
-    }                                                                  \
+    bf16x8 a3[2][3], b3[NB][3];                                        \
+    _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) split3(xa[set][t2], a3[t2]);  \
+    _Pragma("unroll") for (int t2 = 0; t2 < NB; ++t2) split3(xb[set][t2], b3[t2]); \
     _Pragma("unroll") for (int aa = 0; aa < 2; ++aa)                   \
-    _Pragma("unroll") for (int bb = 0; bb < 2; ++bb) {                 \
+    _Pragma("unroll") for (int bb = 0; bb < NB; ++bb) {                \
       PL_MF(aa, bb, 2, 0); PL_MF(aa, bb, 1, 1); PL_MF(aa, bb, 0, 2);   \
       PL_MF(aa, bb, 1, 0); PL_MF(aa, bb, 0, 1); PL_MF(aa, bb, 0, 0);   \
     }                                                                  \
@@ -375,13 +388,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
     const float* cur = lds + (kt & 1) * 2 * OP_FLOATS;
     float* nxt = lds + ((kt + 1) & 1) * 2 * OP_FLOATS;
     if (do_store.value) {
-      store_tile<A_KS>(nxt, tid, ra);
-      store_tile<B_KS>(nxt + OP_FLOATS, tid, rb);
+      store_tile<A_KS, NT>(nxt, tid, ra);
+      store_tile<B_KS, NT>(nxt + OP_FLOATS, tid, rb);
     }
     if (do_load.value) {
       const int k0 = kbeg + (kt + 2) * BK;
-      ra = load_tile<A_KS, EDGE>(p.A, p.lda, m0, p.M, k0, kend, a_vec, tid);
-      rb = load_tile<B_KS, EDGE>(p.B, p.ldb, n0, p.N, k0, kend, b_vec, tid);
+      ra = load_tile<A_KS, EDGE, NT>(p.A, p.lda, m0, p.M, k0, kend, a_vec, tid);
+      rb = load_tile<B_KS, EDGE, NT>(p.B, p.ldb, n0, p.N, k0, kend, b_vec, tid);
     }
     PL_FRAGS_X6(1, cur, 1);
     PL_MFMAS_X6(0);
@@ -395,13 +408,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
   using F = std::false_type;
 
   if (nk > 0) {
-    ra = load_tile<A_KS, EDGE>(p.A, p.lda, m0, p.M, kbeg, kend, a_vec, tid);
-    rb = load_tile<B_KS, EDGE>(p.B, p.ldb, n0, p.N, kbeg, kend, b_vec, tid);
-    store_tile<A_KS>(lds, tid, ra);
-    store_tile<B_KS>(lds + OP_FLOATS, tid, rb);
+    ra = load_tile<A_KS, EDGE, NT>(p.A, p.lda, m0, p.M, kbeg, kend, a_vec, tid);
+    rb = load_tile<B_KS, EDGE, NT>(p.B, p.ldb, n0, p.N, kbeg, kend, b_vec, tid);
+    store_tile<A_KS, NT>(lds, tid, ra);
+    store_tile<B_KS, NT>(lds + OP_FLOATS, tid, rb);
     if (nk > 1) {
-      ra = load_tile<A_KS, EDGE>(p.A, p.lda, m0, p.M, kbeg + BK, kend, a_vec, tid);
-      rb = load_tile<B_KS, EDGE>(p.B, p.ldb, n0, p.N, kbeg + BK, kend, b_vec, tid);
+      ra = load_tile<A_KS, EDGE, NT>(p.A, p.lda, m0, p.M, kbeg + BK, kend, a_vec, tid);
+      rb = load_tile<B_KS, EDGE, NT>(p.B, p.ldb, n0, p.N, kbeg + BK, kend, b_vec, tid);
     }
     __syncthreads();
     int kt = 0;
@@ -432,12 +445,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
 #undef PL_MFMAS
 
   // ---- epilogue ----------------------------------------------------------------------------
-  // acc[a][b][r]: row = m0 + wm*64 + a*32 + (r&3) + 8*(r>>2) + 4*h, col = n0 + wn*64 + b*32 + i
+  // acc[a][b][r]: row = m0 + wm*64 + a*32 + (r&3) + 8*(r>>2) + 4*h, col = n0 + wn*WCOLS + b*32 + i
   const int rbase = m0 + wm * 64 + 4 * h;
   const bool plain = p.split_k > 1;
 #pragma unroll
-  for (int b = 0; b < 2; ++b) {
-    const int col = n0 + wn * 64 + b * 32 + i;
+  for (int b = 0; b < NB; ++b) {
+    const int col = n0 + wn * WCOLS + b * 32 + i;
     const bool cok = !EDGE || col < p.N;
     float bias = 0.f, scale = 1.f, shift = 0.f;
     if (!plain && cok) {
@@ -493,10 +506,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
   }
 }
 
-template <bool A_KS, bool B_KS, bool EDGE, int AR = 0>
-__global__ __launch_bounds__(NTHR) void gemm_f32_kernel(GemmArgs p) {
+template <bool A_KS, bool B_KS, bool EDGE, int AR = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_f32_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];   // one static array (73,728 B)
-  gemm_body<A_KS, B_KS, EDGE, AR>(p, blockIdx.x, gridDim.x, lds);
+  gemm_body<A_KS, B_KS, EDGE, AR, NW>(p, blockIdx.x, gridDim.x, lds);
 }
 
 // Two independent whole-tile GEMMs in ONE launch: workgroups [0, n0) run the NN problem
@@ -504,13 +517,13 @@ __global__ __launch_bounds__(NTHR) void gemm_f32_kernel(GemmArgs p) {
 // with 256 + 256 workgroups every CU hosts one of each (2 x 73.7 KB LDS, 2 waves per SIMD), so
 // one GEMM's prologue / epilogue-store / barrier bubbles are filled by the other's MFMAs, and
 // a launch boundary plus its dirty-L2 write-back disappears.
-template <int AR>
-__global__ __launch_bounds__(NTHR) void gemm_f32_dual_kernel(GemmArgs p0, GemmArgs p1, int n0) {
+template <int AR, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_f32_dual_kernel(GemmArgs p0, GemmArgs p1, int n0) {
   __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   if ((int)blockIdx.x < n0)
-    gemm_body<false, true, false, AR>(p0, blockIdx.x, n0, lds);
+    gemm_body<false, true, false, AR, NW>(p0, blockIdx.x, n0, lds);
   else
-    gemm_body<true, true, false, AR>(p1, blockIdx.x - n0, gridDim.x - n0, lds);
+    gemm_body<true, true, false, AR, NW>(p1, blockIdx.x - n0, gridDim.x - n0, lds);
 }
 
 }  // namespace
@@ -583,9 +596,9 @@ int launch_gemm_f32_pair(const GemmArgs& nn, const GemmArgs& tn, hipStream_t s) 
   ProfRec* prof = prof_begin(both, s);
   if (prof) prof->flops += 2.0 * tn.M * tn.N * tn.K;
   if (nn.arith != tn.arith) PL_FAIL(PL_EINVAL, "gemm pair: mixed arithmetic");
-  if (nn.arith == 2) hipLaunchKernelGGL(gemm_f32_dual_kernel<2>, dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
-  else if (nn.arith == 1) hipLaunchKernelGGL(gemm_f32_dual_kernel<1>, dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
-  else hipLaunchKernelGGL(gemm_f32_dual_kernel<0>, dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
+  if (nn.arith == 2) hipLaunchKernelGGL((gemm_f32_dual_kernel<2, 4>), dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
+  else if (nn.arith == 1) hipLaunchKernelGGL((gemm_f32_dual_kernel<1, 4>), dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
+  else hipLaunchKernelGGL((gemm_f32_dual_kernel<0, 4>), dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
   if (prof) (void)hipEventRecord(prof->e1, s);
   PL_CHECK_LAUNCH("gemm_f32_dual");
   return PL_OK;

@@ -159,6 +159,10 @@ int pl_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n,
 int pl_gemm_f32(int layout, const float* A, const float* B, float* C, int64_t M,
                 int64_t N, int64_t K, const float* bias, int split_k, float* slabs,
                 void* stream);
+/* the same with the arithmetic chosen (PLDtype); bf16 modes apply to whole 128x128x32 tiles only */
+int pl_gemm_arith(int layout, int arith, const float* A, const float* B, float* C, int64_t M,
+                  int64_t N, int64_t K, const float* bias, int split_k, float* slabs,
+                  void* stream);
 
 /* ---- next row N1: fused softmax + integral soft-argmax ----------------------------------- */
 /* Tail of Model_3D.forward  phase4_joined/Model.py:94-133 (ncoord 3, centred 1: (E/dim - 0.5)*2)

@@ -134,6 +134,29 @@ def test_gemm_tn_split_k(pkg, M, N, K, splits):
     assert np.all(np.abs(C.cpu().numpy() - want) <= bound)
 
 
+@pytest.mark.parametrize("arith,tol", [(1, 2e-2), (2, 2e-6)])
+@pytest.mark.parametrize("layout,M,N,K,splits", [(0, 4096, 1024, 1024, 1), (1, 4096, 1024, 1024, 1),
+                                                 (2, 1024, 1024, 4096, 4), (0, 256, 128, 96, 1), (2, 128, 256, 512, 1)])
+def test_gemm_bf16_arithmetic_modes(pkg, arith, tol, layout, M, N, K, splits):
+    """PL_BF16 (1): bf16-sized error.  PL_BF16X6 (2): three-way split, must stay inside the fp32 bound."""
+    rng = np.random.default_rng(M + N + K + layout)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    b = rng.standard_normal((K, N)).astype(np.float32)
+    A = _t(a if layout != 2 else a.T)
+    Bm = _t(b.T if layout == 0 else b)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    slabs = torch.empty(splits, M, N, device=DEV) if splits > 1 else None
+    rc = pkg.lib().pl_gemm_arith(layout, arith, A.data_ptr(), Bm.data_ptr(), C.data_ptr(), M, N, K, None, splits,
+                                 slabs.data_ptr() if splits > 1 else None, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, pkg.lib().pl_last_error()
+    want = a.astype(np.float64) @ b.astype(np.float64)
+    bound = tol * (np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64)) + 1e-6
+    err = np.abs(C.cpu().numpy() - want)
+    assert np.all(err <= bound), float((err / bound).max())
+    if arith == 1:
+        assert err.max() > 1e-4          # really bf16
+
+
 # ---------------------------------------------------------------------------- golden vectors
 @pytest.mark.parametrize("dtype", ["fp32", "bf16x6"])
 def test_g1_eval_forward_vs_reference(pkg, dtype):
