@@ -93,7 +93,7 @@ int out_splits(int M, int N, int K) {
 struct Ws {
   int L, G, RC;
   std::vector<size_t> z, act, bits, mean, rstd, dbpart;
-  size_t stat_a, stat_b, scale, shift, coef, ga, gb, dz, slabs, outpart, total;
+  size_t stat_a, stat_b, scale, shift, coef, ga, gb, dz, slabs, outpart, dyout, mse, total;
   size_t act_bytes, bits_bytes;
 };
 
@@ -145,6 +145,8 @@ Ws plan(const PLDesc* d, int64_t B) {
   }
   w.slabs = take(slab);
   w.outpart = take((size_t)colsum_chunks((int)B) * d->out_dim * 4);
+  w.dyout = take((size_t)B * d->out_dim * 4);                 // d loss / d y of the fused train step
+  w.mse = take(pl_mse_scratch_bytes(B * d->out_dim));
   w.total = o;
   return w;
 }
@@ -507,4 +509,27 @@ extern "C" int pl_prof_read(double min_flops, double max_flops, double* ms_total
                             double* flops_total) {
   if (!ms_total || !launches || !flops_total) PL_FAIL(PL_EINVAL, "pl_prof_read: null pointer");
   return prof_read(min_flops, max_flops, ms_total, launches, flops_total);
+}
+
+// ---------------------------------------------------------------------------------------
+// fused train step: forward (training mode) + MSE(mean) + backward in one call
+// ---------------------------------------------------------------------------------------
+extern "C" int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const float* target, int64_t B, void* ws,
+                                       size_t ws_bytes, uint64_t seed, uint64_t step, float* y, float* loss,
+                                       float* grads, int part, void* stream) {
+  PL_TRY(check_desc(d, true));
+  if (!x || !target || !y || !loss || !grads) PL_FAIL(PL_EINVAL, "pl_lifter_train_fwd_bwd: null pointer");
+  if (B <= 0) PL_FAIL(PL_ESHAPE, "pl_lifter_train_fwd_bwd: B=%lld", (long long)B);
+  if (part < -1 || part > 1) PL_FAIL(PL_EINVAL, "pl_lifter_train_fwd_bwd: part=%d", part);
+  const Ws w = plan(d, B);
+  PL_TRY(check_ws(w, ws, ws_bytes));
+  float* dy = f32(ws, w.dyout);
+  const int L = 1 + 2 * d->num_stage, split = d->num_stage + 1;
+  if (part <= 0) {
+    PL_TRY(pl_lifter_fwd_train(d, x, y, B, ws, ws_bytes, seed, step, nullptr, stream));
+    PL_TRY(pl_mse_fwd_bwd(y, target, B * d->out_dim, 1.0f, dy, loss, f32(ws, w.mse), stream));
+  }
+  if (part == -1) return bwd_impl(d, x, dy, B, ws, ws_bytes, nullptr, grads, stream, true, L - 1, 0);
+  if (part == 0) return bwd_impl(d, x, dy, B, ws, ws_bytes, nullptr, grads, stream, true, L - 1, split);
+  return bwd_impl(d, x, dy, B, ws, ws_bytes, nullptr, grads, stream, false, split - 1, 0);
 }

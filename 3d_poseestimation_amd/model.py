@@ -270,6 +270,42 @@ class LinearModel(nn.Module):
                     p.grad = target[s.offset:s.offset + s.numel].view(s.shape)
         return dx
 
+    # ------------------------------------------------------------------ fused train step
+    def fused_train_fwd_bwd(self, x2, target, sync=None):
+        """forward + MSE(mean) + backward in one library call (two when a data-parallel sync wants
+        the upper layers' gradients early).  Returns (loss, y) device tensors; parameter gradients
+        land in the flat arena and stay attached as .grad views."""
+        B = x2.shape[0]
+        ws = self._acquire_workspace(B)
+        try:
+            y = torch.empty(B, self.output_size, dtype=torch.float32, device=x2.device)
+            loss = torch.empty((), dtype=torch.float32, device=x2.device)
+            grads = self.flat_grads
+            self._step += 1
+            L = _lib.lib()
+
+            def call(part):
+                _lib.check(L.pl_lifter_train_fwd_bwd(
+                    ctypes.byref(self._desc), x2.data_ptr(), target.data_ptr(), B, ws["buf"].data_ptr(), ws["bytes"],
+                    self._seed, self._step, y.data_ptr(), loss.data_ptr(), grads.data_ptr(), part,
+                    _lib.current_stream_ptr()), "pl_lifter_train_fwd_bwd")
+            if sync is not None and sync.world() > 1:
+                split = self._slots[4 * L.pl_bwd_split_layer(ctypes.byref(self._desc))].offset
+                call(0)
+                sync.launch_bucket(grads[split:])
+                call(1)
+                sync.launch_bucket(grads[:split])
+            else:
+                call(-1)
+        finally:
+            self._release_workspace(ws)
+        if self._param_list[-1].grad is None or self._param_list[-1].grad.data_ptr() != \
+                grads.data_ptr() + 4 * self._slots[-1].offset:
+            for s, p in zip(self._slots, self._param_list):
+                p.grad = grads[s.offset:s.offset + s.numel].view(s.shape) if (self.BN or "batch_norm" not in s.name) else None
+        self.last_workspace = ws
+        return loss, y
+
     # ------------------------------------------------------------------ forward
     def forward(self, x):
         if not self._arenas_intact():

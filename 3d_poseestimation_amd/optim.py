@@ -32,6 +32,7 @@ class FlatAdamW(torch.optim.Optimizer):
         if self._bound_arena is not None and self._bound_arena.data_ptr() == flat.data_ptr():
             return
         m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+        self._step_tensor = torch.tensor(0.0)            # ONE host tensor shared by all 22 state entries
         for s, p in zip(model._slots, model._param_list):
             st = self.state[p]
             mv = m[s.offset:s.offset + s.numel].view(s.shape)
@@ -41,7 +42,8 @@ class FlatAdamW(torch.optim.Optimizer):
                 vv.copy_(st["exp_avg_sq"])
                 self._t = max(self._t, int(st["step"]))
             st["exp_avg"], st["exp_avg_sq"] = mv, vv
-            st["step"] = torch.tensor(float(self._t))
+            st["step"] = self._step_tensor
+        self._step_tensor.fill_(float(self._t))
         self._m, self._v, self._bound_arena = m, v, flat
 
     def load_state_dict(self, state_dict):
@@ -68,6 +70,5 @@ class FlatAdamW(torch.optim.Optimizer):
                 float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                 float(g["weight_decay"]), self._t, float(grad_scale), _lib.current_stream_ptr())
         _lib.check(rc, "pl_adamw_flat")
-        for p in model._param_list:
-            self.state[p]["step"].fill_(float(self._t))
+        self._step_tensor.fill_(float(self._t))
         return loss

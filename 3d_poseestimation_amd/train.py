@@ -87,13 +87,31 @@ def epoch_mpjpe_mm(metric_sum, n_samples, num_of_joints=17, zero_centre=True):
     return m
 
 
+def _fusable(model, optimizer, y1, y2):
+    from .model import LinearModel
+    from .optim import FlatAdamW
+    return (isinstance(model, LinearModel) and isinstance(optimizer, FlatAdamW) and optimizer._model is model
+            and model.training and torch.is_grad_enabled() and not y1.requires_grad and y1.is_cuda and y2.is_cuda
+            and model._inject_keep is None and model._arenas_intact()
+            and y2.numel() == y2.shape[0] * model.output_size
+            and y1.numel() == y1.shape[0] * model.input_size)
+
+
 def train_step(model, optimizer, y1, y2, grad_sync=None):
     """One train_1.py:75-100 step: zero_grad, forward, reshape (B,J,3), MSE(mean), backward,
     [gradient all-reduce], optimizer.step.  Returns (loss, y2_hat) as device tensors -- the
     caller decides when to pay the host sync the reference pays every step (train_1.py:98).
     grad_sync: optional callable(model) -> grad_scale, e.g. dp.GradSync."""
-    optimizer.zero_grad()
     y1, y2 = y1.float(), y2.float()
+    if _fusable(model, optimizer, y1, y2):
+        # the whole step is three library calls: fwd+loss+bwd, [all-reduce], AdamW.  Same kernels,
+        # same results as the autograd route below; `zero_grad` is implicit (gradients are overwritten)
+        with torch.cuda.device(y1.device):
+            loss, y2_hat = model.fused_train_fwd_bwd(y1.reshape(y1.shape[0], -1).contiguous(),
+                                                     y2.reshape(y2.shape[0], -1).contiguous(), grad_sync)
+        optimizer.step(grad_scale=grad_sync(model) if grad_sync is not None else 1.0)
+        return loss, y2_hat.reshape(y2.shape)
+    optimizer.zero_grad()
     y2_hat = model(y1).reshape(y2.shape)
     loss = mse_loss(y2_hat, y2)
     loss.backward()

@@ -123,6 +123,15 @@ int pl_lifter_bwd_part(const PLDesc* d, const float* x, const float* dy, int64_t
                        void* workspace, size_t workspace_bytes, float* dx,
                        float* flat_grads, int part, void* stream);
 
+/* One train_1.py:75-95 iteration body up to the optimiser in ONE call: model.train() forward
+ * (baselineModel.py:87-102), MSELoss(mean) against target [B][out_dim] (train_1.py:94) and
+ * loss.backward() (:95).  y [B][out_dim] and loss (1 float) are outputs; flat_grads is overwritten.
+ * part -1: everything; 0: forward + loss + backward part 0; 1: backward part 1 (see
+ * pl_lifter_bwd_part).  Identical results to the separate calls. */
+int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const float* target, int64_t B,
+                            void* workspace, size_t workspace_bytes, uint64_t seed, uint64_t step,
+                            float* y, float* loss, float* flat_grads, int part, void* stream);
+
 /* ---- loss / metric / optimiser -------------------------------------------------- */
 /* torch.nn.MSELoss(reduction="mean") + its backward  train_1.py:37,94-95.
  * n elements; dpred = grad_scale * 2 (pred - tgt) / n; loss_out: 1 device float.

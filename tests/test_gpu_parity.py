@@ -577,6 +577,31 @@ def test_eval_forward_is_graph_capturable(pkg):
         assert torch.equal(ys, want)
 
 
+def test_fused_train_step_is_bitwise_the_autograd_route(pkg, monkeypatch):
+    """train_step's fast path (pl_lifter_train_fwd_bwd + pl_adamw_flat) and the autograd route
+    (LinearModel.forward -> mse_loss -> backward -> optimizer.step) run the same kernels."""
+    results = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        m = pkg.LinearModel(34, 51, linear_size=256, p_dropout=0.5).to(DEV).train()
+        m.manual_seed(3)
+        opt = pkg.FlatAdamW(m, lr=1e-3)
+        if not fused:
+            monkeypatch.setattr(pkg.train, "_fusable", lambda *a: False)
+        losses = []
+        for i in range(3):
+            x, y = pkg.synth.synthetic_batch(384, 40 + i, DEV)
+            loss, pred = pkg.train_step(m, opt, x, y)
+            losses.append(loss.clone())
+        results.append((torch.stack(losses), pred.clone(), m.flat_params.clone(), m.flat_grads.clone(),
+                        m._bn_running.clone(), opt._m.clone()))
+        assert m.w2.weight.grad is not None and m.w2.weight.grad.data_ptr() == \
+            m.flat_grads.data_ptr() + 4 * m._slots[-2].offset
+        assert opt.state_dict()["state"][0]["step"] == 3
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+
+
 def test_flip_pose_vs_oracle(pkg):
     rng = np.random.default_rng(4)
     for D in (2, 3):
