@@ -481,7 +481,11 @@ extern "C" int pl_gemm_f32(int layout, const float* A, const float* Bm, float* C
 extern "C" int pl_gemm_arith(int layout, int arith, const float* A, const float* Bm, float* C, int64_t M,
                              int64_t N, int64_t K, const float* bias, int split_k, float* slabs, void* stream) {
   if (layout < 0 || layout > 2) PL_FAIL(PL_EINVAL, "pl_gemm_f32: layout %d", layout);
+#ifdef PL_ABLATE
+  if (arith < 0 || arith > 4) PL_FAIL(PL_EDTYPE, "pl_gemm_arith: arith %d", arith);
+#else
   if (arith < 0 || arith > 2) PL_FAIL(PL_EDTYPE, "pl_gemm_arith: arith %d", arith);
+#endif
   if (M <= 0 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX)
     PL_FAIL(PL_ESHAPE, "pl_gemm_f32: bad shape");
   GemmArgs g = {};

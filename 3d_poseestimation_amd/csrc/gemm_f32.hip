@@ -362,8 +362,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
   // ~450 split instructions per tile at 4 cycles each exceed the 1,536 cycles of matrix work, and a
   // lone wave per SIMD issues one instruction at a time -- weaving the split into the MFMA shadows
   // (sched_group_barrier) produced the intended ISA and changed nothing, and neither did 8-wave
-  // workgroups (two waves per SIMD).  Untried: splitting once per element at staging (bf16 planes in
-  // LDS), which halves the split work and the LDS fragment bytes for k-contiguous operands.
+  // workgroups (two waves per SIMD), two operand tiles in flight (a second staging register set; the
+  // dual launch then loses its two-blocks-per-CU residency), or weaving the staging ds_writes /
+  // global_loads into the MFMA shadows.  Compile-time ablations (-DPL_ABLATE, arith 3 / 4 of
+  // pl_gemm_arith; forward GEMM, us): bf16 40, full split + ONE product 44, NO split + six products
+  // 51-55, full bf16x6 61: the six MFMAs, not the split, are the larger share, and the two add
+  // super-linearly (both want the wave's single issue port).  Untried: splitting once per element
+  // at staging (bf16 planes in LDS: half the split work and fragment bytes for k-contiguous operands).
   float xa[2][2][8], xb[2][NB][8];
 #define PL_FRAGS_X6(set, buf, s16)                                                       \
   do {                                                                                   \
@@ -376,12 +381,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
 #define PL_MFMAS_X6(set)                                               \
   do {                                                                 \
     bf16x8 a3[2][3], b3[NB][3];                                        \
+    if (AR == 4) { /* ablation build only: no split, six MFMAs on the rounded value */ \
+      _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) { _Pragma("unroll") for (int j = 0; j < 8; ++j) a3[t2][0][j] = (__bf16)xa[set][t2][j]; a3[t2][1] = a3[t2][0]; a3[t2][2] = a3[t2][0]; } \
+      _Pragma("unroll") for (int t2 = 0; t2 < NB; ++t2) { _Pragma("unroll") for (int j = 0; j < 8; ++j) b3[t2][0][j] = (__bf16)xb[set][t2][j]; b3[t2][1] = b3[t2][0]; b3[t2][2] = b3[t2][0]; } \
+    } else {                                                           \
     _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2) split3(xa[set][t2], a3[t2]);  \
     _Pragma("unroll") for (int t2 = 0; t2 < NB; ++t2) split3(xb[set][t2], b3[t2]); \
+    }                                                                  \
     _Pragma("unroll") for (int aa = 0; aa < 2; ++aa)                   \
     _Pragma("unroll") for (int bb = 0; bb < NB; ++bb) {                \
-      PL_MF(aa, bb, 2, 0); PL_MF(aa, bb, 1, 1); PL_MF(aa, bb, 0, 2);   \
-      PL_MF(aa, bb, 1, 0); PL_MF(aa, bb, 0, 1); PL_MF(aa, bb, 0, 0);   \
+      if (AR != 3) { PL_MF(aa, bb, 2, 0); PL_MF(aa, bb, 1, 1); PL_MF(aa, bb, 0, 2);   \
+      PL_MF(aa, bb, 1, 0); PL_MF(aa, bb, 0, 1); }                      \
+      else { asm volatile("" :: "v"(a3[aa][1]), "v"(a3[aa][2]), "v"(b3[bb][1]), "v"(b3[bb][2])); } /* ablation: one product */ \
+      PL_MF(aa, bb, 0, 0);                                             \
     }                                                                  \
   } while (0)
   auto step_x6 = [&](const int kt, auto do_store, auto do_load, auto has_next) {
@@ -418,7 +430,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
     }
     __syncthreads();
     int kt = 0;
-    if (AR == 2) {
+    if (AR >= 2) {
       PL_FRAGS_X6(0, lds, 0);
       for (; kt + 2 < nk; ++kt) step_x6(kt, T{}, T{}, T{});
       if (kt + 1 < nk) { step_x6(kt, T{}, F{}, T{}); ++kt; }
@@ -615,9 +627,17 @@ int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s) {
   const size_t lds_bytes = 0;   // LDS is static
   ProfRec* prof = prof_begin(a, s);
   const bool whole = whole_tiles(a);
+#ifdef PL_ABLATE   /* timing-only variants of the bf16x6 loop (wrong results by construction) */
+#define PL_ABLATE_LAUNCH(AKS, BKS)                                                                        \
+    else if (whole && a.arith == 3) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false, 3>), grid, block, lds_bytes, s, a); \
+    else if (whole && a.arith == 4) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false, 4>), grid, block, lds_bytes, s, a);
+#else
+#define PL_ABLATE_LAUNCH(AKS, BKS)
+#endif
 #define PL_GEMM_LAUNCH(AKS, BKS)                                                                          \
   do {                                                                                                    \
     if (whole && a.arith == 2) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false, 2>), grid, block, lds_bytes, s, a); \
+    PL_ABLATE_LAUNCH(AKS, BKS)                                                                            \
     else if (whole && a.arith == 1) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false, 1>), grid, block, lds_bytes, s, a); \
     else if (whole) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false>), grid, block, lds_bytes, s, a);      \
     else hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, true>), grid, block, lds_bytes, s, a);             \
