@@ -602,6 +602,42 @@ def test_fused_train_step_is_bitwise_the_autograd_route(pkg, monkeypatch):
         assert torch.equal(a, b)
 
 
+def test_phase5_cycle_usage_pattern_vs_torch_twin(pkg):
+    """phase5_loop/train_5 copy.py:164-168,190-199: the lifter is called TWICE inside one autograd graph
+    (on a prediction that needs its input gradient, and on the ground truth), L1 losses, one backward;
+    the projector is LinearModel(51, 34, linear_size=64).  Checked against the stock-PyTorch twin on
+    CPU with the same weights (p_dropout = 0: torch's dropout stream cannot be matched)."""
+    from oracle.torch_twin import TwinLifter
+    torch.manual_seed(11)
+    B = 160
+    for (i_dim, o_dim, H) in ((34, 51, 256), (51, 34, 64)):
+        m = pkg.LinearModel(i_dim, o_dim, linear_size=H, p_dropout=0.0).to(DEV).train()
+        tw = TwinLifter(i_dim, o_dim, linear_size=H, p_dropout=0.0).train()
+        tw.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+        pred_in = torch.rand(B, i_dim)                 # stand-in for Model_2D(frame): needs a gradient
+        gt_in, tgt_a, tgt_b = torch.rand(B, i_dim), torch.rand(B, o_dim) - 0.5, torch.rand(B, o_dim) - 0.5
+        outs = []
+        for model, dev in ((m, DEV), (tw, "cpu")):
+            a = pred_in.clone().to(dev).requires_grad_(True)
+            l1 = torch.nn.L1Loss()
+            loss = l1(model(a), tgt_a.to(dev)) + l1(model(gt_in.to(dev)), tgt_b.to(dev))
+            loss.backward()
+            outs.append((loss.item(), a.grad.cpu().numpy(),
+                         {k: p.grad.cpu().numpy() for k, p in model.named_parameters()},
+                         {k: v.cpu().numpy() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}))
+        (lg, dxg, gg, bg), (lc, dxc, gc, bc) = outs
+        _close(lg, lc, 1e-5, 0)
+        sdx = np.abs(dxc).max()
+        _close(dxg / sdx, dxc / sdx, 0, 5e-4)
+        for k, v in gc.items():
+            if k.endswith(".bias") and "batch_norm" not in k and k != "w2.bias":
+                continue
+            rel = np.linalg.norm((gg[k] - v).astype(np.float64)) / (np.linalg.norm(v.astype(np.float64)) + 1e-30)
+            assert rel < 2e-3, (k, rel)       # L1's sign() gradient flips on ties: norm-wise comparison
+        for k, v in bc.items():               # two forwards -> two running-stat updates, as in torch
+            _close(bg[k], v, 1e-5, 1e-6)
+
+
 def test_flip_pose_vs_oracle(pkg):
     rng = np.random.default_rng(4)
     for D in (2, 3):
