@@ -43,10 +43,9 @@ SIGNATURES = {
     "pl_lifter_fwd_train": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _c.c_uint64,
                                        _c.c_uint64, _P, _P]),
     "pl_lifter_bwd": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _P, _P, _P]),
-    "pl_bwd_split_layer": (_c.c_int64, [_D]),
-    "pl_lifter_bwd_part": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _P, _P, _c.c_int, _P]),
+    "pl_lifter_bwd_layers": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _P, _P, _c.c_int, _c.c_int, _P]),
     "pl_lifter_train_fwd_bwd": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _c.c_uint64, _c.c_uint64,
-                                           _P, _P, _P, _c.c_int, _P]),
+                                           _P, _P, _P, _c.c_int, _c.c_int, _P]),
     "pl_mse_scratch_bytes": (_c.c_size_t, [_c.c_int64]),
     "pl_mse_fwd_bwd": (_c.c_int, [_P, _P, _c.c_int64, _c.c_float, _P, _P, _P, _P]),
     "pl_mpjpe_scratch_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64]),

@@ -459,15 +459,18 @@ extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, i
   return bwd_impl(d, x, dy, B, ws, ws_bytes, dx, grads, stream, true, 2 * d->num_stage, 0);
 }
 
-extern "C" int64_t pl_bwd_split_layer(const PLDesc* d) { return d ? (int64_t)d->num_stage + 1 : PL_EINVAL; }
+static int check_range(const PLDesc* d, int hi, int lo, const char* who) {
+  const int L = 1 + 2 * d->num_stage;
+  if (lo < 0 || hi < lo || hi > L) PL_FAIL(PL_EINVAL, "%s: layer range hi=%d lo=%d outside 0..%d", who, hi, lo, L);
+  return PL_OK;
+}
 
-extern "C" int pl_lifter_bwd_part(const PLDesc* d, const float* x, const float* dy, int64_t B, void* ws,
-                                  size_t ws_bytes, float* dx, float* grads, int part, void* stream) {
-  if (!d) PL_FAIL(PL_EINVAL, "descriptor is NULL");
-  const int L = 1 + 2 * d->num_stage, split = d->num_stage + 1;
-  if (part == 0) return bwd_impl(d, x, dy, B, ws, ws_bytes, nullptr, grads, stream, true, L - 1, split);
-  if (part == 1) return bwd_impl(d, x, dy, B, ws, ws_bytes, dx, grads, stream, false, split - 1, 0);
-  PL_FAIL(PL_EINVAL, "pl_lifter_bwd_part: part=%d", part);
+extern "C" int pl_lifter_bwd_layers(const PLDesc* d, const float* x, const float* dy, int64_t B, void* ws,
+                                    size_t ws_bytes, float* dx, float* grads, int hi, int lo, void* stream) {
+  PL_TRY(check_desc(d, true));
+  PL_TRY(check_range(d, hi, lo, "pl_lifter_bwd_layers"));
+  const int L = 1 + 2 * d->num_stage;
+  return bwd_impl(d, x, dy, B, ws, ws_bytes, lo == 0 ? dx : nullptr, grads, stream, hi == L, hi == L ? L - 1 : hi, lo);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -520,20 +523,18 @@ extern "C" int pl_prof_read(double min_flops, double max_flops, double* ms_total
 // ---------------------------------------------------------------------------------------
 extern "C" int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const float* target, int64_t B, void* ws,
                                        size_t ws_bytes, uint64_t seed, uint64_t step, float* y, float* loss,
-                                       float* grads, int part, void* stream) {
+                                       float* grads, int hi, int lo, void* stream) {
   PL_TRY(check_desc(d, true));
   if (!x || !target || !y || !loss || !grads) PL_FAIL(PL_EINVAL, "pl_lifter_train_fwd_bwd: null pointer");
   if (B <= 0) PL_FAIL(PL_ESHAPE, "pl_lifter_train_fwd_bwd: B=%lld", (long long)B);
-  if (part < -1 || part > 1) PL_FAIL(PL_EINVAL, "pl_lifter_train_fwd_bwd: part=%d", part);
+  PL_TRY(check_range(d, hi, lo, "pl_lifter_train_fwd_bwd"));
   const Ws w = plan(d, B);
   PL_TRY(check_ws(w, ws, ws_bytes));
   float* dy = f32(ws, w.dyout);
-  const int L = 1 + 2 * d->num_stage, split = d->num_stage + 1;
-  if (part <= 0) {
+  const int L = 1 + 2 * d->num_stage;
+  if (hi == L) {
     PL_TRY(pl_lifter_fwd_train(d, x, y, B, ws, ws_bytes, seed, step, nullptr, stream));
     PL_TRY(pl_mse_fwd_bwd(y, target, B * d->out_dim, 1.0f, dy, loss, f32(ws, w.mse), stream));
   }
-  if (part == -1) return bwd_impl(d, x, dy, B, ws, ws_bytes, nullptr, grads, stream, true, L - 1, 0);
-  if (part == 0) return bwd_impl(d, x, dy, B, ws, ws_bytes, nullptr, grads, stream, true, L - 1, split);
-  return bwd_impl(d, x, dy, B, ws, ws_bytes, nullptr, grads, stream, false, split - 1, 0);
+  return bwd_impl(d, x, dy, B, ws, ws_bytes, nullptr, grads, stream, hi == L, hi == L ? L - 1 : hi, lo);
 }

@@ -87,6 +87,7 @@ class LinearModel(nn.Module):
         self._step = 0
         self._inject_keep = None
         self._grad_sync = None
+        self._dp_cuts = None
         self._flat = self._flat_grad = self._flat_grad_tmp = None
         self._ws_pool, self._ws_token = {}, 0
         self._flatten()
@@ -138,7 +139,7 @@ class LinearModel(nn.Module):
 
     def __setstate__(self, st):
         self.__dict__.update(st)
-        self._grad_sync = self._inject_keep = None
+        self._grad_sync = self._inject_keep = self._dp_cuts = None
         self._ws_pool, self._ws_token = {}, 0
         self._flatten()
 
@@ -168,10 +169,39 @@ class LinearModel(nn.Module):
         self._seed, self._step = int(seed) & 0xFFFFFFFFFFFFFFFF, int(step)
         return self
 
-    def set_grad_sync(self, sync):
+    def set_grad_sync(self, sync, cuts=None):
         """Attach a dp.GradSync: backward then all-reduces the upper layers' gradients while the
-        lower layers are still being computed (see pl_lifter_bwd_part)."""
+        lower layers are still being computed (see pl_lifter_bwd_layers).
+
+        cuts: descending hidden-layer indices at which backward is cut; each cut c closes a bucket
+        = the gradient arena from layer c's first tensor up to the previous cut.  Default: the
+        output layer with the two top hidden layers, then one bucket per layer -- every bucket
+        except the last (the 34-wide first layer, 150 KB) has a full layer of backward compute
+        behind which to hide."""
         self._grad_sync = sync
+        self._dp_cuts = self._check_cuts(cuts)
+
+    def _check_cuts(self, cuts):
+        n = len(self._named_holders())
+        if cuts is None:
+            cuts = list(range(max(n - 2, 0), -1, -1))
+        cuts = [int(c) for c in cuts]
+        if cuts != sorted(set(cuts), reverse=True) or (cuts and (cuts[0] > n or cuts[-1] < 0)):
+            raise ValueError(f"cuts must be strictly descending layer indices within 0..{n}: {cuts}")
+        if not cuts or cuts[-1] != 0:
+            cuts.append(0)
+        return cuts
+
+    def _bwd_ranges(self):
+        """[(hi, lo, arena_lo, arena_hi)]: layer ranges of a cut backward and the arena slice that
+        becomes final with each."""
+        n = len(self._named_holders())
+        out, hi, end = [], n, self._flat.numel()
+        for c in (self._dp_cuts or self._check_cuts(None)):
+            off = self._slots[4 * c].offset
+            out.append((hi, c, off, end))
+            hi, end = c - 1, off
+        return out
 
     def debug_inject_keep(self, keep_bitmaps):
         """Parity mode: the next training forward takes its dropout keep decisions from
@@ -248,13 +278,12 @@ class LinearModel(nn.Module):
                 dx.data_ptr() if need_dx else None, target.data_ptr())
         sync = self._grad_sync
         if sync is not None and not accumulate and sync.world() > 1:
-            # data-parallel overlap: the tail of the arena (output layer + upper hidden layers) is
-            # final after part 0 and is all-reduced while part 1 computes the rest
-            split = self._slots[4 * _lib.lib().pl_bwd_split_layer(ctypes.byref(self._desc))].offset
-            _lib.check(_lib.lib().pl_lifter_bwd_part(*args, 0, _lib.current_stream_ptr()), "pl_lifter_bwd_part(0)")
-            sync.launch_bucket(target[split:])
-            _lib.check(_lib.lib().pl_lifter_bwd_part(*args, 1, _lib.current_stream_ptr()), "pl_lifter_bwd_part(1)")
-            sync.launch_bucket(target[:split])
+            # data-parallel overlap: after each layer range the tail of the arena down to that
+            # range's lowest layer is final and is all-reduced while the layers below compute
+            for hi, lo, a_lo, a_hi in self._bwd_ranges():
+                _lib.check(_lib.lib().pl_lifter_bwd_layers(*args, hi, lo, _lib.current_stream_ptr()),
+                           "pl_lifter_bwd_layers")
+                sync.launch_bucket(target[a_lo:a_hi])
         else:
             _lib.check(_lib.lib().pl_lifter_bwd(*args, _lib.current_stream_ptr()), "pl_lifter_bwd")
         if accumulate:
@@ -284,19 +313,17 @@ class LinearModel(nn.Module):
             self._step += 1
             L = _lib.lib()
 
-            def call(part):
+            def call(hi, lo):
                 _lib.check(L.pl_lifter_train_fwd_bwd(
                     ctypes.byref(self._desc), x2.data_ptr(), target.data_ptr(), B, ws["buf"].data_ptr(), ws["bytes"],
-                    self._seed, self._step, y.data_ptr(), loss.data_ptr(), grads.data_ptr(), part,
+                    self._seed, self._step, y.data_ptr(), loss.data_ptr(), grads.data_ptr(), hi, lo,
                     _lib.current_stream_ptr()), "pl_lifter_train_fwd_bwd")
             if sync is not None and sync.world() > 1:
-                split = self._slots[4 * L.pl_bwd_split_layer(ctypes.byref(self._desc))].offset
-                call(0)
-                sync.launch_bucket(grads[split:])
-                call(1)
-                sync.launch_bucket(grads[:split])
+                for hi, lo, a_lo, a_hi in self._bwd_ranges():
+                    call(hi, lo)
+                    sync.launch_bucket(grads[a_lo:a_hi])
             else:
-                call(-1)
+                call(len(self._named_holders()), 0)
         finally:
             self._release_workspace(ws)
         if self._param_list[-1].grad is None or self._param_list[-1].grad.data_ptr() != \

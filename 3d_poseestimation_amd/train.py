@@ -101,14 +101,16 @@ def train_step(model, optimizer, y1, y2, grad_sync=None):
     """One train_1.py:75-100 step: zero_grad, forward, reshape (B,J,3), MSE(mean), backward,
     [gradient all-reduce], optimizer.step.  Returns (loss, y2_hat) as device tensors -- the
     caller decides when to pay the host sync the reference pays every step (train_1.py:98).
-    grad_sync: optional callable(model) -> grad_scale, e.g. dp.GradSync."""
+    grad_sync: optional callable(model) -> grad_scale, e.g. dp.GradSync; attach it with
+    model.set_grad_sync(grad_sync) to have its all-reduce overlapped with the backward pass."""
     y1, y2 = y1.float(), y2.float()
     if _fusable(model, optimizer, y1, y2):
         # the whole step is three library calls: fwd+loss+bwd, [all-reduce], AdamW.  Same kernels,
         # same results as the autograd route below; `zero_grad` is implicit (gradients are overwritten)
         with torch.cuda.device(y1.device):
             loss, y2_hat = model.fused_train_fwd_bwd(y1.reshape(y1.shape[0], -1).contiguous(),
-                                                     y2.reshape(y2.shape[0], -1).contiguous(), grad_sync)
+                                                     y2.reshape(y2.shape[0], -1).contiguous(),
+                                                     grad_sync if model._grad_sync is grad_sync else None)
         optimizer.step(grad_scale=grad_sync(model) if grad_sync is not None else 1.0)
         return loss, y2_hat.reshape(y2.shape)
     optimizer.zero_grad()

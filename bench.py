@@ -234,6 +234,10 @@ def main():
             x, y = pool[i % len(pool)]
             pkg.train_step(model, opt, x, y, grad_sync=sync)
 
+    if world > 1:                                           # RCCL communicator + the bucket sizes the step
+        for _, _, lo, hi in model._bwd_ranges():            # uses are set up before anything is timed,
+            dist.all_reduce(model.flat_grads[lo:hi])        # whatever --warmup says
+        model.flat_grads.zero_()
     run(a.warmup)
     if not a.no_prof:
         L.pl_prof_enable(1)

@@ -113,24 +113,25 @@ int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, int64_t B,
                   void* workspace, size_t workspace_bytes, float* dx,
                   float* flat_grads, void* stream);
 
-/* The same backward cut in two at a layer boundary (data-parallel overlap, no reference
- * counterpart): part 0 = output layer + hidden layers [split, n_hidden), part 1 = hidden layers
- * [0, split) (+ dx), split = pl_bwd_split_layer() = num_stage + 1.  After part 0 the gradients of
- * every tensor from pl_param_offset(d, 4*split) to the end of the arena are final, so their
- * all-reduce can run while part 1 computes.  part 0 then part 1 == pl_lifter_bwd, bit for bit. */
-int64_t pl_bwd_split_layer(const PLDesc* d);
-int pl_lifter_bwd_part(const PLDesc* d, const float* x, const float* dy, int64_t B,
-                       void* workspace, size_t workspace_bytes, float* dx,
-                       float* flat_grads, int part, void* stream);
+/* The same backward restricted to a range of layers (data-parallel overlap, no reference
+ * counterpart).  Layers are numbered along the chain: hidden Linears 0 .. L-1 (L = pl_num_hidden)
+ * and the output Linear = L.  The call runs layers hi, hi-1, .., lo (0 <= lo <= hi <= L); the
+ * gradient flowing between two calls lives in the workspace, so consecutive ranges
+ * (L..a), (a-1..b), .., (c-1..0) == pl_lifter_bwd, bit for bit.  After the range ending at lo the
+ * gradients of every tensor from pl_param_offset(d, 4*lo) to the end of the arena are final:
+ * their all-reduce can run while the lower layers compute.  dx is written by the range with lo = 0. */
+int pl_lifter_bwd_layers(const PLDesc* d, const float* x, const float* dy, int64_t B,
+                         void* workspace, size_t workspace_bytes, float* dx,
+                         float* flat_grads, int hi, int lo, void* stream);
 
 /* One train_1.py:75-95 iteration body up to the optimiser in ONE call: model.train() forward
  * (baselineModel.py:87-102), MSELoss(mean) against target [B][out_dim] (train_1.py:94) and
  * loss.backward() (:95).  y [B][out_dim] and loss (1 float) are outputs; flat_grads is overwritten.
- * part -1: everything; 0: forward + loss + backward part 0; 1: backward part 1 (see
- * pl_lifter_bwd_part).  Identical results to the separate calls. */
+ * hi, lo as in pl_lifter_bwd_layers: the call with hi = L runs forward + loss first, then
+ * backward over layers hi..lo; (L, 0) is the whole step.  Identical results to the separate calls. */
 int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const float* target, int64_t B,
                             void* workspace, size_t workspace_bytes, uint64_t seed, uint64_t step,
-                            float* y, float* loss, float* flat_grads, int part, void* stream);
+                            float* y, float* loss, float* flat_grads, int hi, int lo, void* stream);
 
 /* ---- loss / metric / optimiser -------------------------------------------------- */
 /* torch.nn.MSELoss(reduction="mean") + its backward  train_1.py:37,94-95.

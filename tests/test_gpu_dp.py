@@ -28,7 +28,8 @@ class _FakeSync:
         self.buckets.append((t.data_ptr(), t.numel()))
 
 
-def test_two_part_backward_is_bitwise_the_one_call_backward():
+@pytest.mark.parametrize("cuts", [None, [3], [4, 2], [5, 4, 3, 2, 1, 0], [0]])
+def test_cut_backward_is_bitwise_the_one_call_backward(cuts):
     import __graft_entry__ as ge
     pkg = ge.build()
     torch.manual_seed(0)
@@ -36,18 +37,36 @@ def test_two_part_backward_is_bitwise_the_one_call_backward():
     x, y = pkg.synth.synthetic_batch(384, 3, "cuda:0")
     grads = []
     for sync in (None, _FakeSync()):
-        m.set_grad_sync(sync)
+        m.set_grad_sync(sync, cuts)
         m.zero_grad(set_to_none=True)
         m.manual_seed(4, step=0)
         xr = x.clone().requires_grad_(True)
         pkg.mse_loss(m(xr).reshape(y.shape), y).backward()
         grads.append((m.flat_grads.clone(), xr.grad.clone()))
     assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
-    # the two buckets tile the arena: tail first (output layer + upper hidden layers), then the head
-    (p0, n0), (p1, n1) = sync.buckets
-    base = m.flat_grads.data_ptr()
-    assert p1 == base and p0 == base + 4 * n1 and n0 + n1 == m.flat_grads.numel()
-    assert n1 == m._slots[4 * 3].offset
+    # the buckets tile the arena from its end (output layer) down to its start, in launch order
+    base, end = m.flat_grads.data_ptr(), m.flat_grads.numel()
+    want = [c for c in (cuts if cuts is not None else [3, 2, 1, 0])]
+    if want[-1] != 0:
+        want.append(0)
+    assert len(sync.buckets) == len(want)
+    for (p, n), c in zip(sync.buckets, want):
+        off = m._slots[4 * c].offset
+        assert p == base + 4 * off and n == end - off
+        end = off
+    assert end == 0
+    # the fused step cut the same way gives the same gradients as the uncut fused step
+    fused = []
+    for sync in (None, _FakeSync()):
+        m.set_grad_sync(sync, cuts)
+        m.manual_seed(4, step=0)
+        m.fused_train_fwd_bwd(x.reshape(384, -1), y.reshape(384, -1), sync)
+        fused.append(m.flat_grads.clone())
+    assert torch.equal(fused[0], fused[1]) and torch.equal(fused[0], grads[0][0])
+    with pytest.raises(ValueError):
+        m.set_grad_sync(None, [2, 3])
+    with pytest.raises(ValueError):
+        m.set_grad_sync(None, [7])
 
 
 def _free_port():
