@@ -14,6 +14,15 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libposelift.so")
 PL_F32, PL_BF16, PL_BF16X6 = 0, 1, 2
 
 
+# int gather(void* user, float* buf, int64_t floats_per_rank, void* stream)   (poselift.h: PLGatherFn)
+GATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
+
+
+class PLSync(ctypes.Structure):
+    _fields_ = [("world", ctypes.c_int32), ("rank", ctypes.c_int32), ("gather", GATHER_FN),
+                ("user", ctypes.c_void_p)]
+
+
 class PLDesc(ctypes.Structure):
     _fields_ = [
         ("in_dim", ctypes.c_int32), ("hidden", ctypes.c_int32), ("out_dim", ctypes.c_int32),
@@ -21,6 +30,7 @@ class PLDesc(ctypes.Structure):
         ("p_dropout", ctypes.c_float), ("bn_eps", ctypes.c_float), ("bn_momentum", ctypes.c_float),
         ("reserved", ctypes.c_int32),
         ("params", ctypes.c_void_p), ("bn_running", ctypes.c_void_p), ("bn_batches", ctypes.c_void_p),
+        ("sync", ctypes.POINTER(PLSync)),
     ]
 
 

@@ -40,6 +40,25 @@ int check_desc(const PLDesc* d, bool need_arenas) {
     if (reinterpret_cast<uintptr_t>(d->params) & 15) PL_FAIL(PL_EINVAL, "params arena not 16-byte aligned");
     if (d->bn && !d->bn_running) PL_FAIL(PL_EINVAL, "bn_running arena is NULL");
   }
+  if (d->sync) {
+    const PLSync* y = d->sync;
+    if (y->world < 1 || y->rank < 0 || y->rank >= y->world)
+      PL_FAIL(PL_EINVAL, "PLSync: rank %d of world %d", y->rank, y->world);
+    if (y->world > 1 && !y->gather) PL_FAIL(PL_EINVAL, "PLSync: gather callback is NULL");
+  }
+  return PL_OK;
+}
+
+// cross-rank BatchNorm statistics (PLSync): world 1 = local statistics
+inline int sync_world(const PLDesc* d) { return (d->sync && d->bn) ? d->sync->world : 1; }
+inline int sync_rank(const PLDesc* d) { return (d->sync && d->bn) ? d->sync->rank : 0; }
+
+// Partial-statistics buffer: [world][2][P][H] floats; rank r's slab holds its P partial rows of the
+// first quantity then P rows of the second.  The finalize kernels walk all world*P partials.
+int sync_gather(const PLDesc* d, float* base, int64_t floats_per_rank, hipStream_t s) {
+  if (sync_world(d) <= 1) return PL_OK;
+  const int rc = d->sync->gather(d->sync->user, base, floats_per_rank, (void*)s);
+  if (rc != 0) PL_FAIL(PL_ESYNC, "PLSync gather callback failed (%d)", rc);
   return PL_OK;
 }
 
@@ -93,7 +112,7 @@ int out_splits(int M, int N, int K) {
 struct Ws {
   int L, G, RC;
   std::vector<size_t> z, act, bits, mean, rstd, dbpart;
-  size_t stat_a, stat_b, scale, shift, coef, ga, gb, dz, slabs, outpart, dyout, mse, total;
+  size_t stat, scale, shift, coef, ga, gb, dz, slabs, outpart, dyout, mse, total;
   size_t act_bytes, bits_bytes;
 };
 
@@ -119,9 +138,8 @@ Ws plan(const PLDesc* d, int64_t B) {
     w.rstd.push_back(take((size_t)H * 4));
     w.dbpart.push_back(take((size_t)w.RC * H * 4));
   }
-  const size_t part = (size_t)std::max(w.G, w.RC) * H * 4;
-  w.stat_a = take(part);
-  w.stat_b = take(part);
+  const int Pmax = std::max(std::max(w.G, skinny_stat_groups((int)B)), w.RC);
+  w.stat = take((size_t)sync_world(d) * 2 * Pmax * H * 4);
   w.scale = take((size_t)w.L * H * 4);
   w.shift = take((size_t)w.L * H * 4);
   w.coef = take((size_t)3 * H * 4);
@@ -327,10 +345,14 @@ extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, in
     g.A = a_in; g.B = ly.W; g.C = f32(ws, w.z[l]); g.bias = ly.b;
     g.M = (int)B; g.N = H; g.K = ly.K; g.lda = ly.K; g.ldb = ly.K; g.ldc = H; g.split_k = 1;
     g.arith = d->dtype;
-    if (d->bn) { g.stat_sum = f32(ws, w.stat_a); g.stat_m2 = f32(ws, w.stat_b); }
-    int groups = w.G;
-    if (l == 0 && skinny_supported(ly.K, H)) {
-      groups = skinny_stat_groups((int)B);
+    const bool skinny = l == 0 && skinny_supported(ly.K, H);
+    const int groups = skinny ? skinny_stat_groups((int)B) : w.G;
+    float* stat = f32(ws, w.stat);
+    if (d->bn) {
+      g.stat_sum = stat + (size_t)sync_rank(d) * 2 * groups * H;
+      g.stat_m2 = g.stat_sum + (size_t)groups * H;
+    }
+    if (skinny) {
       PL_TRY(launch_skinny_wide_out(a_in, ly.W, ly.b, g.C, (int)B, ly.K, H, false, g.stat_sum, g.stat_m2, s));
     } else {
       PL_TRY(launch_gemm_f32(kNT, g, s));
@@ -339,7 +361,8 @@ extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, in
     if (d->bn) {
       float* sc = f32(ws, w.scale) + (size_t)l * H;
       float* sh = f32(ws, w.shift) + (size_t)l * H;
-      PL_TRY(launch_bn_finalize(g.stat_sum, g.stat_m2, groups, (int)B, H, ly.gamma, ly.beta, d->bn_eps,
+      PL_TRY(sync_gather(d, stat, (int64_t)2 * groups * H, s));
+      PL_TRY(launch_bn_finalize(stat, groups, sync_world(d), (int)B, H, ly.gamma, ly.beta, d->bn_eps,
                                 d->bn_momentum, ly.rm, ly.rv, ly.nbt, f32(ws, w.mean[l]),
                                 f32(ws, w.rstd[l]), sc, sh, s));
       scale = sc; shift = sh;
@@ -411,9 +434,12 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
     if (d->bn) {
       // (pass 1 was tried inside the producing GEMM's epilogue: +17 us per GEMM for the 7.5 us
       //  kernel it removed -- every tile finishes at once, so epilogue work is pure tail)
+      float* stat = f32(ws, w.stat);
+      float* mine = stat + (size_t)sync_rank(d) * 2 * w.RC * H;
       PL_TRY(launch_bn_bwd_reduce(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), kscale, Bi, H,
-                                  f32(ws, w.stat_a), f32(ws, w.stat_b), s));
-      PL_TRY(launch_bn_bwd_finalize(f32(ws, w.stat_a), f32(ws, w.stat_b), w.RC, Bi, H, ly.gamma,
+                                  mine, mine + (size_t)w.RC * H, s));
+      PL_TRY(sync_gather(d, stat, (int64_t)2 * w.RC * H, s));
+      PL_TRY(launch_bn_bwd_finalize(stat, w.RC, sync_world(d), sync_rank(d), Bi, H, ly.gamma,
                                     f32(ws, w.rstd[l]), f32(ws, w.coef), ly.ggamma, ly.gbeta, s));
     } else {
       PL_TRY(launch_fill(ly.ggamma, H, 0.f, s));

@@ -41,8 +41,12 @@ __device__ __forceinline__ float parts_sum(float v, float (*red)[RCOLS], int cl,
 }
 
 // BatchNorm statistics finalize: Chan merge of (sum, M2) over 64-row groups.
+// stat = [world][2][G][H] (rank-major: G rows of sums, then G rows of M2); Br rows per rank.  Walking
+// the world*G partials in rank-major order is walking the concatenated batch's groups in row order,
+// so the result is the one a single process gets on the concatenated batch (when Br % 128 == 0 even
+// bit for bit: same partials, same order).
 __global__ __launch_bounds__(NTHR) void bn_finalize_kernel(
-    const float* __restrict__ stat_sum, const float* __restrict__ stat_m2, int G, int B, int H,
+    const float* __restrict__ stat, int G, int world, int Br, int H,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* running_mean, float* running_var, int64_t* batches, float* mean_out, float* rstd_out,
     float* scale_out, float* shift_out) {
@@ -50,22 +54,30 @@ __global__ __launch_bounds__(NTHR) void bn_finalize_kernel(
   const int cl = threadIdx.x & (RCOLS - 1), part = threadIdx.x / RCOLS;
   const int c = blockIdx.x * RCOLS + cl;
   const bool ok = c < H;
+  const int GT = G * world;
+  const float Bt = (float)Br * (float)world;
+  const size_t GH = (size_t)G * H;
   float s = 0.f;
   if (ok)
-    for (int g = part; g < G; g += RPARTS) s += stat_sum[(size_t)g * H + c];
-  const float mean = parts_sum(s, red, cl, part) / (float)B;
+    for (int g = part; g < GT; g += RPARTS) {
+      const int r = g / G, gl = g - r * G;
+      s += stat[(size_t)r * 2 * GH + (size_t)gl * H + c];
+    }
+  const float mean = parts_sum(s, red, cl, part) / Bt;
   float m2 = 0.f;
   if (ok)
-    for (int g = part; g < G; g += RPARTS) {
-      const int n = max(0, min(64, B - g * 64));
+    for (int g = part; g < GT; g += RPARTS) {
+      const int r = g / G, gl = g - r * G;
+      const int n = max(0, min(64, Br - gl * 64));
       if (n > 0) {
-        const float d = stat_sum[(size_t)g * H + c] / (float)n - mean;
-        m2 += stat_m2[(size_t)g * H + c] + (float)n * d * d;
+        const size_t at = (size_t)r * 2 * GH + (size_t)gl * H + c;
+        const float d = stat[at] / (float)n - mean;
+        m2 += stat[at + GH] + (float)n * d * d;
       }
     }
   const float m2t = parts_sum(m2, red, cl, part);
   if (part == 0 && ok) {
-    const float var = m2t / (float)B;  // biased
+    const float var = m2t / Bt;  // biased
     const float rstd = 1.0f / sqrtf(var + eps);
     const float sc = gamma[c] * rstd;
     mean_out[c] = mean;
@@ -73,7 +85,7 @@ __global__ __launch_bounds__(NTHR) void bn_finalize_kernel(
     scale_out[c] = sc;
     shift_out[c] = beta[c] - mean * sc;
     if (running_mean) {
-      const float unbiased = var * ((float)B / (float)(B - 1));
+      const float unbiased = var * (Bt / (Bt - 1.0f));
       running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
       running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
     }
@@ -199,26 +211,44 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_reduce_kernel(
   }
 }
 
+// part = [world][2][RC][H] (rank-major: RC rows of sum dy, then RC rows of sum dy*zhat).  The dz
+// coefficients use every rank's partials (the statistics were global, so is their gradient); dgamma
+// and dbeta are this rank's own sums -- the gradient all-reduce adds the other ranks'.
 __global__ __launch_bounds__(NTHR) void bn_bwd_finalize_kernel(
-    const float* __restrict__ part_dy, const float* __restrict__ part_dyz, int RC, int B, int H,
+    const float* __restrict__ part_all, int RC, int world, int rank, int Br, int H,
     const float* __restrict__ gamma, const float* __restrict__ rstd, float* __restrict__ coef,
     float* __restrict__ dgamma, float* __restrict__ dbeta) {
   __shared__ float red[RPARTS][RCOLS];
   const int cl = threadIdx.x & (RCOLS - 1), part = threadIdx.x / RCOLS;
   const int c = blockIdx.x * RCOLS + cl;
   const bool ok = c < H;
+  const size_t RH = (size_t)RC * H;
+  const float* mine = part_all + (size_t)rank * 2 * RH;
   float a = 0.f, b = 0.f;
   if (ok)
     for (int k = part; k < RC; k += RPARTS) {
-      a += part_dy[(size_t)k * H + c];
-      b += part_dyz[(size_t)k * H + c];
+      a += mine[(size_t)k * H + c];
+      b += mine[RH + (size_t)k * H + c];
     }
   const float sdy = parts_sum(a, red, cl, part);
   const float sdyz = parts_sum(b, red, cl, part);
+  float tdy = sdy, tdyz = sdyz;
+  if (world > 1) {                        // fixed rank-major order: every rank computes the same totals
+    a = 0.f; b = 0.f;
+    if (ok)
+      for (int k = part; k < RC * world; k += RPARTS) {
+        const int r = k / RC, kl = k - r * RC;
+        a += part_all[(size_t)r * 2 * RH + (size_t)kl * H + c];
+        b += part_all[(size_t)r * 2 * RH + RH + (size_t)kl * H + c];
+      }
+    tdy = parts_sum(a, red, cl, part);
+    tdyz = parts_sum(b, red, cl, part);
+  }
   if (part == 0 && ok) {
+    const float Bt = (float)Br * (float)world;
     coef[c] = gamma[c] * rstd[c];
-    coef[H + c] = sdy / (float)B;
-    coef[2 * H + c] = sdyz / (float)B;
+    coef[H + c] = tdy / Bt;
+    coef[2 * H + c] = tdyz / Bt;
     dgamma[c] = sdyz;
     dbeta[c] = sdy;
   }
@@ -506,11 +536,11 @@ inline int stream_rows_grid(int B, int strips) {
 // =====================================================================================
 // launchers
 // =====================================================================================
-int launch_bn_finalize(const float* stat_sum, const float* stat_m2, int G, int B, int H,
+int launch_bn_finalize(const float* stat, int G, int world, int B, int H,
                        const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, int64_t* batches, float* mean,
                        float* rstd, float* scale, float* shift, hipStream_t s) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((H + RCOLS - 1) / RCOLS), dim3(NTHR), 0, s, stat_sum, stat_m2, G, B,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((H + RCOLS - 1) / RCOLS), dim3(NTHR), 0, s, stat, G, world, B,
                      H, gamma, beta, eps, momentum, running_mean, running_var, batches, mean, rstd,
                      scale, shift);
   PL_CHECK_LAUNCH("bn_finalize");
@@ -553,10 +583,10 @@ int launch_bn_bwd_reduce(const float* g, const uint64_t* bits, const float* z, c
   return PL_OK;
 }
 
-int launch_bn_bwd_finalize(const float* part_dy, const float* part_dyz, int RC, int B, int H,
+int launch_bn_bwd_finalize(const float* part, int RC, int world, int rank, int B, int H,
                            const float* gamma, const float* rstd, float* coef, float* dgamma,
                            float* dbeta, hipStream_t s) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((H + RCOLS - 1) / RCOLS), dim3(NTHR), 0, s, part_dy, part_dyz, RC,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((H + RCOLS - 1) / RCOLS), dim3(NTHR), 0, s, part, RC, world, rank,
                      B, H, gamma, rstd, coef, dgamma, dbeta);
   PL_CHECK_LAUNCH("bn_bwd_finalize");
   return PL_OK;

@@ -70,7 +70,8 @@ int prof_read(double min_flops, double max_flops, double* ms_total, int64_t* lau
 inline int bitmap_words_per_row(int H) { return ((H + 255) / 256) * 4; }
 
 // BN statistics: merge per-group (sum, M2) partials -> mean/rstd/scale/shift, update running
-int launch_bn_finalize(const float* stat_sum, const float* stat_m2, int G, int B, int H,
+// (stat = [world][2][G][H]: per rank G rows of sums then G rows of M2; B = rows per rank)
+int launch_bn_finalize(const float* stat, int G, int world, int B, int H,
                        const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, int64_t* batches,
                        float* mean, float* rstd, float* scale, float* shift, hipStream_t s);
@@ -86,7 +87,8 @@ int launch_bn_bwd_reduce(const float* g, const uint64_t* bits, const float* z, c
                          const float* rstd, float keep_scale, int B, int H, float* part_dy,
                          float* part_dyz, hipStream_t s);
 // finalize: c = {gamma*rstd, sum_dy/B, sum_dyz/B}; dgamma, dbeta
-int launch_bn_bwd_finalize(const float* part_dy, const float* part_dyz, int RC, int B, int H,
+// (part = [world][2][RC][H]; coef uses all ranks' partials, dgamma/dbeta this rank's only)
+int launch_bn_bwd_finalize(const float* part, int RC, int world, int rank, int B, int H,
                            const float* gamma, const float* rstd, float* coef, float* dgamma,
                            float* dbeta, hipStream_t s);
 // pass 2: dz = c0*(dy - c1 - zhat*c2)  (bn) or dz = dy (no bn); partial column sums of dz

@@ -95,6 +95,21 @@ class GradSync:
         return self.reduce_flat(model.flat_grads)
 
 
+def all_gather_slabs(buf, group=None):
+    """buf [world][n] on the device with this rank's slab filled: fill the other slabs (the
+    PLSync gather contract of include/poselift.h).  RCCL gathers in place on its own stream,
+    ordered against the current stream by torch.distributed."""
+    rank = dist.get_rank(group)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(buf, buf[rank], group=group)
+    else:
+        parts = [torch.empty_like(buf[0]) for _ in range(buf.shape[0])]
+        dist.all_gather(parts, buf[rank].clone(), group=group)
+        for r, part in enumerate(parts):
+            if r != rank:
+                buf[r].copy_(part)
+
+
 def broadcast_model(model, src=0, group=None):
     """Make every rank start from rank `src`'s parameters and BatchNorm buffers."""
     if not dist.is_initialized():

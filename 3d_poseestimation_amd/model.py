@@ -88,6 +88,7 @@ class LinearModel(nn.Module):
         self._inject_keep = None
         self._grad_sync = None
         self._dp_cuts = None
+        self._sync_struct = self._gather_cb = self._sync_group = self._active_ws = self._cb_error = None
         self._flat = self._flat_grad = self._flat_grad_tmp = None
         self._ws_pool, self._ws_token = {}, 0
         self._flatten()
@@ -129,17 +130,21 @@ class LinearModel(nn.Module):
             bn=int(bool(self.BN)), dtype=self.compute_dtype, p_dropout=float(self.p_dropout),
             bn_eps=float(self.batch_norm1.eps), bn_momentum=float(self.batch_norm1.momentum), reserved=0,
             params=flat.data_ptr(), bn_running=running.data_ptr(), bn_batches=batches.data_ptr())
+        if self._sync_struct is not None:
+            self._desc.sync = ctypes.pointer(self._sync_struct)
 
     # ctypes descriptors and device workspaces are rebuilt, not copied (copy.deepcopy / torch.save(model))
     def __getstate__(self):
         st = self.__dict__.copy()
-        for k in ("_desc", "_ws_pool", "_flat_grad", "_flat_grad_tmp", "_grad_sync", "last_workspace", "_inject_keep"):
+        for k in ("_desc", "_ws_pool", "_flat_grad", "_flat_grad_tmp", "_grad_sync", "last_workspace", "_inject_keep",
+                  "_sync_struct", "_gather_cb", "_sync_group", "_active_ws", "_cb_error"):
             st.pop(k, None)
         return st
 
     def __setstate__(self, st):
         self.__dict__.update(st)
         self._grad_sync = self._inject_keep = self._dp_cuts = None
+        self._sync_struct = self._gather_cb = self._sync_group = self._active_ws = self._cb_error = None
         self._ws_pool, self._ws_token = {}, 0
         self._flatten()
 
@@ -180,6 +185,63 @@ class LinearModel(nn.Module):
         behind which to hide."""
         self._grad_sync = sync
         self._dp_cuts = self._check_cuts(cuts)
+
+    # ------------------------------------------------------------------ SyncBN
+    def set_sync_bn(self, enabled=True, group=None):
+        """Training-mode BatchNorm over the GLOBAL batch of a data-parallel job (every rank must feed
+        the same number of rows): the per-layer partial statistics are all-gathered (one small
+        collective per hidden layer in forward, one in backward -- PLSync in include/poselift.h).
+        The result does not depend on how the global batch is cut into ranks.  Off by default: the
+        reference is single-process, and plain DP (statistics per shard) is the DDP convention."""
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if not enabled or world == 1:
+            return self._enable_sync(1, 0, None)
+        from . import dp
+        return self._enable_sync(world, dist.get_rank(group), lambda slabs: dp.all_gather_slabs(slabs, group))
+
+    def _enable_sync(self, world, rank, gather_impl):
+        """gather_impl(slabs [world][n] device tensor, slab `rank` filled) fills the other slabs."""
+        if world == 1:
+            self._sync_struct = self._gather_cb = self._sync_group = None
+            self._desc.sync = None
+        else:
+            self._sync_group = gather_impl
+            self._gather_cb = _lib.GATHER_FN(self._on_gather)
+            self._sync_struct = _lib.PLSync(world, rank, self._gather_cb, None)
+            self._desc.sync = ctypes.pointer(self._sync_struct)
+        self._ws_pool = {}                    # the workspace holds world-sized gather buffers
+        return self
+
+    @property
+    def sync_bn(self):
+        return self._sync_struct is not None
+
+    def _on_gather(self, _user, buf, floats_per_rank, _stream):
+        """PLGatherFn: called by the library between two of its own launches.  Exceptions cannot
+        cross the C frames: they are parked and re-raised by _guarded()."""
+        try:
+            ws, world = self._active_ws, self._sync_struct.world
+            off, nbytes = buf - ws["buf"].data_ptr(), world * floats_per_rank * 4
+            if off < 0 or off + nbytes > ws["bytes"]:
+                raise _lib.PoseliftError("gather buffer outside the active workspace")
+            self._sync_group(ws["buf"][off:off + nbytes].view(torch.float32).view(world, floats_per_rank))
+            return 0
+        except BaseException as e:            # noqa: BLE001 -- re-raised on the Python side of the call
+            self._cb_error = e
+            return 1
+
+    def _guarded(self, ws, rc_fn, what):
+        """Run one library call that may call back into _on_gather."""
+        self._active_ws, self._cb_error = ws, None
+        try:
+            rc = rc_fn()
+        finally:
+            self._active_ws = None
+        if self._cb_error is not None:
+            err, self._cb_error = self._cb_error, None
+            raise err
+        _lib.check(rc, what)
 
     def _check_cuts(self, cuts):
         n = len(self._named_holders())
@@ -256,11 +318,10 @@ class LinearModel(nn.Module):
             if tuple(inj.shape) != want or inj.element_size() != 8:
                 raise _lib.PoseliftError(f"inject_keep must be 64-bit words of shape {want}")
         self._step += 1
-        rc = _lib.lib().pl_lifter_fwd_train(
+        self._guarded(ws, lambda: _lib.lib().pl_lifter_fwd_train(
             ctypes.byref(self._desc), x2.data_ptr(), y.data_ptr(), B, ws["buf"].data_ptr(), ws["bytes"],
             self._seed, self._step, inj.data_ptr() if inj is not None else None,
-            _lib.current_stream_ptr())
-        _lib.check(rc, "pl_lifter_fwd_train")
+            _lib.current_stream_ptr()), "pl_lifter_fwd_train")
         self.last_workspace = ws
         return y
 
@@ -281,11 +342,11 @@ class LinearModel(nn.Module):
             # data-parallel overlap: after each layer range the tail of the arena down to that
             # range's lowest layer is final and is all-reduced while the layers below compute
             for hi, lo, a_lo, a_hi in self._bwd_ranges():
-                _lib.check(_lib.lib().pl_lifter_bwd_layers(*args, hi, lo, _lib.current_stream_ptr()),
-                           "pl_lifter_bwd_layers")
+                self._guarded(ws, lambda: _lib.lib().pl_lifter_bwd_layers(*args, hi, lo, _lib.current_stream_ptr()),
+                              "pl_lifter_bwd_layers")
                 sync.launch_bucket(target[a_lo:a_hi])
         else:
-            _lib.check(_lib.lib().pl_lifter_bwd(*args, _lib.current_stream_ptr()), "pl_lifter_bwd")
+            self._guarded(ws, lambda: _lib.lib().pl_lifter_bwd(*args, _lib.current_stream_ptr()), "pl_lifter_bwd")
         if accumulate:
             for s, p in zip(self._slots, self._param_list):
                 gview = target[s.offset:s.offset + s.numel].view(s.shape)
@@ -314,7 +375,7 @@ class LinearModel(nn.Module):
             L = _lib.lib()
 
             def call(hi, lo):
-                _lib.check(L.pl_lifter_train_fwd_bwd(
+                self._guarded(ws, lambda: L.pl_lifter_train_fwd_bwd(
                     ctypes.byref(self._desc), x2.data_ptr(), target.data_ptr(), B, ws["buf"].data_ptr(), ws["bytes"],
                     self._seed, self._step, y.data_ptr(), loss.data_ptr(), grads.data_ptr(), hi, lo,
                     _lib.current_stream_ptr()), "pl_lifter_train_fwd_bwd")

@@ -34,7 +34,8 @@ typedef enum PLStatus {
   PL_EDTYPE = -3,       /* unsupported compute dtype                             */
   PL_EBATCH = -4,       /* B < 2 with training-mode BatchNorm (torch raises too) */
   PL_EHIP = -5,         /* a HIP runtime call or launch failed                   */
-  PL_EWORKSPACE = -6    /* workspace pointer null or too small                   */
+  PL_EWORKSPACE = -6,   /* workspace pointer null or too small                   */
+  PL_ESYNC = -7         /* the PLSync gather callback reported a failure         */
 } PLStatus;
 
 /* arithmetic of the 1024-wide GEMMs (storage is fp32 in every mode):
@@ -43,6 +44,26 @@ typedef enum PLStatus {
  *   PL_BF16X6  each fp32 operand split into 3 bf16 pieces, 6 bf16 MFMAs per product term:
  *              fp32-grade results at 6/16 of the fp32 matrix time */
 typedef enum PLDtype { PL_F32 = 0, PL_BF16 = 1, PL_BF16X6 = 2 } PLDtype;
+
+/* Cross-rank BatchNorm statistics ("SyncBN"; data-parallel extension, SURVEY 8e -- the reference is
+ * single-process and has no counterpart).  With PLDesc.sync set and world > 1, training-mode BatchNorm
+ * normalises with the statistics of the GLOBAL batch (world x B rows; every rank must pass the same B):
+ * after a layer's partial statistics are computed the library calls
+ *     gather(user, buf, floats_per_rank, stream)
+ * where buf = [world][floats_per_rank] device floats inside the caller's workspace and slab `rank` is
+ * already filled by work enqueued on `stream`.  The callee must enqueue an all-gather that fills the
+ * other slabs, ordered after that work and before anything enqueued on `stream` later (RCCL:
+ * ncclAllGather in place on that stream), and return 0 (non-zero -> PL_ESYNC).  One gather per hidden
+ * layer in the training forward (2 x ceil(B/64)-ish x hidden floats) and one in backward.  The merged
+ * result does not depend on how the global batch is cut into ranks: forward activations and running
+ * statistics are bit-identical to one process running the concatenated batch. */
+typedef int (*PLGatherFn)(void* user, float* buf, int64_t floats_per_rank, void* stream);
+typedef struct PLSync {
+  int32_t world;       /* number of ranks (1 = local statistics)              */
+  int32_t rank;        /* this process, 0 <= rank < world                     */
+  PLGatherFn gather;
+  void* user;          /* passed back to gather                               */
+} PLSync;
 
 /* Lifter descriptor: LinearModel(i_dim, o_dim, linear_size, num_stage, p_dropout, BN)
  * phase1_lifting/baselineModel.py:50-85.
@@ -69,6 +90,7 @@ typedef struct PLDesc {
   float* params;
   float* bn_running;
   int64_t* bn_batches;
+  const PLSync* sync;  /* NULL = BatchNorm over the local batch (the reference's behaviour) */
 } PLDesc;
 
 int pl_version(void);

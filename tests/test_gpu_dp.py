@@ -69,6 +69,60 @@ def test_cut_backward_is_bitwise_the_one_call_backward(cuts):
         m.set_grad_sync(None, [7])
 
 
+@pytest.mark.parametrize("rank", [0, 1])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x6"])
+def test_sync_bn_with_a_mirror_rank_is_the_doubled_batch(rank, dtype):
+    """PLSync in one process: a fake 2-rank world whose other rank holds the same rows (the gather
+    copies this rank's slab into the other).  Global-batch statistics of [x; x] -- the forward
+    must be bitwise what one process computes on the concatenated batch (B % 128 == 0), running
+    statistics included; gradients agree to round-off once the mirror's share is added."""
+    import __graft_entry__ as ge
+    pkg = ge.build()
+    B = 256
+    x, y = pkg.synth.synthetic_batch(B, 8, "cuda:0")
+    torch.manual_seed(0)
+    ref = pkg.LinearModel(34, 51, linear_size=256, p_dropout=0.0, compute_dtype=dtype).to("cuda:0").train()
+    torch.manual_seed(0)
+    m = pkg.LinearModel(34, 51, linear_size=256, p_dropout=0.0, compute_dtype=dtype).to("cuda:0").train()
+    calls = []
+
+    def mirror(slabs):
+        calls.append(tuple(slabs.shape))
+        slabs[1 - rank].copy_(slabs[rank])
+    m._enable_sync(2, rank, mirror)
+    assert m.sync_bn
+
+    xx, yy = torch.cat([x, x]), torch.cat([y, y])
+    out_ref = ref(xx)
+    pkg.mse_loss(out_ref.reshape(yy.shape), yy).backward()
+    out = m(x)
+    pkg.mse_loss(out.reshape(y.shape), y).backward()
+    assert torch.equal(out, out_ref[:B]) and torch.equal(out, out_ref[B:])
+    assert torch.equal(m._bn_running, ref._bn_running) and torch.equal(m._bn_batches, ref._bn_batches)
+    assert len(calls) == 10 and all(c[0] == 2 for c in calls)          # 5 layers x (forward + backward)
+    # DP averaging: (g_rank + g_mirror) / 2 = g_rank here; the full-batch loss is the mean over 2B rows
+    for s in m._slots:
+        if s.name.endswith(".bias") and "batch_norm" not in s.name and s.name != "w2.bias":
+            continue                                                   # pre-BN biases: zero true gradient
+        a = m.flat_grads[s.offset:s.offset + s.numel].double()
+        b = ref.flat_grads[s.offset:s.offset + s.numel].double()
+        assert float((a - b).norm() / (b.norm() + 1e-30)) < 2e-5, s.name
+    # the fused step takes the same route
+    m.manual_seed(0, step=0)
+    g_autograd = m.flat_grads.clone()
+    m.fused_train_fwd_bwd(x.reshape(B, -1), y.reshape(B, -1), None)
+    assert torch.equal(m.flat_grads, g_autograd)
+    # an exception inside the gather surfaces as itself, not as a status code
+    def broken(_):
+        raise RuntimeError("link down")
+    m._enable_sync(2, rank, broken)
+    with pytest.raises(RuntimeError, match="link down"):
+        m(x)
+    m.set_sync_bn(False)
+    assert not m.sync_bn
+    m(x)                                                               # local statistics again
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -114,6 +168,37 @@ def _worker(rank, world, port, q):
     c = run(True, False, True)
     d = run(True, False, False)          # every rank the whole batch: the average is the same gradient
     assert torch.allclose(c, d, rtol=1e-4, atol=1e-6), float((c - d).abs().max())
+    # SyncBN (PLSync over a real all-gather): 2 x half batch with global statistics == one process
+    # on the whole batch -- forward and running statistics bitwise (128-row shards), gradients to
+    # round-off after the DP average
+    torch.manual_seed(0)
+    ref = pkg.LinearModel(34, 51, linear_size=128, p_dropout=0.0).to(dev).train()
+    torch.manual_seed(0)
+    m = pkg.LinearModel(34, 51, linear_size=128, p_dropout=0.0).to(dev).train().set_sync_bn(True)
+    assert m.sync_bn
+    out_ref = ref(xs)
+    pkg.mse_loss(out_ref.reshape(ys.shape), ys).backward()
+    out = m(xs[lo:hi])
+    pkg.mse_loss(out.reshape(ys[lo:hi].shape), ys[lo:hi]).backward()
+    assert torch.equal(out, out_ref[lo:hi]), "SyncBN forward differs from the single-process global batch"
+    assert torch.equal(m._bn_running, ref._bn_running)
+    gsum = m.flat_grads.clone()
+    dist.all_reduce(gsum)
+    gsum /= world
+    for s in m._slots:
+        if s.name.endswith(".bias") and "batch_norm" not in s.name and s.name != "w2.bias":
+            continue
+        a_, b_ = gsum[s.offset:s.offset + s.numel].double(), ref.flat_grads[s.offset:s.offset + s.numel].double()
+        assert float((a_ - b_).norm() / (b_.norm() + 1e-30)) < 2e-5, s.name
+    # and through train_step with the overlapped gradient all-reduce
+    opt = pkg.FlatAdamW(m, lr=1e-3)
+    sync = pkg.dp.GradSync()
+    m.set_grad_sync(sync)
+    pkg.train_step(m, opt, xs[lo:hi], ys[lo:hi], grad_sync=sync)
+    torch.cuda.synchronize()
+    gathered = [torch.zeros_like(m.flat_params) for _ in range(world)]
+    dist.all_gather(gathered, m.flat_params)
+    assert all(torch.equal(gathered[0], g) for g in gathered), "ranks diverged under SyncBN"
     dist.barrier()
     dist.destroy_process_group()
     q.put(rank)

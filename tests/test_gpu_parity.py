@@ -728,3 +728,28 @@ def test_checkpoint_envelope_roundtrip_and_stock_optimizer(pkg, tmp_path):
     fresh.load_state_dict(ck["model"])
     assert all(torch.equal(a, b) for a, b in zip(fresh.state_dict().values(), ours_m.state_dict().values()))
     assert fresh._arenas_intact()
+
+
+def test_reduce_lr_on_plateau_drives_the_flat_optimizer(pkg):
+    """train_1.py:41,106: ReduceLROnPlateau(factor .7, patience 3, cooldown 2, min_lr 5e-6) stepped with the
+    last batch's train loss.  FlatAdamW is a torch Optimizer: the scheduler rewrites param_groups[0]['lr']
+    and the next kernel launch must use it (checked against the oracle's AdamW at the scheduled rate)."""
+    torch.manual_seed(2)
+    m = pkg.LinearModel(34, 51, linear_size=64, p_dropout=0.0).to(DEV).train()
+    opt = pkg.FlatAdamW(m, lr=1e-2)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=0.7, patience=3, cooldown=2, min_lr=5e-6)
+    x, y = pkg.synth.synthetic_batch(64, 5, DEV)
+    pkg.train_step(m, opt, x, y)
+    for _ in range(5):                     # a loss that never improves: patience 3 -> one reduction
+        sched.step(1.0)
+    assert abs(opt.param_groups[0]["lr"] - 0.7e-2) < 1e-12
+    before = m.flat_params.clone()
+    names = [k for k, _ in m.named_parameters()]
+    p0 = {k: p.detach().cpu().numpy().copy() for k, p in m.named_parameters()}
+    m0 = {k: opt.state[p]["exp_avg"].cpu().numpy().copy() for k, p in m.named_parameters()}
+    v0 = {k: opt.state[p]["exp_avg_sq"].cpu().numpy().copy() for k, p in m.named_parameters()}
+    pkg.train_step(m, opt, x, y)
+    for k, p in m.named_parameters():
+        want, _, _ = orc.adamw_step(p0[k], p.grad.cpu().numpy(), m0[k], v0[k], 2, lr=0.7e-2)
+        _close(p.detach().cpu().numpy(), want, 1e-5, 1e-7)
+    assert names and not torch.equal(before, m.flat_params)
