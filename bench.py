@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--dtype", choices=["fp32", "bf16", "bf16x6"], default="bf16x6",
                     help="GEMM arithmetic of the headline run.  bf16x6 (default) and fp32 both meet the 1e-3 mm "
                          "parity gate; bf16 does not (about 1 mm)")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="N>1 only: BatchNorm statistics over the global batch (10 small all-gathers per step); "
+                         "off by default = statistics per shard, the DDP convention")
     ap.add_argument("--no-extras", action="store_true", help="skip the bf16-mode and PyTorch-eager side measurements")
     return ap.parse_args()
 
@@ -219,6 +222,8 @@ def main():
     model = pkg.LinearModel(34, 51, linear_size=1024, num_stage=2, p_dropout=0.5, BN=True,
                             compute_dtype=a.dtype).to(dev).train()
     model.manual_seed(1234 + rank)                          # own dropout stream per rank
+    if a.sync_bn and world > 1:
+        model.set_sync_bn(True)
     opt = pkg.FlatAdamW(model, lr=1e-4)                     # train_1.py:39 (weight_decay 0.01)
     sync = pkg.dp.GradSync() if world > 1 else None
     model.set_grad_sync(sync)                               # all-reduce overlapped with the backward tail
@@ -300,7 +305,7 @@ def main():
                                    "step = zero_grad+forward+MSE+backward+AdamW"
                                    + ("+RCCL grad all-reduce" if world > 1 else ""),
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
-                       "parallelism": f"dp{world}",
+                       "parallelism": f"dp{world}" + ("+syncbn" if a.sync_bn and world > 1 else ""),
                        "gemm_arith": "fp32 MFMA (v_mfma_f32_32x32x2_f32)" if a.dtype == "fp32"
                        else "bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate and storage"
                        + (", three-way operand split x 6 products (fp32-grade)" if a.dtype == "bf16x6" else "")},

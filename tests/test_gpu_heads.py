@@ -42,7 +42,7 @@ def test_soft_argmax_3d(pkg, B, D, H, W, scale):
     c = pkg.soft_argmax_3d(x, J, D)
     want = ho.soft_argmax(out.numpy(), J, D, True)
     np.testing.assert_allclose(c.detach().cpu().numpy(), want, rtol=0, atol=2e-5)
-    assert c.shape == (B, J * 3) and float(c.abs().max()) <= 1.0
+    assert c.shape == (B, J * 3) and float(c.detach().abs().max()) <= 1.0
     g = torch.randn(B, J * 3)
     c.backward(g.to(DEV))
     xr = out.double().requires_grad_(True)
