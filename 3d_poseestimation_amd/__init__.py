@@ -6,6 +6,7 @@ alias module at the repository root.
 from ._lib import PoseliftError, lib  # noqa: F401
 from .model import Linear, LinearModel, weight_init  # noqa: F401
 from .optim import FlatAdamW  # noqa: F401
-from .train import epoch_mpjpe_mm, eval_step, flip_pose, loss_MPJPE, mse_loss, train_step  # noqa: F401
+from .train import epoch_mpjpe_mm, eval_step, flip_pose, loss_MPJPE, mse_loss, predict_flip_tta, train_step  # noqa: F401
 from .heads import soft_argmax_2d, soft_argmax_3d  # noqa: F401
-from . import dp, layout, synth  # noqa: F401
+from .data import PoseFeeder, epoch_indices  # noqa: F401
+from . import data, dp, layout, synth  # noqa: F401

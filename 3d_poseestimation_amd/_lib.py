@@ -63,6 +63,9 @@ SIGNATURES = {
     "pl_adamw_flat": (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_float, _c.c_float, _c.c_float,
                                  _c.c_float, _c.c_float, _c.c_int64, _c.c_float, _P]),
     "pl_flip_pose": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P]),
+    "pl_gather_rows2": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _P, _c.c_int64, _c.c_int64, _P, _P, _P]),
+    "pl_flip_tta_pack": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P]),
+    "pl_flip_tta_merge": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P]),
     "pl_softargmax_fwd": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _P, _P, _P]),
     "pl_softargmax_bwd": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,
                                      _P, _P]),

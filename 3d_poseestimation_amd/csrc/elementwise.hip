@@ -483,6 +483,55 @@ __global__ void flip_pose_kernel(const float* __restrict__ in, float* __restrict
   out[i] = v;
 }
 
+// Flip test-time augmentation around ONE forward of 2B rows (eval-mode BatchNorm is row-wise, so the
+// two passes the reference makes, train_5 copy.py:160-171 / train_1.py:128-134, are one batch):
+//   pack : xx[0:B) = x, xx[B:2B) = flip(x)
+//   merge: y = (yy[0:B) + flip(yy[B:2B))) / 2
+__device__ __forceinline__ int flip_src_joint(int j) {
+  return (j >= 1 && j <= 3) ? j + 3 : (j >= 4 && j <= 6) ? j - 3
+       : (j >= 11 && j <= 13) ? j + 3 : (j >= 14 && j <= 16) ? j - 3 : j;
+}
+
+__global__ void flip_tta_pack_kernel(const float* __restrict__ x, float* __restrict__ xx, int64_t n, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int d = (int)(i % D);
+  const int64_t bj = i / D;
+  const int j = (int)(bj % 17);
+  const int64_t b = bj / 17;
+  float v = x[(b * 17 + flip_src_joint(j)) * D + d];
+  if (d == 0) v = (D == 2) ? 1.0f - v : -v;
+  xx[i] = x[i];
+  xx[n + i] = v;
+}
+
+__global__ void flip_tta_merge_kernel(const float* __restrict__ yy, float* __restrict__ y, int64_t n, int D) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int d = (int)(i % D);
+  const int64_t bj = i / D;
+  const int j = (int)(bj % 17);
+  const int64_t b = bj / 17;
+  float v = yy[n + (b * 17 + flip_src_joint(j)) * D + d];
+  if (d == 0) v = (D == 2) ? 1.0f - v : -v;
+  y[i] = (v + yy[i]) / 2.0f;
+}
+
+// ---- batch gather (data.py PoseFeeder): rows idx[0..n) of two resident row-major tables ----------
+// oa[i][:] = a[idx[i]][:] (wa floats), ob[i][:] = b[idx[i]][:] (wb floats); one thread per output float
+__global__ void gather_rows2_kernel(const float* __restrict__ a, int wa, const float* __restrict__ b, int wb,
+                                    const int64_t* __restrict__ idx, int64_t n, float* __restrict__ oa,
+                                    float* __restrict__ ob) {
+  const int w = wa + wb;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * w) return;
+  const int64_t i = t / w;
+  const int c = (int)(t - i * w);
+  const int64_t r = idx[i];
+  if (c < wa) oa[i * wa + c] = a[r * wa + c];
+  else ob[i * wb + (c - wa)] = b[r * wb + (c - wa)];
+}
+
 // ---- flat AdamW (torch single-tensor update order) ----------------------------------------
 struct AdamWK {
   float decay;       // 1 - lr*wd
@@ -767,5 +816,39 @@ extern "C" int pl_flip_pose(const float* in, float* out, int64_t B, int64_t join
   hipLaunchKernelGGL(flip_pose_kernel, dim3((unsigned)((n + NTHR - 1) / NTHR)), dim3(NTHR), 0, (hipStream_t)stream,
                      in, out, n, (int)D);
   PL_CHECK_LAUNCH("flip_pose");
+  return PL_OK;
+}
+
+extern "C" int pl_flip_tta_pack(const float* x, float* xx, int64_t B, int64_t joints, int64_t D, void* stream) {
+  if (!x || !xx) PL_FAIL(PL_EINVAL, "pl_flip_tta_pack: null pointer");
+  if (B <= 0 || joints != 17 || (D != 2 && D != 3)) PL_FAIL(PL_ESHAPE, "pl_flip_tta_pack: expects (B, 17, 2|3)");
+  const int64_t n = B * joints * D;
+  hipLaunchKernelGGL(flip_tta_pack_kernel, dim3((unsigned)((n + NTHR - 1) / NTHR)), dim3(NTHR), 0,
+                     (hipStream_t)stream, x, xx, n, (int)D);
+  PL_CHECK_LAUNCH("flip_tta_pack");
+  return PL_OK;
+}
+
+extern "C" int pl_flip_tta_merge(const float* yy, float* y, int64_t B, int64_t joints, int64_t D, void* stream) {
+  if (!yy || !y) PL_FAIL(PL_EINVAL, "pl_flip_tta_merge: null pointer");
+  if (B <= 0 || joints != 17 || (D != 2 && D != 3)) PL_FAIL(PL_ESHAPE, "pl_flip_tta_merge: expects (B, 17, 2|3)");
+  const int64_t n = B * joints * D;
+  hipLaunchKernelGGL(flip_tta_merge_kernel, dim3((unsigned)((n + NTHR - 1) / NTHR)), dim3(NTHR), 0,
+                     (hipStream_t)stream, yy, y, n, (int)D);
+  PL_CHECK_LAUNCH("flip_tta_merge");
+  return PL_OK;
+}
+
+extern "C" int pl_gather_rows2(const float* a, int64_t wa, const float* b, int64_t wb, const int64_t* idx,
+                               int64_t n, int64_t table_rows, float* oa, float* ob, void* stream) {
+  if (!a || !b || !idx || !oa || !ob) PL_FAIL(PL_EINVAL, "pl_gather_rows2: null pointer");
+  if (n <= 0 || wa <= 0 || wb <= 0 || wa + wb > 4096 || table_rows <= 0)
+    PL_FAIL(PL_ESHAPE, "pl_gather_rows2: n=%lld wa=%lld wb=%lld rows=%lld", (long long)n, (long long)wa,
+            (long long)wb, (long long)table_rows);
+  const int64_t total = n * (wa + wb);
+  if (total > (int64_t)INT32_MAX * NTHR) PL_FAIL(PL_ESHAPE, "pl_gather_rows2: batch too large");
+  hipLaunchKernelGGL(gather_rows2_kernel, dim3((unsigned)((total + NTHR - 1) / NTHR)), dim3(NTHR), 0,
+                     (hipStream_t)stream, a, (int)wa, b, (int)wb, idx, n, oa, ob);
+  PL_CHECK_LAUNCH("gather_rows2");
   return PL_OK;
 }

@@ -125,10 +125,35 @@ def train_step(model, optimizer, y1, y2, grad_sync=None):
 
 
 @torch.no_grad()
-def eval_step(model, y1, y2, metric_out=None):
-    """train_1.py:112-145 body (model must be in eval mode): forward, MSE, loss_MPJPE."""
+def predict_flip_tta(model, y1, out_dims=3):
+    """(flip_pose(model(flip_pose(y1))) + model(y1)) / 2 for a model in eval mode, as ONE forward
+    of 2B rows (eval BatchNorm is row-wise): pack [y1; flip(y1)], lift, merge.  The intent of the
+    reference's `Flip` branches (train_1.py:128-134, which at HEAD never flips the input;
+    phase5_loop/train_5 copy.py:160-171)."""
+    if model.training:
+        raise ValueError("flip TTA is an eval-mode operation (BatchNorm on running statistics)")
+    y1 = y1.float().contiguous()
+    _lib.require_device_tensor(y1, "y1")
+    if y1.dim() != 3 or y1.shape[1] != 17 or y1.shape[2] not in (2, 3):
+        raise ValueError("flip TTA expects (B, 17, 2|3) poses")
+    B, L = y1.shape[0], _lib.lib()
+    xx = torch.empty((2 * B,) + tuple(y1.shape[1:]), dtype=torch.float32, device=y1.device)
+    with torch.cuda.device(y1.device):
+        _lib.check(L.pl_flip_tta_pack(y1.data_ptr(), xx.data_ptr(), B, 17, y1.shape[2], _lib.current_stream_ptr()),
+                   "pl_flip_tta_pack")
+        yy = model(xx).reshape(2 * B, 17, out_dims).contiguous()
+        out = torch.empty(B, 17, out_dims, dtype=torch.float32, device=y1.device)
+        _lib.check(L.pl_flip_tta_merge(yy.data_ptr(), out.data_ptr(), B, 17, out_dims, _lib.current_stream_ptr()),
+                   "pl_flip_tta_merge")
+    return out
+
+
+@torch.no_grad()
+def eval_step(model, y1, y2, metric_out=None, flip=False):
+    """train_1.py:112-145 body (model must be in eval mode): forward, MSE, loss_MPJPE.
+    flip=True: flip test-time augmentation (predict_flip_tta)."""
     y1, y2 = y1.float(), y2.float()
-    y2_hat = model(y1).reshape(y2.shape)
+    y2_hat = predict_flip_tta(model, y1, y2.shape[-1]).reshape(y2.shape) if flip else model(y1).reshape(y2.shape)
     loss = mse_loss(y2_hat, y2)
     metric = loss_MPJPE(y2_hat, y2, out=metric_out)
     return loss, metric, y2_hat

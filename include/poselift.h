@@ -155,6 +155,14 @@ int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const float* target
                             void* workspace, size_t workspace_bytes, uint64_t seed, uint64_t step,
                             float* y, float* loss, float* flat_grads, int hi, int lo, void* stream);
 
+/* ---- batch feed ------------------------------------------------------------------- */
+/* One batch of the DataLoader path (train_1.py:26-31,75-81: shuffle, collate, .float(), .to(device))
+ * from tables resident in HBM: oa[i] = a[idx[i]] (wa floats per row, the (17,2) keypoints),
+ * ob[i] = b[idx[i]] (wb floats, the (17,3) targets), i < n.  idx: device int64, every value in
+ * [0, table_rows) (the caller's permutation; not checked on the device). */
+int pl_gather_rows2(const float* a, int64_t wa, const float* b, int64_t wb, const int64_t* idx,
+                    int64_t n, int64_t table_rows, float* oa, float* ob, void* stream);
+
 /* ---- loss / metric / optimiser -------------------------------------------------- */
 /* torch.nn.MSELoss(reduction="mean") + its backward  train_1.py:37,94-95.
  * n elements; dpred = grad_scale * 2 (pred - tgt) / n; loss_out: 1 device float.
@@ -173,6 +181,13 @@ int pl_mpjpe_accum(const float* pred, const float* tgt, int64_t B, int64_t joint
  * out = horizontal flip of in, both [B][17][D], D = 2 (x -> 1-x) or 3 (x -> -x), left/right joints
  * [4,5,6,11,12,13] <-> [1,2,3,14,15,16] swapped.  Out of place. */
 int pl_flip_pose(const float* in, float* out, int64_t B, int64_t joints, int64_t D, void* stream);
+
+/* Flip test-time augmentation, (flip_pose(model(flip_pose(x))) + model(x)) / 2 -- the intent of
+ * train_1.py:128-134 and phase5_loop/train_5 copy.py:160-171 -- around ONE eval forward of 2B rows:
+ *   pack : xx [2B][17][D]: rows [0,B) = x, rows [B,2B) = flip_pose(x)
+ *   merge: y [B][17][D] = (yy[0:B) + flip_pose(yy[B:2B))) / 2 */
+int pl_flip_tta_pack(const float* x, float* xx, int64_t B, int64_t joints, int64_t D, void* stream);
+int pl_flip_tta_merge(const float* yy, float* y, int64_t B, int64_t joints, int64_t D, void* stream);
 
 /* torch.optim.AdamW.step  train_1.py:39,96 over one flat arena (p, g, m, v of n floats).
  * t = 1-based step count; g is multiplied by grad_scale first (1/world_size after a

@@ -60,7 +60,7 @@ def test_soft_argmax_2d(pkg, B, H, W):
     x = out.to(DEV).requires_grad_(True)
     c = pkg.soft_argmax_2d(x, J)
     np.testing.assert_allclose(c.detach().cpu().numpy(), ho.soft_argmax(out.numpy(), J, 1, False), rtol=0, atol=2e-5)
-    assert float(c.min()) >= 0.0 and float(c.max()) <= 1.0
+    assert float(c.detach().min()) >= 0.0 and float(c.detach().max()) <= 1.0
     g = torch.randn(B, J * 2)
     c.backward(g.to(DEV))
     xr = out.double().requires_grad_(True)

@@ -649,6 +649,31 @@ def test_flip_pose_vs_oracle(pkg):
         pkg.flip_pose(torch.zeros(4, 16, 3, device=DEV))
 
 
+def test_flip_tta_eval_vs_oracle(pkg):
+    """(flip(model(flip(x))) + model(x)) / 2 in one 2B-row forward == the oracle's two passes."""
+    torch.manual_seed(9)
+    m = pkg.LinearModel(34, 51, linear_size=256, p_dropout=0.5).to(DEV)
+    x, y = pkg.synth.synthetic_batch(200, 6, DEV)
+    m.train()
+    for _ in range(3):                                     # non-trivial running statistics
+        m(x)
+    m.eval()
+    st = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    xn = x.cpu().numpy()
+    plain, _ = orc.forward(st, xn, num_stage=2, train=False)
+    flipped, _ = orc.forward(st, orc.flip_pose(xn), num_stage=2, train=False)
+    want = (orc.flip_pose(flipped.reshape(-1, 17, 3)) + plain.reshape(-1, 17, 3)) / 2
+    got = pkg.predict_flip_tta(m, x)
+    assert orc.mpjpe_mm(got.cpu().numpy().reshape(-1, 51), want.reshape(-1, 51)) < 1e-3
+    two_pass = (pkg.flip_pose(m(pkg.flip_pose(x)).reshape(-1, 17, 3)) + m(x).reshape(-1, 17, 3)) / 2
+    assert torch.equal(got, two_pass)                      # one 2B forward == two B forwards, bitwise
+    loss, metric, y_hat = pkg.eval_step(m, x, y, flip=True)
+    assert torch.equal(y_hat, got)
+    _close(loss.item(), float(np.mean((want - y.cpu().numpy()) ** 2)), 1e-5, 0)
+    with pytest.raises(ValueError):
+        pkg.predict_flip_tta(m.train(), x)
+
+
 def test_bf16x6_mode_is_fp32_grade(pkg):
     """PL_BF16X6 at the bench size: train fwd/bwd against the oracle with the fp32 tolerances."""
     torch.manual_seed(0)
@@ -753,3 +778,38 @@ def test_reduce_lr_on_plateau_drives_the_flat_optimizer(pkg):
         want, _, _ = orc.adamw_step(p0[k], p.grad.cpu().numpy(), m0[k], v0[k], 2, lr=0.7e-2)
         _close(p.detach().cpu().numpy(), want, 1e-5, 1e-7)
     assert names and not torch.equal(before, m.flat_params)
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_pose_feeder_batches_are_the_permuted_rows(pkg, resident):
+    """data.PoseFeeder (the DataLoader hop of train_1.py:26-31,75-81): resident tables + device
+    gather, or pinned tables + prefetched H2D -- the same batches, each pose once per epoch."""
+    rng = np.random.default_rng(3)
+    N, bs = 1000, 96
+    x = rng.random((N, 17, 2))                       # float64 on purpose: the feeder does .float()
+    y = rng.standard_normal((N, 17, 3)).astype(np.float32)
+    fd = pkg.PoseFeeder(x, y, bs, device=DEV, seed=7, resident=resident)
+    assert len(fd) == 11
+    for epoch in (0, 1):
+        fd.set_epoch(epoch)
+        want = pkg.epoch_indices(N, bs, epoch=epoch, seed=7)
+        seen = 0
+        for (a, b), idx in zip(fd, want):
+            assert a.shape == (idx.numel(), 17, 2) and b.shape == (idx.numel(), 17, 3) and a.dtype == torch.float32
+            assert np.array_equal(a.cpu().numpy(), x[idx.numpy()].astype(np.float32))
+            assert np.array_equal(b.cpu().numpy(), y[idx.numpy()])
+            seen += idx.numel()
+        assert seen == N
+    # feeds the train step directly; two DP ranks cut each global batch in two
+    m = pkg.LinearModel(34, 51, linear_size=64).to(DEV).train()
+    opt = pkg.FlatAdamW(m, lr=1e-3)
+    for a, b in pkg.PoseFeeder(x, y, 128, device=DEV, resident=resident, drop_last=True):
+        loss, _ = pkg.train_step(m, opt, a, b)
+    assert torch.isfinite(loss)
+    r0 = [a for a, _ in pkg.PoseFeeder(x, y, 48, device=DEV, seed=7, rank=0, world=2, resident=resident)]
+    r1 = [a for a, _ in pkg.PoseFeeder(x, y, 48, device=DEV, seed=7, rank=1, world=2, resident=resident)]
+    fd.set_epoch(0)
+    for (a, _), p, q in zip(fd, r0, r1):
+        assert torch.equal(a, torch.cat([p, q]))
+    with pytest.raises(pkg.PoseliftError):
+        pkg.PoseFeeder(x, y, 8, device="cpu")

@@ -158,3 +158,30 @@ def test_reduce_lr_on_plateau_drives_flat_adamw(pkg):
     assert lrs[-1] < lrs[4]
     sd = opt.state_dict()
     assert sd["param_groups"][0]["lr"] == lrs[-1] and len(sd["param_groups"][0]["params"]) == 22
+
+
+def test_feeder_epoch_indices_partition_the_table():
+    """data.epoch_indices: every pose exactly once per epoch over all ranks and batches, global
+    batches cut like dp.shard_rows, fresh order per epoch, drop_last drops only the short batch."""
+    import importlib
+    import torch
+    data = importlib.import_module("3d_poseestimation_amd.data")
+    N, bs, world = 1003, 64, 3
+    per_rank = [data.epoch_indices(N, bs, epoch=2, seed=5, rank=r, world=world) for r in range(world)]
+    allidx = torch.cat([torch.cat(b) for b in per_rank])
+    assert sorted(allidx.tolist()) == list(range(N))
+    n_batches = len(per_rank[0])
+    assert n_batches == (N + bs * world - 1) // (bs * world)
+    for k in range(n_batches - 1):
+        assert all(per_rank[r][k].numel() == bs for r in range(world))
+    assert sum(per_rank[r][-1].numel() for r in range(world)) == N - (n_batches - 1) * bs * world
+    # one process sees the same global batches as the ranks together
+    whole = data.epoch_indices(N, bs * world, epoch=2, seed=5)
+    for k in range(n_batches):
+        assert torch.equal(whole[k], torch.cat([per_rank[r][k] for r in range(world) if k < len(per_rank[r])]))
+    other = data.epoch_indices(N, bs, epoch=3, seed=5, rank=0, world=world)
+    assert not torch.equal(other[0], per_rank[0][0])
+    dropped = data.epoch_indices(N, bs, epoch=2, seed=5, rank=0, world=world, drop_last=True)
+    assert len(dropped) == N // (bs * world) and all(t.numel() == bs for t in dropped)
+    plain = data.epoch_indices(10, 4, shuffle=False)
+    assert [t.tolist() for t in plain] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]
