@@ -513,7 +513,8 @@ extern "C" int pl_gemm_arith(int layout, int arith, const float* A, const float*
 #ifdef PL_ABLATE
   if (arith < 0 || arith > 4) PL_FAIL(PL_EDTYPE, "pl_gemm_arith: arith %d", arith);
 #else
-  if (arith < 0 || arith > 2) PL_FAIL(PL_EDTYPE, "pl_gemm_arith: arith %d", arith);
+  // 5 / 6: test hooks forcing the PL_BF16X6 planes / fragment-split main loop (2 = the library's choice)
+  if ((arith < 0 || arith > 2) && arith != 5 && arith != 6) PL_FAIL(PL_EDTYPE, "pl_gemm_arith: arith %d", arith);
 #endif
   if (M <= 0 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX)
     PL_FAIL(PL_ESHAPE, "pl_gemm_f32: bad shape");

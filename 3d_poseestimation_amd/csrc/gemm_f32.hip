@@ -193,6 +193,73 @@ __device__ __forceinline__ void split3(const float (&f)[8], bf16x8 (&p)[3]) {
   }
 }
 
+// ---- epilogue (shared by every main-loop variant) ------------------------------------------
+// acc[a][b][r]: row = m0 + wm*64 + a*32 + (r&3) + 8*(r>>2) + 4*h, col = n0 + wn*32*NB + b*32 + i
+template <bool EDGE, int NB>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restrict__ C, f32x16 (&acc)[2][NB],
+                                              const int m0, const int n0, const int wm, const int wn,
+                                              const int i, const int h) {
+  constexpr int WCOLS = 32 * NB;
+  const int rbase = m0 + wm * 64 + 4 * h;
+  const bool plain = p.split_k > 1;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int col = n0 + wn * WCOLS + b * 32 + i;
+    const bool cok = !EDGE || col < p.N;
+    float bias = 0.f, scale = 1.f, shift = 0.f;
+    if (!plain && cok) {
+      if (p.bias) bias = p.bias[col];
+      if (p.col_scale) { scale = p.col_scale[col]; shift = p.col_shift[col]; }
+    }
+    float ssum = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
+        float v = acc[a][b][r];
+        if (!plain) {
+          v += bias;
+          if (p.addend && cok && (!EDGE || row < p.M)) v += p.addend[(size_t)row * p.ldc + col];
+          if (p.col_scale) v = fmaf(v, scale, shift);
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (p.resid && cok && (!EDGE || row < p.M)) v += p.resid[(size_t)row * p.ldc + col];
+        }
+        acc[a][b][r] = v;
+        if (!EDGE || row < p.M) ssum += v;
+      }
+    if (!plain && p.stat_sum) {
+      // column statistics over this wavefront's 64 rows (both lane halves)
+      ssum += __shfl_xor(ssum, 32);
+      const int g0 = m0 + wm * 64;
+      const int cnt = max(0, min(64, p.M - g0));
+      const float mean = cnt > 0 ? ssum / (float)cnt : 0.f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
+          const float d = acc[a][b][r] - mean;
+          if (!EDGE || row < p.M) m2 = fmaf(d, d, m2);
+        }
+      m2 += __shfl_xor(m2, 32);
+      if (h == 0 && cok) {
+        const size_t o = (size_t)(g0 >> 6) * p.N + col;
+        p.stat_sum[o] = ssum;
+        p.stat_m2[o] = m2;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
+        if (cok && (!EDGE || row < p.M)) C[(size_t)row * p.ldc + col] = acc[a][b][r];
+      }
+  }
+}
+
 // NW = 4 wavefronts (2x2, 64x64 per wave) is what ships.  NW = 8 (2x4, 64x32 per wave, 512 threads) is
 // kept compilable: it was built for the VALU-heavy PL_BF16X6 arithmetic on the theory that two
 // waves per SIMD would share the instruction issue port, and measured SLOWER (forward 62 vs 59 us; the
@@ -456,66 +523,332 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
 #undef PL_FRAGS
 #undef PL_MFMAS
 
-  // ---- epilogue ----------------------------------------------------------------------------
-  // acc[a][b][r]: row = m0 + wm*64 + a*32 + (r&3) + 8*(r>>2) + 4*h, col = n0 + wn*WCOLS + b*32 + i
-  const int rbase = m0 + wm * 64 + 4 * h;
-  const bool plain = p.split_k > 1;
+  gemm_epilogue<EDGE, NB>(p, C, acc, m0, n0, wm, wn, i, h);
+}
+
+// =====================================================================================
+// PL_BF16X6, "planes" pipeline: the three-way bf16 split is done ONCE per element while the operand
+// tile is staged (global -> registers -> split -> LDS), and LDS holds MFMA-ready bf16 planes.
+//
+// Why (tools/ubench/mfma_valu*.hip, measured on gfx950): a VALU instruction issued in the shadow of
+// v_mfma_f32_32x32x16_bf16 is only nearly free up to ~4 per MFMA; beyond that each costs 1.2-1.6 ns
+// of matrix-pipe time.  The fragment-time split above spends ~7.3 VALU instructions per MFMA (every
+// element of the A tile is split by two wavefronts, every element of B by two).  Splitting at staging
+// halves the work (3.7 per MFMA) and leaves the inner loop as ds_read_b128 + MFMA; to keep the VALU
+// density UNIFORM over a tile's MFMAs the split of tile kt+2 is spread over the whole of step kt, which
+// needs three LDS stages (tile kt consumed, kt+1 complete and readable, kt+2 being written) and two
+// staging register sets (tile kt+2 being split, kt+3 in flight).  One barrier per tile, at its end.
+//
+// LDS image of one operand tile (128 rows x BK k): 3 planes x BK/8 k-octets x [128 rows][8 bf16 = 16 B].
+// A lane of the 32x32x16 MFMA wants row = lane&31, k = 8*(lane>>5) .. +7 of a 16-deep step: one
+// ds_read_b128 from octet 2*step + (lane>>5), 32 rows contiguous -> conflict-free without padding.  The
+// octet stride carries a bank rotation (64 B for four octets, 128 B for two) so that the octets one
+// staging wave writes together land on disjoint bank groups.
+//   BK = 32: 3 stages x 50,688 B = 152,064 B, one workgroup per CU          (single-GEMM launches)
+//   BK = 16: 3 stages x 25,728 B =  77,184 B, two workgroups per CU         (the backward dual launch)
+// =====================================================================================
+template <int BKX>
+struct PCfg {
+  static constexpr int OCT = BKX / 8;                               // k-octets per tile
+  static constexpr int OCTS = 2048 + (OCT == 4 ? 64 : 128);          // octet stride, bytes
+  static constexpr int PLANE = OCT * OCTS;
+  static constexpr int OPP = 3 * PLANE;                             // one operand tile
+  static constexpr int STAGE = 2 * OPP;
+  static constexpr int LDS = 3 * STAGE;
+};
+
+// Global -> registers: BKX/2 floats per thread and operand tile, in the order split8 wants them.
+//   k-contiguous source (rows K-major):
+//     BK 32: thread = (octet = tid&3, row = tid>>2 [+64]): v0,v1 = the 8 k of row, v2,v3 = of row + 64
+//     BK 16: thread = (octet = tid&1, row = tid>>1):       v0,v1
+//   k-strided source (rows M/N-major):
+//     BK 32: thread = (row pair = tid&63, octet = tid>>6): eight float2; v[j/2] = (r0@k_j, r1@k_j, r0@k_j+1, r1@k_j+1)
+//     BK 16: thread = (row = tid&127, octet = tid>>7):     eight floats;  v0 = k0..3, v1 = k4..7
+template <bool KS, int BKX>
+__device__ __forceinline__ void load_tile_p(Stage& s, const float* __restrict__ base, int ld, int r0, int k0,
+                                            int tid) {
+  if (!KS && BKX == 32) {
+    const float* t = base + (size_t)r0 * ld + k0 + (size_t)(tid >> 2) * ld + (tid & 3) * 8;
+    s.v0 = *reinterpret_cast<const float4*>(t);
+    s.v1 = *reinterpret_cast<const float4*>(t + 4);
+    s.v2 = *reinterpret_cast<const float4*>(t + (size_t)64 * ld);
+    s.v3 = *reinterpret_cast<const float4*>(t + (size_t)64 * ld + 4);
+  } else if (!KS) {
+    const float* t = base + (size_t)r0 * ld + k0 + (size_t)(tid >> 1) * ld + (tid & 1) * 8;
+    s.v0 = *reinterpret_cast<const float4*>(t);
+    s.v1 = *reinterpret_cast<const float4*>(t + 4);
+  } else if (BKX == 32) {
+    const float* t = base + (size_t)(k0 + (tid >> 6) * 8) * ld + r0 + (tid & 63) * 2;
+    float2 q[8];
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int col = n0 + wn * WCOLS + b * 32 + i;
-    const bool cok = !EDGE || col < p.N;
-    float bias = 0.f, scale = 1.f, shift = 0.f;
-    if (!plain && cok) {
-      if (p.bias) bias = p.bias[col];
-      if (p.col_scale) { scale = p.col_scale[col]; shift = p.col_shift[col]; }
-    }
-    float ssum = 0.f;
+    for (int j = 0; j < 8; ++j) q[j] = *reinterpret_cast<const float2*>(t + (size_t)j * ld);
+    s.v0 = make_float4(q[0].x, q[0].y, q[1].x, q[1].y);
+    s.v1 = make_float4(q[2].x, q[2].y, q[3].x, q[3].y);
+    s.v2 = make_float4(q[4].x, q[4].y, q[5].x, q[5].y);
+    s.v3 = make_float4(q[6].x, q[6].y, q[7].x, q[7].y);
+  } else {
+    const float* t = base + (size_t)(k0 + (tid >> 7) * 8) * ld + r0 + (tid & 127);
+    float q[8];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
-        float v = acc[a][b][r];
-        if (!plain) {
-          v += bias;
-          if (p.addend && cok && (!EDGE || row < p.M)) v += p.addend[(size_t)row * p.ldc + col];
-          if (p.col_scale) v = fmaf(v, scale, shift);
-          if (p.relu) v = fmaxf(v, 0.f);
-          if (p.resid && cok && (!EDGE || row < p.M)) v += p.resid[(size_t)row * p.ldc + col];
-        }
-        acc[a][b][r] = v;
-        if (!EDGE || row < p.M) ssum += v;
-      }
-    if (!plain && p.stat_sum) {
-      // column statistics over this wavefront's 64 rows (both lane halves)
-      ssum += __shfl_xor(ssum, 32);
-      const int g0 = m0 + wm * 64;
-      const int cnt = max(0, min(64, p.M - g0));
-      const float mean = cnt > 0 ? ssum / (float)cnt : 0.f;
-      float m2 = 0.f;
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
-          const float d = acc[a][b][r] - mean;
-          if (!EDGE || row < p.M) m2 = fmaf(d, d, m2);
-        }
-      m2 += __shfl_xor(m2, 32);
-      if (h == 0 && cok) {
-        const size_t o = (size_t)(g0 >> 6) * p.N + col;
-        p.stat_sum[o] = ssum;
-        p.stat_m2[o] = m2;
-      }
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = rbase + a * 32 + (r & 3) + 8 * (r >> 2);
-        if (cok && (!EDGE || row < p.M)) C[(size_t)row * p.ldc + col] = acc[a][b][r];
-      }
+    for (int j = 0; j < 8; ++j) q[j] = t[(size_t)j * ld];
+    s.v0 = make_float4(q[0], q[1], q[2], q[3]);
+    s.v1 = make_float4(q[4], q[5], q[6], q[7]);
   }
+}
+
+// x = x0 + x1 + x2 exactly, the same RNE split as split3 (results are bit-identical to the fragment path)
+template <int PLANE>
+__device__ __forceinline__ void split8_store(char* __restrict__ dst, const float (&f)[8]) {
+  // stage-major over the eight values: every instruction's operands were produced a whole stage
+  // (>= 4 instructions) earlier.  Written value-major, hipcc emits one serial cvt -> shift -> sub -> cvt
+  // chain per value pair and every instruction waits on its predecessor (PMC: a third of the wave's
+  // cycles in SQ_WAIT_INST_ANY).
+  bf16x8 p0, p1, p2;
+  float r1[8], r2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p0[j] = (__bf16)f[j];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r1[j] = f[j] - (float)p0[j];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p1[j] = (__bf16)r1[j];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r2[j] = r1[j] - (float)p1[j];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p2[j] = (__bf16)r2[j];
+  *reinterpret_cast<bf16x8*>(dst) = p0;
+  *reinterpret_cast<bf16x8*>(dst + PLANE) = p1;
+  *reinterpret_cast<bf16x8*>(dst + 2 * PLANE) = p2;
+}
+
+// Split + store one half (HALF = 0, 1) of a staged operand tile; BK 16 has a single half (0).
+template <bool KS, int BKX, int HALF>
+__device__ __forceinline__ void store_half_p(char* __restrict__ op, int tid, const Stage& g) {
+  using Cf = PCfg<BKX>;
+  if (!KS && BKX == 32) {
+    char* d = op + (tid & 3) * Cf::OCTS + (tid >> 2) * 16 + HALF * 64 * 16;
+    const float4 u = HALF ? g.v2 : g.v0, v = HALF ? g.v3 : g.v1;
+    const float a[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+    split8_store<Cf::PLANE>(d, a);
+  } else if (!KS) {
+    char* d = op + (tid & 1) * Cf::OCTS + (tid >> 1) * 16;
+    const float a[8] = {g.v0.x, g.v0.y, g.v0.z, g.v0.w, g.v1.x, g.v1.y, g.v1.z, g.v1.w};
+    split8_store<Cf::PLANE>(d, a);
+  } else if (BKX == 32) {
+    char* d = op + (tid >> 6) * Cf::OCTS + (tid & 63) * 32 + HALF * 16;
+    float a[8];
+    if (HALF == 0) { a[0] = g.v0.x; a[1] = g.v0.z; a[2] = g.v1.x; a[3] = g.v1.z; a[4] = g.v2.x; a[5] = g.v2.z; a[6] = g.v3.x; a[7] = g.v3.z; }
+    else           { a[0] = g.v0.y; a[1] = g.v0.w; a[2] = g.v1.y; a[3] = g.v1.w; a[4] = g.v2.y; a[5] = g.v2.w; a[6] = g.v3.y; a[7] = g.v3.w; }
+    split8_store<Cf::PLANE>(d, a);
+  } else {
+    char* d = op + (tid >> 7) * Cf::OCTS + (tid & 127) * 16;
+    const float a[8] = {g.v0.x, g.v0.y, g.v0.z, g.v0.w, g.v1.x, g.v1.y, g.v1.z, g.v1.w};
+    split8_store<Cf::PLANE>(d, a);
+  }
+}
+
+// whole tiles only (M, N % 128 == 0, every K slice % BKX == 0, 16-byte aligned rows); 4 wavefronts 2x2
+// NS = staging register sets: tile kt+2 being split plus NS-1 tiles in flight from L2/HBM.
+// What bounds this loop now (same-box A/B, tools/ab_env.py, tools/gemm_scan.py; B = 4096 shapes):
+//   * steady state 1.33-1.39 us per 32-k tile against 0.79 us of matrix-pipe time; PL_BF16 mode (EIGHT
+//     MFMAs per tile) sits at 0.76-0.97 us per tile: moving 32 KB of fp32 operands per tile and CU from L2
+//     (8.4 MB per step chip-wide, ~9-10 TB/s) is a floor of its own, and it only partly overlaps the MFMAs;
+//   * a third staging set (two tiles in flight, NS = 3) changed nothing: not latency, bandwidth;
+//   * operands delivered PRE-split by the producing kernel (bn_apply writing three bf16 planes, no split
+//     VALU left in the GEMM at all) ran SLOWER (57.8 vs 55.9 us per forward GEMM): 6 B instead of 4 B per
+//     element through the same L2 path.  Removed again.
+//   PMC (SQ_*): MFMA busy 46 % of wave cycles, WAIT_ANY 22 %, issue time of the ~5.6 non-MFMA instructions
+//   per MFMA gap not hidden (the guide's limit is <= 5 per 32x32x16 gap, hand-placed).
+template <bool A_KS, bool B_KS, int BKX, int NS>
+__device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int block_id, const int nwork,
+                                                 char* __restrict__ lds) {
+  using Cf = PCfg<BKX>;
+  constexpr int KSTEPS = BKX / 16;          // 16-deep MFMA steps per tile
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = p.N / BN;
+  const int splits = p.split_k > 1 ? p.split_k : 1;
+  const int ntiles = nwork / splits;
+  int w = block_id;
+  if ((nwork & 7) == 0) w = (w & 7) * (nwork >> 3) + (w >> 3);
+  const int slice = w / ntiles;
+  const int t = w - slice * ntiles;
+  const int m0 = (t / tiles_n) * BM;
+  const int n0 = (t % tiles_n) * BN;
+  int kbeg = 0, kend = p.K;
+  float* C = p.C;
+  if (p.split_k > 1) {
+    const int per = p.K / p.split_k;
+    kbeg = slice * per;
+    kend = kbeg + per;
+    C += (size_t)slice * p.M * p.ldc;
+  }
+  const int nk = (kend - kbeg) / BKX;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // fragment sets: BK 32: set s = 16-deep step s of the tile in flight; BK 16: set = tile parity
+  bf16x8 fa[2][2][3], fb[2][2][3];
+  const int arow = (wm * 64 + i) * 16, brow = (wn * 64 + i) * 16;
+#define PL_FRAGS_P(set, buf, s16)                                                                        \
+  do {                                                                                                   \
+    const char* qa = (buf) + (2 * (s16) + h) * Cf::OCTS + arow;                                          \
+    const char* qb = (buf) + Cf::OPP + (2 * (s16) + h) * Cf::OCTS + brow;                                \
+    _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2)                                                     \
+    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                                   \
+      fa[set][t2][pl] = *reinterpret_cast<const bf16x8*>(qa + t2 * 32 * 16 + pl * Cf::PLANE);            \
+      fb[set][t2][pl] = *reinterpret_cast<const bf16x8*>(qb + t2 * 32 * 16 + pl * Cf::PLANE);            \
+    }                                                                                                    \
+  } while (0)
+#define PL_MFP(set, aa, bb, ia, ib) \
+  acc[aa][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][aa][ia], fb[set][bb][ib], acc[aa][bb], 0, 0, 0)
+#define PL_MF6(set, aa, bb)                                                                      \
+  do {                                                                                           \
+    PL_MFP(set, aa, bb, 2, 0); PL_MFP(set, aa, bb, 1, 1); PL_MFP(set, aa, bb, 0, 2);             \
+    PL_MFP(set, aa, bb, 1, 0); PL_MFP(set, aa, bb, 0, 1); PL_MFP(set, aa, bb, 0, 0);             \
+  } while (0)
+#define PL_MFMAS_ROW(set, aa) do { PL_MF6(set, aa, 0); PL_MF6(set, aa, 1); } while (0)
+#define PL_MFMAS_P(set) do { PL_MFMAS_ROW(set, 0); PL_MFMAS_ROW(set, 1); } while (0)
+
+  char* cur = lds;                    // tile kt: being consumed
+  char* nx1 = lds + Cf::STAGE;        // tile kt+1: complete, readable
+  char* nx2 = lds + 2 * Cf::STAGE;    // tile kt+2: being written during step kt
+  static_assert(NS == 2 || (NS == 3 && BKX == 32), "three staging sets only with the BK 32 loop");
+  using SA = Stage;
+  SA ra0, ra1, ra2;                   // staging register sets: tile t lives in set t % NS
+  Stage rb0, rb1, rb2;
+  auto load_a = [&](SA& d, const int k0) { load_tile_p<A_KS, BKX>(d, p.A, p.lda, m0, k0, tid); };
+  auto store_a = [&](char* op, auto half, const SA& g) {
+    store_half_p<A_KS, BKX, decltype(half)::value>(op, tid, g);
+  };
+  using H0 = std::integral_constant<int, 0>;
+  using H1 = std::integral_constant<int, 1>;
+
+  // One pipeline step.  P = parity of kt (selects the fragment set for BK 16); sa/sb: raw tile kt+2 to
+  // split now; la/lb: receive tile kt+3.  STEADY: every flag known true at compile time.
+  auto step = [&](const int kt, auto par, auto steady, const SA& sa, const Stage& sb, SA& la, Stage& lb) {
+    constexpr int P = decltype(par)::value;
+    constexpr bool STEADY = decltype(steady)::value;
+    const bool do_load = STEADY || kt + 1 + NS < nk;
+    const bool do_split = STEADY || kt + 2 < nk;
+    const bool has_next = STEADY || kt + 1 < nk;
+    if (do_load) {
+      const int k0 = kbeg + (kt + 1 + NS) * BKX;
+      load_a(la, k0);
+      load_tile_p<B_KS, BKX>(lb, p.B, p.ldb, n0, k0, tid);
+    }
+    if (KSTEPS == 2) {
+      PL_FRAGS_P(1, cur, 1);
+      if (do_split) { store_a(nx2, H0{}, sa); store_half_p<B_KS, BKX, 0>(nx2 + Cf::OPP, tid, sb); }
+      PL_MFMAS_P(0);
+      if (has_next) PL_FRAGS_P(0, nx1, 0);
+      if (do_split) { store_a(nx2, H1{}, sa); store_half_p<B_KS, BKX, 1>(nx2 + Cf::OPP, tid, sb); }
+      PL_MFMAS_P(1);
+    } else {
+      if (has_next) PL_FRAGS_P(1 - P, nx1, 0);
+      if (do_split) store_a(nx2, H0{}, sa);
+      PL_MFMAS_ROW(P, 0);
+      if (do_split) store_half_p<B_KS, BKX, 0>(nx2 + Cf::OPP, tid, sb);
+      PL_MFMAS_ROW(P, 1);
+    }
+    if (STEADY) {
+      // Schedule of the step (one basic block): ONE MFMA, then at most four of the split's VALU
+      // instructions in its shadow (more than ~4 per MFMA stop being free, tools/ubench), the global
+      // loads up front, the fragment reads and the plane writes threaded between.
+      constexpr int NG = (A_KS ? 8 : BKX / 8) + (B_KS ? 8 : BKX / 8);      // global loads per step
+#pragma unroll
+      for (int q = 0; q < 24 * KSTEPS; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+        if (q < NG) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    char* o = cur; cur = nx1; nx1 = nx2; nx2 = o;
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using T = std::true_type;
+  using F = std::false_type;
+  if (nk > 0) {
+    // prologue: tiles 0 and 1 into stages 0 and 1, tiles 2 .. NS into their register sets
+    load_a(ra0, kbeg);
+    load_tile_p<B_KS, BKX>(rb0, p.B, p.ldb, n0, kbeg, tid);
+    if (nk > 1) {
+      load_a(ra1, kbeg + BKX);
+      load_tile_p<B_KS, BKX>(rb1, p.B, p.ldb, n0, kbeg + BKX, tid);
+    }
+    if (NS == 3 && nk > 2) {
+      load_a(ra2, kbeg + 2 * BKX);
+      load_tile_p<B_KS, BKX>(rb2, p.B, p.ldb, n0, kbeg + 2 * BKX, tid);
+    }
+    store_a(cur, H0{}, ra0); store_half_p<B_KS, BKX, 0>(cur + Cf::OPP, tid, rb0);
+    if (KSTEPS == 2) { store_a(cur, H1{}, ra0); store_half_p<B_KS, BKX, 1>(cur + Cf::OPP, tid, rb0); }
+    if (nk > NS) {       // NS 2: tile 2 -> set 0;  NS 3: tile 3 -> set 0
+      load_a(ra0, kbeg + NS * BKX);
+      load_tile_p<B_KS, BKX>(rb0, p.B, p.ldb, n0, kbeg + NS * BKX, tid);
+    }
+    if (nk > 1) {
+      store_a(nx1, H0{}, ra1); store_half_p<B_KS, BKX, 0>(nx1 + Cf::OPP, tid, rb1);
+      if (KSTEPS == 2) { store_a(nx1, H1{}, ra1); store_half_p<B_KS, BKX, 1>(nx1 + Cf::OPP, tid, rb1); }
+    }
+    __syncthreads();
+    PL_FRAGS_P(0, cur, 0);
+    int kt = 0;
+    if (NS == 2) {
+      // step kt splits tile kt+2 (set kt % 2) and loads tile kt+3 into the other set
+      for (; kt + 4 < nk; kt += 2) {
+        step(kt, P0{}, T{}, ra0, rb0, ra1, rb1);
+        step(kt + 1, P1{}, T{}, ra1, rb1, ra0, rb0);
+      }
+      for (; kt < nk; kt += 2) {
+        step(kt, P0{}, F{}, ra0, rb0, ra1, rb1);
+        if (kt + 1 < nk) step(kt + 1, P1{}, F{}, ra1, rb1, ra0, rb0);
+      }
+    } else {
+      // step kt splits tile kt+2 (set (kt+2) % 3) and loads tile kt+4 into set (kt+1) % 3
+      for (; kt + 6 < nk; kt += 3) {
+        step(kt, P0{}, T{}, ra2, rb2, ra1, rb1);
+        step(kt + 1, P0{}, T{}, ra0, rb0, ra2, rb2);
+        step(kt + 2, P0{}, T{}, ra1, rb1, ra0, rb0);
+      }
+      for (; kt < nk; kt += 3) {
+        step(kt, P0{}, F{}, ra2, rb2, ra1, rb1);
+        if (kt + 1 < nk) step(kt + 1, P0{}, F{}, ra0, rb0, ra2, rb2);
+        if (kt + 2 < nk) step(kt + 2, P0{}, F{}, ra1, rb1, ra0, rb0);
+      }
+    }
+  }
+#undef PL_FRAGS_P
+#undef PL_MFP
+#undef PL_MF6
+#undef PL_MFMAS_ROW
+#undef PL_MFMAS_P
+  gemm_epilogue<false, 2>(p, C, acc, m0, n0, wm, wn, i, h);
+}
+
+template <bool A_KS, bool B_KS>
+__global__ __launch_bounds__(256) void gemm_x6_planes_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[PCfg<32>::LDS];
+  gemm_body_planes<A_KS, B_KS, 32, 2>(p, blockIdx.x, gridDim.x, lds);   // NS = 3 measured no faster
+}
+
+// backward pair in one launch (see gemm_f32_dual_kernel): BK 16, two workgroups per CU
+__global__ __launch_bounds__(256, 2) void gemm_x6_planes_dual_kernel(GemmArgs p0, GemmArgs p1, int n0) {
+  __shared__ __attribute__((aligned(16))) char lds[PCfg<16>::LDS];
+  if ((int)blockIdx.x < n0)
+    gemm_body_planes<false, true, 16, 2>(p0, blockIdx.x, n0, lds);
+  else
+    gemm_body_planes<true, true, 16, 2>(p1, blockIdx.x - n0, gridDim.x - n0, lds);
 }
 
 template <bool A_KS, bool B_KS, bool EDGE, int AR = 0, int NW = 4>
@@ -593,6 +926,21 @@ static bool whole_tiles(const GemmArgs& a) {
          ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0);
 }
 
+// the planes pipeline additionally wants even row strides for its float2 loads and whole K slices
+static bool planes_ok(const GemmArgs& a) {
+  const int splits = a.split_k > 1 ? a.split_k : 1;
+  return a.K % (BK * splits) == 0 && (a.lda % 4 == 0) && (a.ldb % 4 == 0);
+}
+
+// PL_BF16X6 main loop of the single-GEMM launches: planes pipeline unless POSELIFT_X6_FRAG=1
+static bool x6_planes_default() {
+  static const bool on = [] {
+    const char* e = getenv("POSELIFT_X6_FRAG");
+    return !(e && e[0] == '1');
+  }();
+  return on;
+}
+
 static int grid_of(const GemmArgs& a) {
   return ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * (a.split_k > 1 ? a.split_k : 1);
 }
@@ -608,7 +956,9 @@ int launch_gemm_f32_pair(const GemmArgs& nn, const GemmArgs& tn, hipStream_t s) 
   ProfRec* prof = prof_begin(both, s);
   if (prof) prof->flops += 2.0 * tn.M * tn.N * tn.K;
   if (nn.arith != tn.arith) PL_FAIL(PL_EINVAL, "gemm pair: mixed arithmetic");
-  if (nn.arith == 2) hipLaunchKernelGGL((gemm_f32_dual_kernel<2, 4>), dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
+  if (nn.arith == 2 && x6_planes_default() && planes_ok(nn) && planes_ok(tn))
+    hipLaunchKernelGGL(gemm_x6_planes_dual_kernel, dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
+  else if (nn.arith == 2) hipLaunchKernelGGL((gemm_f32_dual_kernel<2, 4>), dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
   else if (nn.arith == 1) hipLaunchKernelGGL((gemm_f32_dual_kernel<1, 4>), dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
   else hipLaunchKernelGGL((gemm_f32_dual_kernel<0, 4>), dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
   if (prof) (void)hipEventRecord(prof->e1, s);
@@ -636,7 +986,9 @@ int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s) {
 #endif
 #define PL_GEMM_LAUNCH(AKS, BKS)                                                                          \
   do {                                                                                                    \
-    if (whole && a.arith == 2) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false, 2>), grid, block, lds_bytes, s, a); \
+    if (whole && planes_ok(a) && (a.arith == 5 || (a.arith == 2 && x6_planes_default())))                 \
+      hipLaunchKernelGGL((gemm_x6_planes_kernel<AKS, BKS>), grid, block, lds_bytes, s, a);                 \
+    else if (whole && (a.arith == 2 || a.arith == 5 || a.arith == 6)) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false, 2>), grid, block, lds_bytes, s, a); \
     PL_ABLATE_LAUNCH(AKS, BKS)                                                                            \
     else if (whole && a.arith == 1) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false, 1>), grid, block, lds_bytes, s, a); \
     else if (whole) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false>), grid, block, lds_bytes, s, a);      \

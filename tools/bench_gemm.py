@@ -17,6 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--B", type=int, default=4096)
+    ap.add_argument("--arith", type=int, default=0, help="0 fp32, 1 bf16, 2 bf16x6, 5 bf16x6 planes, 6 bf16x6 fragment split")
     a = ap.parse_args()
     L, dev = pkg.lib(), "cuda:0"
     B, H = a.B, 1024
@@ -30,8 +31,8 @@ def main():
         slabs = torch.empty(sk, M, N, device=dev) if sk > 1 else None
 
         def run():
-            rc = L.pl_gemm_f32(layout, A.data_ptr(), Bm.data_ptr(), C.data_ptr(), M, N, K, None, sk,
-                               slabs.data_ptr() if sk > 1 else None, s)
+            rc = L.pl_gemm_arith(layout, a.arith, A.data_ptr(), Bm.data_ptr(), C.data_ptr(), M, N, K, None, sk,
+                                 slabs.data_ptr() if sk > 1 else None, s)
             assert rc == 0, L.pl_last_error()
         for _ in range(5):
             run()
