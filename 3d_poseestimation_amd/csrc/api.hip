@@ -452,6 +452,9 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
     if (l > 0) {
       // da_in = dz W and dW = dz^T a_in share dz and are independent: ONE launch.  A residual
       // block's first Linear also receives the skip gradient (in GA, added in the epilogue).
+      // (Tried: dW on a side stream so that the next layer's BatchNorm-backward kernels overlap it --
+      //  -2 % per step only: two single-GEMM workgroups do not fit one CU together, so dX and dW
+      //  time-slice the CUs and the dual launch's co-residency is lost.  Same-box A/B, tools/ab_env.py.)
       GemmArgs g = {};
       g.A = DZ; g.B = ly.W; g.M = Bi; g.N = H; g.K = H; g.lda = H; g.ldb = H; g.ldc = H; g.split_k = 1;
       if (l % 2 == 1) { g.C = GA; g.addend = GA; } else { g.C = GB; }

@@ -19,8 +19,10 @@ for r in range(rounds):
                              text=True, timeout=600)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)
-        res[name].append((d["ms_per_step"], d["roofline"]["avg_launch_us"], d["roofline_forward_gemm"]["avg_launch_us"]))
-        print(f"round {r} {name:12s} ms/step {d['ms_per_step']:.4f}  pair {d['roofline']['avg_launch_us']:.1f} us  "
-              f"fwd {d['roofline_forward_gemm']['avg_launch_us']:.1f} us  mpjpe {d['mpjpe_mm_eval_fwd_vs_oracle']}", flush=True)
+        pair = (d.get("roofline") or {}).get("avg_launch_us", float("nan"))
+        fwd = (d.get("roofline_forward_gemm") or {}).get("avg_launch_us", float("nan"))
+        res[name].append((d["ms_per_step"], pair, fwd))
+        print(f"round {r} {name:12s} ms/step {d['ms_per_step']:.4f}  pair {pair:.1f} us  "
+              f"fwd {fwd:.1f} us  mpjpe {d['mpjpe_mm_eval_fwd_vs_oracle']}", flush=True)
 for name, v in res.items():
     print(f"{name:12s} mean ms/step {sum(x[0] for x in v) / len(v):.4f}  pair {sum(x[1] for x in v) / len(v):.1f}  fwd {sum(x[2] for x in v) / len(v):.1f}")
