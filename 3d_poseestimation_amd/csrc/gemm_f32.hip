@@ -542,15 +542,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int block_id,
 // LDS image of one operand tile (128 rows x BK k): 3 planes x BK/8 k-octets x [128 rows][8 bf16 = 16 B].
 // A lane of the 32x32x16 MFMA wants row = lane&31, k = 8*(lane>>5) .. +7 of a 16-deep step: one
 // ds_read_b128 from octet 2*step + (lane>>5), 32 rows contiguous -> conflict-free without padding.  The
-// octet stride carries a bank rotation (64 B for four octets, 128 B for two) so that the octets one
-// staging wave writes together land on disjoint bank groups.
-//   BK = 32: 3 stages x 50,688 B = 152,064 B, one workgroup per CU          (single-GEMM launches)
-//   BK = 16: 3 stages x 25,728 B =  77,184 B, two workgroups per CU         (the backward dual launch)
+// octet stride carries a bank rotation (32 B for four octets, 64 B for two): ds_write_b128 is banked
+// modulo 32 dwords over groups of 8 consecutive lanes, and the k-contiguous staging writes of such a
+// group (4 octets x 2 rows, or 2 octets x 4 rows) then cover the 32 banks exactly once (PMC with the
+// rotation a multiple of 128 B: SQ_LDS_BANK_CONFLICT = a third of SQ_LDS_IDX_ACTIVE).
+//   BK = 32: 3 stages x 49,920 B = 149,760 B, one workgroup per CU          (single-GEMM launches)
+//   BK = 16: 3 stages x 25,344 B =  76,032 B, two workgroups per CU         (the backward dual launch)
 // =====================================================================================
 template <int BKX>
 struct PCfg {
   static constexpr int OCT = BKX / 8;                               // k-octets per tile
-  static constexpr int OCTS = 2048 + (OCT == 4 ? 64 : 128);          // octet stride, bytes
+  static constexpr int OCTS = 2048 + (OCT == 4 ? 32 : 64);           // octet stride, bytes (bank rotation)
   static constexpr int PLANE = OCT * OCTS;
   static constexpr int OPP = 3 * PLANE;                             // one operand tile
   static constexpr int STAGE = 2 * OPP;

@@ -105,42 +105,72 @@ __global__ __launch_bounds__(NTHR) void skinny_wide_out_kernel(
 }
 
 // part[chunk][k][c] = sum_{r in chunk} X[r][k] * D[r][c]     X: [B][K] narrow, D: [B][H] wide
-// (dW0^T = x^T dz0 and dW5 = dy^T h).  MFMA rows = k (two 32-row tiles, zero beyond K), columns =
-// a 32-wide strip of D, contraction over the chunk's 64 rows: both operands are read in 128-byte
-// row segments.
+// (dW0^T = x^T dz0 and dW5 = dy^T h).  MFMA rows = k (two 32-row tiles; rows >= K compute garbage that
+// is never stored), columns = a 32-wide strip of D, contraction over 64 rows per wavefront: both
+// operands are read in 128-byte row segments.  The workgroup's four wavefronts take four consecutive
+// 64-row groups of the SAME strip and add their accumulators through LDS in a fixed order, so a
+// chunk is 256 rows: a quarter of the partial-sum traffic of one partial per wavefront (it was as
+// large as the read of D itself), and the combine kernel walks 16 partials instead of 64 at B = 4096.
+constexpr int IN_CHUNK = 4 * RG;
+
 template <int K>
 __global__ __launch_bounds__(NTHR) void skinny_wide_in_kernel(const float* __restrict__ X,
                                                               const float* __restrict__ D, int B, int H,
                                                               float* __restrict__ part) {
+  __shared__ float red[3][32 * 64];          // accumulators of waves 1..3
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
-  const int strips4 = H / 128;
-  const int ch = blockIdx.x / strips4;
-  const int c = ((blockIdx.x % strips4) * 4 + wave) * 32 + j;
-  const int r_base = ch * RG;
+  const int strips = H / 32;
+  const int ch = blockIdx.x / strips;
+  const int c = (blockIdx.x % strips) * 32 + j;
+  const int r_base = ch * IN_CHUNK + wave * RG;
   f32x16 acc[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  const bool k1ok = 32 + j < K;              // second k tile: rows 32..63 of the output
+  const int k1 = min(32 + j, K - 1);         // second k tile: clamp instead of masking (rows >= K are dropped)
+  if (r_base + RG <= B) {                    // whole group: no guards, loads run ahead of the MFMAs
+    const float* __restrict__ dp = D + (size_t)(r_base + h) * H + c;
+    const float* __restrict__ xp = X + (size_t)(r_base + h) * K;
 #pragma unroll 16
-  for (int s = 0; s < RG / 2; ++s) {
-    const int r = r_base + 2 * s + h;
-    const bool ok = r < B;
-    const float d = ok ? D[(size_t)r * H + c] : 0.f;
-    const float a0 = ok ? X[(size_t)r * K + j] : 0.f;
-    const float a1 = (ok && k1ok) ? X[(size_t)r * K + 32 + j] : 0.f;
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, d, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, d, acc[1], 0, 0, 0);
-  }
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int k = t * 32 + acc_row(r, h);
-      if (k < K) part[((size_t)ch * K + k) * H + c] = acc[t][r];
+    for (int s = 0; s < RG / 2; ++s) {
+      const float d = dp[(size_t)2 * s * H];
+      const float a0 = xp[2 * s * K + j];
+      const float a1 = xp[2 * s * K + k1];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, d, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, d, acc[1], 0, 0, 0);
     }
+  } else {
+#pragma unroll 4
+    for (int s = 0; s < RG / 2; ++s) {
+      const int r = r_base + 2 * s + h;
+      const bool ok = r < B;
+      const float d = ok ? D[(size_t)r * H + c] : 0.f;
+      const float a0 = ok ? X[(size_t)r * K + j] : 0.f;
+      const float a1 = ok ? X[(size_t)r * K + k1] : 0.f;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, d, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, d, acc[1], 0, 0, 0);
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[wave - 1][(t * 16 + r) * 64 + lane] = acc[t][r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = (t * 16 + r) * 64 + lane;
+        const float v = ((acc[t][r] + red[0][q]) + red[1][q]) + red[2][q];
+        const int k = t * 32 + acc_row(r, h);
+        if (k < K) part[((size_t)ch * K + k) * H + c] = v;
+      }
+  }
 }
 
 // out = sum over chunks of part[chunk][i], i = k*H + c; TRANS writes out[c*K + k] (dW0 is [H][K]).
@@ -234,7 +264,8 @@ __global__ __launch_bounds__(NTHR) void skinny_narrow_out_reduce_kernel(const fl
 }  // namespace
 
 bool skinny_supported(int K, int H) { return (K == 34 || K == 51) && H % 128 == 0; }
-int skinny_chunks(int B) { return (B + RG - 1) / RG; }           // row tasks
+int skinny_chunks(int B) { return (B + RG - 1) / RG; }           // row tasks (wide_out; upper bound for wide_in)
+static int skinny_in_chunks(int B) { return (B + IN_CHUNK - 1) / IN_CHUNK; }
 int skinny_stat_groups(int B) { return (B + 63) / 64; }
 
 // forward of the input layer (+ BN statistics)  /  g = dy W5 (transposed weights, no bias)
@@ -257,8 +288,8 @@ int launch_skinny_wide_out(const float* X, const float* W, const float* bias, fl
 int launch_skinny_wide_in(const float* X, const float* D, float* out, int B, int K, int H,
                           bool out_transposed, float* part, hipStream_t s) {
   if (!skinny_supported(K, H)) PL_FAIL(PL_ESHAPE, "skinny_wide_in: K=%d H=%d not specialised", K, H);
-  const int nc = skinny_chunks(B);
-  dim3 grid(nc * (H / 128)), block(NTHR);
+  const int nc = skinny_in_chunks(B);
+  dim3 grid(nc * (H / 32)), block(NTHR);
   if (K == 34) hipLaunchKernelGGL((skinny_wide_in_kernel<34>), grid, block, 0, s, X, D, B, H, part);
   else hipLaunchKernelGGL((skinny_wide_in_kernel<51>), grid, block, 0, s, X, D, B, H, part);
   PL_CHECK_LAUNCH("skinny_wide_in");
