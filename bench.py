@@ -136,9 +136,11 @@ def read_rooflines(pkg, L, dtype, one, traffic):
         return r
     # dominant kernel by time: the backward dual launch (dX = dz W and dW = dz^T a of one layer,
     # 2 x 8.59 GFLOP); the forward single-GEMM kernel is reported beside it
-    dual = read(1.9 * one, 2.1 * one, "gemm_f32_dual_kernel<%s> (4096x1024x1024 dX + 1024x1024x4096 dW in one "
-                "launch, 4 launches/step)" % dtype, "gemm_f32_dual_hbm_bytes_per_launch")
-    single = read(0.99 * one, 1.01 * one, "gemm_f32_kernel<NT,%s> (4096x1024x1024 forward, 4 launches/step)" % dtype,
+    kd = "gemm_x6_planes_dual_kernel" if dtype == "bf16x6" else "gemm_f32_dual_kernel<%s>" % dtype
+    ks = "gemm_x6_planes_kernel<NT>" if dtype == "bf16x6" else "gemm_f32_kernel<NT,%s>" % dtype
+    dual = read(1.9 * one, 2.1 * one, kd + " (4096x1024x1024 dX + 1024x1024x4096 dW in one launch, 4 launches/step)",
+                "gemm_f32_dual_hbm_bytes_per_launch")
+    single = read(0.99 * one, 1.01 * one, ks + " (4096x1024x1024 forward, 4 launches/step)",
                   "gemm_f32_hbm_bytes_per_launch")
     return dual, single
 
