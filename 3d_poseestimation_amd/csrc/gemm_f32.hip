@@ -649,18 +649,18 @@ __device__ __forceinline__ void store_half_p(char* __restrict__ op, int tid, con
 }
 
 // whole tiles only (M, N % 128 == 0, every K slice % BKX == 0, 16-byte aligned rows); 4 wavefronts 2x2
-// NS = staging register sets: tile kt+2 being split plus NS-1 tiles in flight from L2/HBM.
+// Two staging register sets: tile kt+2 being split, tile kt+3 in flight from L2/HBM.
 // What bounds this loop now (same-box A/B, tools/ab_env.py, tools/gemm_scan.py; B = 4096 shapes):
 //   * steady state 1.33-1.39 us per 32-k tile against 0.79 us of matrix-pipe time; PL_BF16 mode (EIGHT
 //     MFMAs per tile) sits at 0.76-0.97 us per tile: moving 32 KB of fp32 operands per tile and CU from L2
 //     (8.4 MB per step chip-wide, ~9-10 TB/s) is a floor of its own, and it only partly overlaps the MFMAs;
-//   * a third staging set (two tiles in flight, NS = 3) changed nothing: not latency, bandwidth;
+//   * a third staging register set (two tiles in flight) changed nothing: not latency, bandwidth;
 //   * operands delivered PRE-split by the producing kernel (bn_apply writing three bf16 planes, no split
 //     VALU left in the GEMM at all) ran SLOWER (57.8 vs 55.9 us per forward GEMM): 6 B instead of 4 B per
 //     element through the same L2 path.  Removed again.
 //   PMC (SQ_*): MFMA busy 46 % of wave cycles, WAIT_ANY 22 %, issue time of the ~5.6 non-MFMA instructions
 //   per MFMA gap not hidden (the guide's limit is <= 5 per 32x32x16 gap, hand-placed).
-template <bool A_KS, bool B_KS, int BKX, int NS>
+template <bool A_KS, bool B_KS, int BKX>
 __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int block_id, const int nwork,
                                                  char* __restrict__ lds) {
   using Cf = PCfg<BKX>;
@@ -722,10 +722,9 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
   char* cur = lds;                    // tile kt: being consumed
   char* nx1 = lds + Cf::STAGE;        // tile kt+1: complete, readable
   char* nx2 = lds + 2 * Cf::STAGE;    // tile kt+2: being written during step kt
-  static_assert(NS == 2 || (NS == 3 && BKX == 32), "three staging sets only with the BK 32 loop");
   using SA = Stage;
-  SA ra0, ra1, ra2;                   // staging register sets: tile t lives in set t % NS
-  Stage rb0, rb1, rb2;
+  SA ra0, ra1;                        // staging register sets: tile t lives in set t % 2
+  Stage rb0, rb1;
   auto load_a = [&](SA& d, const int k0) { load_tile_p<A_KS, BKX>(d, p.A, p.lda, m0, k0, tid); };
   auto store_a = [&](char* op, auto half, const SA& g) {
     store_half_p<A_KS, BKX, decltype(half)::value>(op, tid, g);
@@ -738,11 +737,11 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
   auto step = [&](const int kt, auto par, auto steady, const SA& sa, const Stage& sb, SA& la, Stage& lb) {
     constexpr int P = decltype(par)::value;
     constexpr bool STEADY = decltype(steady)::value;
-    const bool do_load = STEADY || kt + 1 + NS < nk;
+    const bool do_load = STEADY || kt + 3 < nk;
     const bool do_split = STEADY || kt + 2 < nk;
     const bool has_next = STEADY || kt + 1 < nk;
     if (do_load) {
-      const int k0 = kbeg + (kt + 1 + NS) * BKX;
+      const int k0 = kbeg + (kt + 3) * BKX;
       load_a(la, k0);
       load_tile_p<B_KS, BKX>(lb, p.B, p.ldb, n0, k0, tid);
     }
@@ -782,22 +781,18 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
   using T = std::true_type;
   using F = std::false_type;
   if (nk > 0) {
-    // prologue: tiles 0 and 1 into stages 0 and 1, tiles 2 .. NS into their register sets
+    // prologue: tiles 0 and 1 into stages 0 and 1, tile 2 into register set 0
     load_a(ra0, kbeg);
     load_tile_p<B_KS, BKX>(rb0, p.B, p.ldb, n0, kbeg, tid);
     if (nk > 1) {
       load_a(ra1, kbeg + BKX);
       load_tile_p<B_KS, BKX>(rb1, p.B, p.ldb, n0, kbeg + BKX, tid);
     }
-    if (NS == 3 && nk > 2) {
-      load_a(ra2, kbeg + 2 * BKX);
-      load_tile_p<B_KS, BKX>(rb2, p.B, p.ldb, n0, kbeg + 2 * BKX, tid);
-    }
     store_a(cur, H0{}, ra0); store_half_p<B_KS, BKX, 0>(cur + Cf::OPP, tid, rb0);
     if (KSTEPS == 2) { store_a(cur, H1{}, ra0); store_half_p<B_KS, BKX, 1>(cur + Cf::OPP, tid, rb0); }
-    if (nk > NS) {       // NS 2: tile 2 -> set 0;  NS 3: tile 3 -> set 0
-      load_a(ra0, kbeg + NS * BKX);
-      load_tile_p<B_KS, BKX>(rb0, p.B, p.ldb, n0, kbeg + NS * BKX, tid);
+    if (nk > 2) {
+      load_a(ra0, kbeg + 2 * BKX);
+      load_tile_p<B_KS, BKX>(rb0, p.B, p.ldb, n0, kbeg + 2 * BKX, tid);
     }
     if (nk > 1) {
       store_a(nx1, H0{}, ra1); store_half_p<B_KS, BKX, 0>(nx1 + Cf::OPP, tid, rb1);
@@ -806,28 +801,14 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
     __syncthreads();
     PL_FRAGS_P(0, cur, 0);
     int kt = 0;
-    if (NS == 2) {
-      // step kt splits tile kt+2 (set kt % 2) and loads tile kt+3 into the other set
-      for (; kt + 4 < nk; kt += 2) {
-        step(kt, P0{}, T{}, ra0, rb0, ra1, rb1);
-        step(kt + 1, P1{}, T{}, ra1, rb1, ra0, rb0);
-      }
-      for (; kt < nk; kt += 2) {
-        step(kt, P0{}, F{}, ra0, rb0, ra1, rb1);
-        if (kt + 1 < nk) step(kt + 1, P1{}, F{}, ra1, rb1, ra0, rb0);
-      }
-    } else {
-      // step kt splits tile kt+2 (set (kt+2) % 3) and loads tile kt+4 into set (kt+1) % 3
-      for (; kt + 6 < nk; kt += 3) {
-        step(kt, P0{}, T{}, ra2, rb2, ra1, rb1);
-        step(kt + 1, P0{}, T{}, ra0, rb0, ra2, rb2);
-        step(kt + 2, P0{}, T{}, ra1, rb1, ra0, rb0);
-      }
-      for (; kt < nk; kt += 3) {
-        step(kt, P0{}, F{}, ra2, rb2, ra1, rb1);
-        if (kt + 1 < nk) step(kt + 1, P0{}, F{}, ra0, rb0, ra2, rb2);
-        if (kt + 2 < nk) step(kt + 2, P0{}, F{}, ra1, rb1, ra0, rb0);
-      }
+    // step kt splits tile kt+2 (set kt % 2) and loads tile kt+3 into the other set
+    for (; kt + 4 < nk; kt += 2) {
+      step(kt, P0{}, T{}, ra0, rb0, ra1, rb1);
+      step(kt + 1, P1{}, T{}, ra1, rb1, ra0, rb0);
+    }
+    for (; kt < nk; kt += 2) {
+      step(kt, P0{}, F{}, ra0, rb0, ra1, rb1);
+      if (kt + 1 < nk) step(kt + 1, P1{}, F{}, ra1, rb1, ra0, rb0);
     }
   }
 #undef PL_FRAGS_P
@@ -841,16 +822,16 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
 template <bool A_KS, bool B_KS>
 __global__ __launch_bounds__(256) void gemm_x6_planes_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[PCfg<32>::LDS];
-  gemm_body_planes<A_KS, B_KS, 32, 2>(p, blockIdx.x, gridDim.x, lds);   // NS = 3 measured no faster
+  gemm_body_planes<A_KS, B_KS, 32>(p, blockIdx.x, gridDim.x, lds);
 }
 
 // backward pair in one launch (see gemm_f32_dual_kernel): BK 16, two workgroups per CU
 __global__ __launch_bounds__(256, 2) void gemm_x6_planes_dual_kernel(GemmArgs p0, GemmArgs p1, int n0) {
   __shared__ __attribute__((aligned(16))) char lds[PCfg<16>::LDS];
   if ((int)blockIdx.x < n0)
-    gemm_body_planes<false, true, 16, 2>(p0, blockIdx.x, n0, lds);
+    gemm_body_planes<false, true, 16>(p0, blockIdx.x, n0, lds);
   else
-    gemm_body_planes<true, true, 16, 2>(p1, blockIdx.x - n0, gridDim.x - n0, lds);
+    gemm_body_planes<true, true, 16>(p1, blockIdx.x - n0, gridDim.x - n0, lds);
 }
 
 template <bool A_KS, bool B_KS, bool EDGE, int AR = 0, int NW = 4>

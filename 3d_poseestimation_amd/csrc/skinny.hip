@@ -130,16 +130,28 @@ __global__ __launch_bounds__(NTHR) void skinny_wide_in_kernel(const float* __res
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   const int k1 = min(32 + j, K - 1);         // second k tile: clamp instead of masking (rows >= K are dropped)
-  if (r_base + RG <= B) {                    // whole group: no guards, loads run ahead of the MFMAs
+  if (r_base + RG <= B) {                    // whole group: no guards
+    // Loads in explicit batches of 16 row pairs (48 per wave in flight), pinned above their MFMAs: left to
+    // itself hipcc keeps ONE iteration's three loads in flight and waits for them before every MFMA
+    // pair -- 32 dependent HBM round trips per wave, 17 us for a 16.8 MB pass.
     const float* __restrict__ dp = D + (size_t)(r_base + h) * H + c;
     const float* __restrict__ xp = X + (size_t)(r_base + h) * K;
-#pragma unroll 16
-    for (int s = 0; s < RG / 2; ++s) {
-      const float d = dp[(size_t)2 * s * H];
-      const float a0 = xp[2 * s * K + j];
-      const float a1 = xp[2 * s * K + k1];
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, d, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, d, acc[1], 0, 0, 0);
+#pragma unroll
+    for (int b0 = 0; b0 < RG / 2; b0 += 16) {
+      float d[16], a0[16], a1[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        d[s] = dp[(size_t)2 * (b0 + s) * H];
+        a0[s] = xp[2 * (b0 + s) * K + j];
+        a1[s] = xp[2 * (b0 + s) * K + k1];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], d[s], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], d[s], acc[1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   } else {
 #pragma unroll 4
@@ -217,27 +229,46 @@ __global__ __launch_bounds__(NTHR) void skinny_narrow_out_kernel(const float* __
   const float* __restrict__ ap = hmat + (size_t)row * H + sp * kper + 4 * h;
   const float* __restrict__ b0p = W + (size_t)min(j, N - 1) * H + sp * kper + 4 * h;
   const float* __restrict__ b1p = W + (size_t)min(32 + j, N - 1) * H + sp * kper + 4 * h;
-  const bool ok0 = j < N, ok1 = 32 + j < N;
+  // columns >= N read a clamped (valid) row of W and compute values the combine kernel never reads
   f32x16 acc[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll 4
-  for (int k = 0; k < kper; k += 8) {
-    const float4 a = *reinterpret_cast<const float4*>(ap + k);
-    const float4 b0 = ok0 ? *reinterpret_cast<const float4*>(b0p + k) : zero;
-    const float4 b1 = ok1 ? *reinterpret_cast<const float4*>(b1p + k) : zero;
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0.x, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b1.x, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b0.y, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1.y, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b0.z, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b1.z, acc[1], 0, 0, 0);
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b0.w, acc[0], 0, 0, 0);
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b1.w, acc[1], 0, 0, 0);
+  // loads in explicit batches of 8 k-steps (24 x 16 B per lane in flight), pinned above their MFMAs:
+  // with guarded one-step-ahead loads every iteration was a dependent memory round trip (19.6 us)
+#define PL_NO_MFMA8(A, B0, B1)                                                          \
+  do {                                                                                  \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).x, (B0).x, acc[0], 0, 0, 0);      \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).x, (B1).x, acc[1], 0, 0, 0);      \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).y, (B0).y, acc[0], 0, 0, 0);      \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).y, (B1).y, acc[1], 0, 0, 0);      \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).z, (B0).z, acc[0], 0, 0, 0);      \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).z, (B1).z, acc[1], 0, 0, 0);      \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).w, (B0).w, acc[0], 0, 0, 0);      \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32((A).w, (B1).w, acc[1], 0, 0, 0);      \
+  } while (0)
+  int kb = 0;
+  for (; kb + 64 <= kper; kb += 64) {
+    float4 a[8], b0[8], b1[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      a[q] = *reinterpret_cast<const float4*>(ap + kb + 8 * q);
+      b0[q] = *reinterpret_cast<const float4*>(b0p + kb + 8 * q);
+      b1[q] = *reinterpret_cast<const float4*>(b1p + kb + 8 * q);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) PL_NO_MFMA8(a[q], b0[q], b1[q]);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  for (; kb < kper; kb += 8) {               // k slices that are not a multiple of 64 (generic hidden sizes)
+    const float4 a = *reinterpret_cast<const float4*>(ap + kb);
+    const float4 b0 = *reinterpret_cast<const float4*>(b0p + kb);
+    const float4 b1 = *reinterpret_cast<const float4*>(b1p + kb);
+    PL_NO_MFMA8(a, b0, b1);
+  }
+#undef PL_NO_MFMA8
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
