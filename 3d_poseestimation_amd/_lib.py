@@ -9,7 +9,8 @@ import os
 import torch  # noqa: F401  (loads torch's bundled HIP runtime first so the library binds to it)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libposelift.so")
+# POSELIFT_LIB: another build of the same library (same-box A/B of two builds, tools/ab_env.py)
+LIB_PATH = os.environ.get("POSELIFT_LIB") or os.path.join(_HERE, "csrc", "libposelift.so")
 
 PL_F32, PL_BF16, PL_BF16X6 = 0, 1, 2
 

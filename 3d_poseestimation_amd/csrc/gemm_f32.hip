@@ -194,6 +194,9 @@ __device__ __forceinline__ void split3(const float (&f)[8], bf16x8 (&p)[3]) {
 }
 
 // ---- epilogue (shared by every main-loop variant) ------------------------------------------
+// (Tried: transposing each wave's 64x64 block through LDS and storing 16 x dwordx4 instead of 64 x dword
+//  per lane -- same-box A/B: 54.2 vs 53.3 us per forward GEMM, i.e. the extra barrier and LDS round trip
+//  cost more than the narrower store issue saves at this size.  Not kept.)
 // acc[a][b][r]: row = m0 + wm*64 + a*32 + (r&3) + 8*(r>>2) + 4*h, col = n0 + wn*32*NB + b*32 + i
 template <bool EDGE, int NB>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restrict__ C, f32x16 (&acc)[2][NB],

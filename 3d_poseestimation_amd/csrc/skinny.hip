@@ -61,16 +61,33 @@ __global__ __launch_bounds__(NTHR) void skinny_wide_out_kernel(
     const int g0 = r_base + g2 * 64;
     if (g0 >= B) break;
     f32x16 acc[2];
+    float xa[2][KS];                         // all A fragments first: one LDS round trip, not one per MFMA
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
       const float* xr = xs + (g2 * 64 + t * 32 + j) * KL + h;
 #pragma unroll
-      for (int s = 0; s < KS; ++s)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[2 * s], wb[s], acc[t], 0, 0, 0);
+      for (int s = 0; s < KS; ++s) xa[t][s] = xr[2 * s];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[0][s], wb[s], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[1][s], wb[s], acc[1], 0, 0, 0);
     }
     float ssum = 0.f;
+    if (g0 + 64 <= B) {                      // whole group: 32 unguarded 128-byte row stores per half-wave
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[t][r] + b;
+          acc[t][r] = v;
+          out[(size_t)(g0 + t * 32 + acc_row(r, h)) * H + c] = v;
+          ssum += v;
+        }
+    } else {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -83,6 +100,7 @@ __global__ __launch_bounds__(NTHR) void skinny_wide_out_kernel(
           ssum += v;
         }
       }
+    }
     if (STATS) {
       ssum += __shfl_xor(ssum, 32);
       const int cnt = min(64, B - g0);
