@@ -24,6 +24,14 @@ class PLSync(ctypes.Structure):
                 ("user", ctypes.c_void_p)]
 
 
+class PLL1Term(ctypes.Structure):
+    _fields_ = [("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("n", ctypes.c_int64),
+                ("da", ctypes.c_void_p), ("db", ctypes.c_void_p)]
+
+
+L1_MAX_TERMS = 8
+
+
 class PLDesc(ctypes.Structure):
     _fields_ = [
         ("in_dim", ctypes.c_int32), ("hidden", ctypes.c_int32), ("out_dim", ctypes.c_int32),
@@ -59,6 +67,8 @@ SIGNATURES = {
                                            _P, _P, _P, _c.c_int, _c.c_int, _P]),
     "pl_mse_scratch_bytes": (_c.c_size_t, [_c.c_int64]),
     "pl_mse_fwd_bwd": (_c.c_int, [_P, _P, _c.c_int64, _c.c_float, _P, _P, _P, _P]),
+    "pl_l1_scratch_bytes": (_c.c_size_t, [_c.c_int]),
+    "pl_l1_terms_fwd_bwd": (_c.c_int, [_c.POINTER(PLL1Term), _c.c_int, _c.c_float, _P, _P, _P]),
     "pl_mpjpe_scratch_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64]),
     "pl_mpjpe_accum": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P, _P]),
     "pl_adamw_flat": (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_float, _c.c_float, _c.c_float,

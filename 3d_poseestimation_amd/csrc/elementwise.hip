@@ -441,6 +441,34 @@ __global__ __launch_bounds__(NTHR) void mse_final_kernel(const float* __restrict
   if (threadIdx.x == 0) loss[0] = t * inv_n;
 }
 
+// ---- L1(mean) terms, forward + backward, several (a, b) pairs per launch -----------------------
+constexpr int L1_BLOCKS = 64;
+struct L1Terms { PLL1Term t[PL_L1_MAX_TERMS]; };
+
+__global__ __launch_bounds__(NTHR) void l1_partial_kernel(L1Terms T, float grad_scale, float* __restrict__ part) {
+  __shared__ float sm[4];
+  const PLL1Term q = T.t[blockIdx.y];
+  const float coef = grad_scale / (float)q.n;
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * NTHR + threadIdx.x; i < q.n; i += (int64_t)L1_BLOCKS * NTHR) {
+    const float d = q.a[i] - q.b[i];
+    acc += fabsf(d);
+    const float g = d > 0.f ? coef : (d < 0.f ? -coef : 0.f);
+    if (q.da) q.da[i] = g;
+    if (q.db) q.db[i] = -g;
+  }
+  const float t = block_sum(acc, sm);
+  if (threadIdx.x == 0) part[blockIdx.y * L1_BLOCKS + blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(64) void l1_final_kernel(const float* __restrict__ part, L1Terms T,
+                                                      float* __restrict__ losses) {
+  float v = part[blockIdx.x * L1_BLOCKS + threadIdx.x];       // L1_BLOCKS == 64 == one wavefront
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  if (threadIdx.x == 0) losses[blockIdx.x] = v / (float)T.t[blockIdx.x].n;
+}
+
 // ---- loss_MPJPE --------------------------------------------------------------------------
 __global__ void mpjpe_partial_kernel(const float* __restrict__ pred, const float* __restrict__ tgt,
                                      int B, int J, int rpc, float* __restrict__ part) {
@@ -850,5 +878,27 @@ extern "C" int pl_gather_rows2(const float* a, int64_t wa, const float* b, int64
   hipLaunchKernelGGL(gather_rows2_kernel, dim3((unsigned)((total + NTHR - 1) / NTHR)), dim3(NTHR), 0,
                      (hipStream_t)stream, a, (int)wa, b, (int)wb, idx, n, oa, ob);
   PL_CHECK_LAUNCH("gather_rows2");
+  return PL_OK;
+}
+
+extern "C" size_t pl_l1_scratch_bytes(int nterms) {
+  return (size_t)(nterms > 0 ? nterms : 1) * L1_BLOCKS * sizeof(float);
+}
+
+extern "C" int pl_l1_terms_fwd_bwd(const PLL1Term* terms, int nterms, float grad_scale, float* losses,
+                                   void* scratch, void* stream) {
+  if (!terms || !losses || !scratch) PL_FAIL(PL_EINVAL, "pl_l1_terms_fwd_bwd: null pointer");
+  if (nterms < 1 || nterms > PL_L1_MAX_TERMS) PL_FAIL(PL_EINVAL, "pl_l1_terms_fwd_bwd: nterms=%d", nterms);
+  L1Terms T = {};
+  for (int t = 0; t < nterms; ++t) {
+    if (!terms[t].a || !terms[t].b || terms[t].n <= 0)
+      PL_FAIL(PL_EINVAL, "pl_l1_terms_fwd_bwd: term %d has a null operand or n <= 0", t);
+    T.t[t] = terms[t];
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(l1_partial_kernel, dim3(L1_BLOCKS, nterms), dim3(NTHR), 0, s, T, grad_scale, (float*)scratch);
+  PL_CHECK_LAUNCH("l1_partial");
+  hipLaunchKernelGGL(l1_final_kernel, dim3(nterms), dim3(64), 0, s, (const float*)scratch, T, losses);
+  PL_CHECK_LAUNCH("l1_final");
   return PL_OK;
 }

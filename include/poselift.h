@@ -171,6 +171,24 @@ size_t pl_mse_scratch_bytes(int64_t n);
 int pl_mse_fwd_bwd(const float* pred, const float* tgt, int64_t n, float grad_scale,
                    float* dpred, float* loss_out, void* scratch, void* stream);
 
+/* torch.nn.L1Loss(reduction="mean") terms of TriangleLoss (phase5_loop/losses.py:10-62; the LinearModel-era
+ * copy phase5_loop/train_5 copy.py:34-86), ALL terms of one call in one launch pair:
+ * losses[t] = mean |a_t - b_t| over n_t elements; gradients, where wanted, da_t = grad_scale *
+ * sign(a_t - b_t) / n_t and db_t = -da_t (sign(0) = 0, as torch).  terms: HOST array of nterms <=
+ * PL_L1_MAX_TERMS descriptors holding device pointers; losses: nterms device floats;
+ * scratch >= pl_l1_scratch_bytes(nterms). */
+#define PL_L1_MAX_TERMS 8
+typedef struct PLL1Term {
+  const float* a;
+  const float* b;
+  int64_t n;
+  float* da; /* or NULL */
+  float* db; /* or NULL */
+} PLL1Term;
+size_t pl_l1_scratch_bytes(int nterms);
+int pl_l1_terms_fwd_bwd(const PLL1Term* terms, int nterms, float grad_scale, float* losses,
+                        void* scratch, void* stream);
+
 /* loss_MPJPE  train_1.py:19-23,100: metric[j] += sum_b ||pred[b][j] - tgt[b][j]||_2.
  * pred/tgt [B][joints][3]; metric [joints] device fp32, accumulated in place. */
 size_t pl_mpjpe_scratch_bytes(int64_t B, int64_t joints);

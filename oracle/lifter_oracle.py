@@ -323,3 +323,51 @@ def flip_pose(data):
         out[..., 0] *= -1
     out[..., left + right, :] = out[..., right + left, :]
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# TriangleLoss of the phase5 cycle step
+# ---------------------------------------------------------------------------------------------
+def l1_mean(a, b):
+    """torch.nn.L1Loss(reduction='mean'): value and the gradient w.r.t. a (the one w.r.t. b is its negative)."""
+    d = np.asarray(a, np.float64) - np.asarray(b, np.float64)
+    return np.abs(d).mean(), np.sign(d) / d.size
+
+
+def _centre_on_first(t):
+    out = np.array(t, dtype=np.float64, copy=True)
+    out[1:] -= out[0]
+    return out
+
+
+def _centre_on_first_bwd(g):
+    """Gradient of `t[1:] -= t[0]`: entry 0 also collects minus the sum of the others."""
+    out = np.array(g, copy=True)
+    out[0] -= g[1:].sum(axis=0)
+    return out
+
+
+def triangle_loss(p2d, p3d, lift_gt, lift_pred, g2d, g3d, proj_pred=None, project=False, era="model2d"):
+    """/root/reference/phase5_loop/losses.py:24-53 (era 'model2d') and the LinearModel-era copy
+    /root/reference/phase5_loop/train_5 copy.py:50-70 (era 'lifter', without its projector branch).
+    Returns (terms, grads) with grads for p2d, p3d, lift_pred, lift_gt and proj_pred."""
+    grads = {k: 0.0 for k in ("p2d", "p3d", "lift_pred", "lift_gt", "proj")}
+    l2, g = l1_mean(p2d, g2d); grads["p2d"] = grads["p2d"] + g
+    l3, g = l1_mean(p3d, g3d); grads["p3d"] = grads["p3d"] + g
+    if era == "model2d":
+        ll, g = l1_mean(lift_pred, p3d)
+        grads["lift_pred"] = grads["lift_pred"] + g
+        grads["p3d"] = grads["p3d"] - g
+        terms = [l2, l3, ll]
+        if project:
+            lp, g = l1_mean(_centre_on_first(proj_pred), _centre_on_first(p2d))
+            grads["proj"] = grads["proj"] + _centre_on_first_bwd(g)
+            grads["p2d"] = grads["p2d"] - _centre_on_first_bwd(g)
+            terms.append(lp)
+    else:
+        ll, g = l1_mean(lift_gt, g3d); grads["lift_gt"] = grads["lift_gt"] + g
+        lg, g = l1_mean(lift_pred, lift_gt)
+        grads["lift_pred"] = grads["lift_pred"] + g
+        grads["lift_gt"] = grads["lift_gt"] - g
+        terms = [l2, l3, ll, lg]
+    return terms, grads

@@ -866,3 +866,36 @@ def test_bf16x6_loop_variants_are_bitwise_identical_over_a_train_step(pkg, tmp_p
         res[tag] = torch.load(out, weights_only=True)
     for k in ("out", "g", "dx"):
         assert torch.equal(res["planes"][k], res["fragment"][k]), k
+
+
+def test_triangle_loss_vs_reference_golden_and_oracle(pkg):
+    """TriangleLoss on the HIP L1 kernel (all terms of a call in one launch pair).  era 'model2d' against
+    phase5_loop/losses.py run as-is (golden g8: values and gradients, with and without the projector
+    term); era 'lifter' (the LinearModel-era copy in train_5 copy.py, restated from its text) against the
+    oracle; l1_loss against torch's L1Loss on the CPU."""
+    g = load_golden("g8_triangle_loss.npz")
+    ins = {k[3:]: g[k] for k in g if k.startswith("in:")}
+    for tag, project in (("noproj", False), ("proj", True)):
+        t = {k: _t(v).requires_grad_(k in ("p2d", "p3d", "lpred", "proj")) for k, v in ins.items()}
+        out = pkg.TriangleLoss(Project=project, era="model2d")(t["p2d"], t["p3d"], t["lgt"], t["lpred"], t["g2d"],
+                                                                t["g3d"], proj_3d_pred=t["proj"])
+        out[0].backward()
+        want = g[f"{tag}:losses"]
+        _close(np.array([float(o.detach()) if torch.is_tensor(o) else float(o) for o in out]), want, 2e-6, 1e-7)
+        for k in ("p2d", "p3d", "lpred") + (("proj",) if project else ()):
+            _close(t[k].grad.cpu().numpy(), g[f"{tag}:grad:{k}"], 1e-5, 1e-9)
+        assert project or t["proj"].grad is None
+    # LinearModel-era variant: four terms, returns their sum; gradients also reach lift(y2d)
+    t = {k: _t(v).requires_grad_(k in ("p2d", "p3d", "lpred", "lgt")) for k, v in ins.items()}
+    crit = pkg.TriangleLoss(era="lifter")
+    loss = crit(t["p2d"], t["p3d"], t["lgt"], t["lpred"], t["g2d"], t["g3d"])
+    loss.backward()
+    terms, grads = orc.triangle_loss(ins["p2d"], ins["p3d"], ins["lgt"], ins["lpred"], ins["g2d"], ins["g3d"], era="lifter")
+    _close(loss.item(), sum(terms), 2e-6, 0)
+    for k, name in (("p2d", "p2d"), ("p3d", "p3d"), ("lpred", "lift_pred"), ("lgt", "lift_gt")):
+        _close(t[k].grad.cpu().numpy(), np.broadcast_to(grads[name], ins[k].shape), 1e-5, 1e-9)
+    _close(np.array(crit.term_means()), np.array(terms), 2e-6, 0)
+    a, b = torch.randn(1000, 51), torch.randn(1000, 51)
+    _close(pkg.l1_loss(a.to(DEV), b.to(DEV)).item(), torch.nn.L1Loss()(a, b).item(), 2e-6, 0)
+    with pytest.raises(pkg.PoseliftError):
+        pkg.l1_loss(a, b)                      # CPU tensors: no fallback

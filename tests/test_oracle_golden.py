@@ -150,3 +150,21 @@ def test_batchnorm_rejects_single_row():
     st = orc.init_state(34, 51, 64, 2, rng=np.random.default_rng(0))
     with pytest.raises(ValueError):
         orc.forward(st, np.zeros((1, 17, 2), np.float32), train=True, p_dropout=0.0)
+
+
+def test_g8_triangle_loss_oracle_vs_reference():
+    """oracle.triangle_loss (era 'model2d') against phase5_loop/losses.py run as-is: term values and the
+    gradients of the sum w.r.t. every predicted tensor, with and without the projector term."""
+    g = load_golden("g8_triangle_loss.npz")
+    ins = {k[3:]: g[k] for k in g if k.startswith("in:")}
+    for tag, project in (("noproj", False), ("proj", True)):
+        terms, grads = orc.triangle_loss(ins["p2d"], ins["p3d"], ins["lgt"], ins["lpred"], ins["g2d"], ins["g3d"],
+                                         proj_pred=ins["proj"], project=project)
+        want = g[f"{tag}:losses"]
+        assert np.allclose(sum(terms), want[0], rtol=1e-6)
+        assert np.allclose(terms[:3], want[1:4], rtol=1e-6)
+        if project:
+            assert np.allclose(terms[3], want[4], rtol=1e-6)
+        for name, key in (("p2d", "p2d"), ("p3d", "p3d"), ("lift_pred", "lpred"), ("proj", "proj")):
+            got = np.broadcast_to(np.asarray(grads[name], np.float64), g[f"{tag}:grad:{key}"].shape)
+            assert np.allclose(got, g[f"{tag}:grad:{key}"], rtol=1e-5, atol=1e-9), (tag, name)

@@ -202,6 +202,34 @@ def main():
             rec["head:" + k] = v.reshape(-1)[:16].numpy().copy()
             rec["sum:" + k] = np.float64(v.double().sum().item())
     np.savez(os.path.join(OUT, "g7_init_seed0.npz"), **rec)
+    # ---- G8: TriangleLoss of the phase5 cycle step (phase5_loop/losses.py, imported as-is) ---
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_losses", "/root/reference/phase5_loop/losses.py")
+    ref_losses = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_losses)
+    rng = np.random.default_rng(808)
+    B = 24
+    rec = {}
+    base = {"p2d": rng.random((B, 17, 2)), "p3d": rng.standard_normal((B, 17, 3)) * 0.3,
+            "lgt": rng.standard_normal((B, 17, 3)) * 0.3, "lpred": rng.standard_normal((B, 17, 3)) * 0.3,
+            "g2d": rng.random((B, 17, 2)), "g3d": rng.standard_normal((B, 17, 3)) * 0.3,
+            "proj": rng.random((B, 17, 2))}
+    for k, v in base.items():
+        rec["in:" + k] = v.astype(np.float32)
+    for project in (False, True):
+        leaves = {k: torch.tensor(v.astype(np.float32), requires_grad=k in ("p2d", "p3d", "lpred", "proj"))
+                  for k, v in base.items()}
+        # the reference centres proj_3d_pred in place: hand it a non-leaf, as the training loop does
+        proj = leaves["proj"] * 1.0
+        out = ref_losses.TriangleLoss(Project=project)(leaves["p2d"], leaves["p3d"], leaves["lgt"], leaves["lpred"],
+                                                       leaves["g2d"], leaves["g3d"], proj_3d_pred=proj)
+        out[0].backward()
+        tag = "proj" if project else "noproj"
+        rec[f"{tag}:losses"] = np.array([float(o) for o in out], dtype=np.float64)
+        for k in ("p2d", "p3d", "lpred", "proj"):
+            g = leaves[k].grad
+            rec[f"{tag}:grad:{k}"] = (g if g is not None else torch.zeros_like(leaves[k])).numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "g8_triangle_loss.npz"), **rec)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
