@@ -74,6 +74,8 @@ SIGNATURES = {
     "pl_adamw_flat": (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_float, _c.c_float, _c.c_float,
                                  _c.c_float, _c.c_float, _c.c_int64, _c.c_float, _P]),
     "pl_flip_pose": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P]),
+    "pl_conv2d_nhwc_fwd": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int,
+                                      _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _c.c_int, _P, _P, _P]),
     "pl_gather_rows2": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _P, _c.c_int64, _c.c_int64, _P, _P, _P]),
     "pl_flip_tta_pack": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P]),
     "pl_flip_tta_merge": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P]),

@@ -225,8 +225,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, float* __restri
           v += bias;
           if (p.addend && cok && (!EDGE || row < p.M)) v += p.addend[(size_t)row * p.ldc + col];
           if (p.col_scale) v = fmaf(v, scale, shift);
-          if (p.relu) v = fmaxf(v, 0.f);
+          if (p.relu == 1) v = fmaxf(v, 0.f);
           if (p.resid && cok && (!EDGE || row < p.M)) v += p.resid[(size_t)row * p.ldc + col];
+          if (p.relu == 2) v = fmaxf(v, 0.f);
         }
         acc[a][b][r] = v;
         if (!EDGE || row < p.M) ssum += v;
@@ -601,6 +602,44 @@ __device__ __forceinline__ void load_tile_p(Stage& s, const float* __restrict__ 
   }
 }
 
+// Implicit-GEMM convolution: the A "matrix" is the NHWC input gathered on the fly (GemmArgs::conv_*).
+// Same thread mapping as the k-contiguous BK 32 loader -- (octet = tid&3, row = tid>>2 [+64]) -- and because
+// Cin % 32 == 0 a 32-wide K tile lies inside ONE filter tap: per tile the tap (kh, kw) and channel offset
+// are wave-uniform scalars, each thread only checks its two output pixels against the image border and
+// loads 2 x 32 B from the (clamped) pixel, zeroed by a select when the tap falls outside.
+struct ConvRow { const float* base; int ih0, iw0; };    // pixel (b, 0, 0) and the tap-(0,0) input coordinates
+
+__device__ __forceinline__ ConvRow conv_row(const GemmArgs& p, int m) {
+  const int ow = m % p.conv_wo, t = m / p.conv_wo;
+  const int oh = t % p.conv_ho, b = t / p.conv_ho;
+  ConvRow r;
+  r.base = p.A + (size_t)b * p.conv_h * p.conv_w * p.conv_cin;
+  r.ih0 = oh * p.conv_stride - p.conv_pad;
+  r.iw0 = ow * p.conv_stride - p.conv_pad;
+  return r;
+}
+
+__device__ __forceinline__ void load_tile_conv(Stage& s, const GemmArgs& p, const ConvRow& r0, const ConvRow& r1,
+                                               int k0, int tid) {
+  const int tap = k0 / p.conv_cin, c0 = k0 - tap * p.conv_cin + (tid & 3) * 8;
+  const int kh = tap / p.conv_kw, kw = tap - kh * p.conv_kw;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const int ih = r0.ih0 + kh, iw = r0.iw0 + kw;
+    const bool ok = (unsigned)ih < (unsigned)p.conv_h && (unsigned)iw < (unsigned)p.conv_w;
+    const float* t = r0.base + ((size_t)(ok ? ih : 0) * p.conv_w + (ok ? iw : 0)) * p.conv_cin + c0;
+    const float4 u = *reinterpret_cast<const float4*>(t), v = *reinterpret_cast<const float4*>(t + 4);
+    s.v0 = ok ? u : zero; s.v1 = ok ? v : zero;
+  }
+  {
+    const int ih = r1.ih0 + kh, iw = r1.iw0 + kw;
+    const bool ok = (unsigned)ih < (unsigned)p.conv_h && (unsigned)iw < (unsigned)p.conv_w;
+    const float* t = r1.base + ((size_t)(ok ? ih : 0) * p.conv_w + (ok ? iw : 0)) * p.conv_cin + c0;
+    const float4 u = *reinterpret_cast<const float4*>(t), v = *reinterpret_cast<const float4*>(t + 4);
+    s.v2 = ok ? u : zero; s.v3 = ok ? v : zero;
+  }
+}
+
 // x = x0 + x1 + x2 exactly, the same RNE split as split3 (results are bit-identical to the fragment path)
 template <int PLANE>
 __device__ __forceinline__ void split8_store(char* __restrict__ dst, const float (&f)[8]) {
@@ -663,7 +702,7 @@ __device__ __forceinline__ void store_half_p(char* __restrict__ op, int tid, con
 //     element through the same L2 path.  Removed again.
 //   PMC (SQ_*): MFMA busy 46 % of wave cycles, WAIT_ANY 22 %, issue time of the ~5.6 non-MFMA instructions
 //   per MFMA gap not hidden (the guide's limit is <= 5 per 32x32x16 gap, hand-placed).
-template <bool A_KS, bool B_KS, int BKX>
+template <bool A_KS, bool B_KS, int BKX, bool A_CONV = false>
 __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int block_id, const int nwork,
                                                  char* __restrict__ lds) {
   using Cf = PCfg<BKX>;
@@ -725,10 +764,16 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
   char* cur = lds;                    // tile kt: being consumed
   char* nx1 = lds + Cf::STAGE;        // tile kt+1: complete, readable
   char* nx2 = lds + 2 * Cf::STAGE;    // tile kt+2: being written during step kt
+  static_assert(!A_CONV || (!A_KS && BKX == 32), "the convolution gather is a k-contiguous BK 32 loader");
   using SA = Stage;
   SA ra0, ra1;                        // staging register sets: tile t lives in set t % 2
   Stage rb0, rb1;
-  auto load_a = [&](SA& d, const int k0) { load_tile_p<A_KS, BKX>(d, p.A, p.lda, m0, k0, tid); };
+  ConvRow cr0 = {}, cr1 = {};
+  if (A_CONV) { cr0 = conv_row(p, m0 + (tid >> 2)); cr1 = conv_row(p, m0 + (tid >> 2) + 64); }
+  auto load_a = [&](SA& d, const int k0) {
+    if constexpr (A_CONV) load_tile_conv(d, p, cr0, cr1, k0, tid);
+    else load_tile_p<A_KS, BKX>(d, p.A, p.lda, m0, k0, tid);
+  };
   auto store_a = [&](char* op, auto half, const SA& g) {
     store_half_p<A_KS, BKX, decltype(half)::value>(op, tid, g);
   };
@@ -826,6 +871,11 @@ template <bool A_KS, bool B_KS>
 __global__ __launch_bounds__(256) void gemm_x6_planes_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[PCfg<32>::LDS];
   gemm_body_planes<A_KS, B_KS, 32>(p, blockIdx.x, gridDim.x, lds);
+}
+
+__global__ __launch_bounds__(256) void conv_x6_planes_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[PCfg<32>::LDS];
+  gemm_body_planes<false, false, 32, true>(p, blockIdx.x, gridDim.x, lds);
 }
 
 // backward pair in one launch (see gemm_f32_dual_kernel): BK 16, two workgroups per CU
@@ -949,6 +999,20 @@ int launch_gemm_f32_pair(const GemmArgs& nn, const GemmArgs& tn, hipStream_t s) 
   else hipLaunchKernelGGL((gemm_f32_dual_kernel<0, 4>), dim3(g0 + g1), dim3(NTHR), 0, s, nn, tn, g0);
   if (prof) (void)hipEventRecord(prof->e1, s);
   PL_CHECK_LAUNCH("gemm_f32_dual");
+  return PL_OK;
+}
+
+int launch_conv_nhwc(const GemmArgs& a, hipStream_t s) {
+  if (!a.A || !a.B || !a.C) PL_FAIL(PL_EINVAL, "conv: null operand");
+  if (a.conv_cin <= 0 || a.conv_cin % 32 || a.M % BM || a.N % BN || a.K % BK || a.K % a.conv_cin || a.split_k > 1)
+    PL_FAIL(PL_ESHAPE, "conv: needs Cin %% 32 == 0, Cout %% 128 == 0, B*Ho*Wo %% 128 == 0 (M=%d N=%d K=%d Cin=%d)",
+            a.M, a.N, a.K, a.conv_cin);
+  if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15)
+    PL_FAIL(PL_EINVAL, "conv: operands not 16-byte aligned");
+  ProfRec* prof = prof_begin(a, s);
+  hipLaunchKernelGGL(conv_x6_planes_kernel, dim3((a.M / BM) * (a.N / BN)), dim3(NTHR), 0, s, a);
+  if (prof) (void)hipEventRecord(prof->e1, s);
+  PL_CHECK_LAUNCH("conv_x6_planes");
   return PL_OK;
 }
 

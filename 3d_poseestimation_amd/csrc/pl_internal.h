@@ -51,12 +51,20 @@ struct GemmArgs {
   float* stat_m2;           //   ... and sums of squares about the group mean
   const float* col_scale;   // [N]     v = v*scale[col] + shift[col]  (eval-mode BN fold)
   const float* col_shift;
-  int relu;                 // v = max(v, 0)
+  int relu;                 // 1: v = max(v, 0) before the resid add; 2: after it (Bottleneck order)
   const float* resid;       // [M][ldc] v += resid[row][col] after relu (may alias C)
   int arith;                // 0 fp32 MFMA; 1 PL_BF16: operands rounded to bf16 on the way to the MFMA;
                             // 2 PL_BF16X6: three-way bf16 split, six MFMAs, fp32-grade products
                             // (whole-tile problems only; edge problems stay fp32)
+  // Implicit-GEMM convolution (launch_conv_nhwc only; conv_cin == 0 otherwise): A is not a matrix but the
+  // NHWC input x [B][H][W][Cin]; row m = (b, oh, ow), k = (kh*KW + kw)*Cin + ci, element
+  // x[b][oh*stride - pad + kh][ow*stride - pad + kw][ci] or 0 outside the image.  B = weights [N][K] (OHWI).
+  int conv_cin, conv_h, conv_w, conv_ho, conv_wo, conv_kw, conv_stride, conv_pad;
 };
+
+// y = conv2d(x, w) as an implicit GEMM on the PL_BF16X6 planes pipeline; a.A = x, a.B = w [Cout][KH*KW*Cin],
+// a.M = B*Ho*Wo, a.N = Cout, a.K = KH*KW*Cin and the conv_* fields filled in; whole tiles only.
+int launch_conv_nhwc(const GemmArgs& a, hipStream_t s);
 
 int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s);
 int launch_gemm_f32_pair(const GemmArgs& nn, const GemmArgs& tn, hipStream_t s);

@@ -155,6 +155,21 @@ int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const float* target
                             void* workspace, size_t workspace_bytes, uint64_t seed, uint64_t step,
                             float* y, float* loss, float* flat_grads, int hi, int lo, void* stream);
 
+/* ---- convolution (first slice: forward) ---------------------------- */
+/* nn.Conv2d forward in NHWC as an implicit GEMM on the PL_BF16X6 pipeline (fp32-grade products), with the
+ * Bottleneck's eval-mode epilogue folded in: phase4_joined/Resnet.py:51-95 (conv1/2/3 + bn + relu + residual),
+ * :121-165 (downsample), phase4_joined/Model.py:66-69 (final 1x1 conv with bias).
+ *   v = sum_{kh,kw,ci} x[b][oh*stride - pad + kh][ow*stride - pad + kw][ci] * w[co][kh][kw][ci]  (+ bias[co])
+ *   v = v * scale[co] + shift[co]          (BatchNorm2d on running statistics, folded; or NULL)
+ *   relu 1: v = max(v, 0), then v += resid;   relu 2: v += resid, then max(v, 0);   relu 0: v += resid
+ * x [B][H][W][Cin], w [Cout][KH][KW][Cin] (OHWI), resid / y [B][Ho][Wo][Cout].  1x1 stride-1 convolutions are
+ * plain GEMMs (any shape); the others need Cin % 32 == 0, Cout % 128 == 0 and B*Ho*Wo % 128 == 0 (PL_ESHAPE
+ * otherwise: the 7x7 stem and the 64-wide layer1 convolutions are not covered yet). */
+int pl_conv2d_nhwc_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* w,
+                       int64_t Cout, int KH, int KW, int stride, int pad, const float* scale,
+                       const float* shift, const float* bias, int relu, const float* resid, float* y,
+                       void* stream);
+
 /* ---- batch feed ------------------------------------------------------------------- */
 /* One batch of the DataLoader path (train_1.py:26-31,75-81: shuffle, collate, .float(), .to(device))
  * from tables resident in HBM: oa[i] = a[idx[i]] (wa floats per row, the (17,2) keypoints),
