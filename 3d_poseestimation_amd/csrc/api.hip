@@ -568,31 +568,3 @@ extern "C" int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const fl
   }
   return bwd_impl(d, x, dy, B, ws, ws_bytes, nullptr, grads, stream, hi == L, hi == L ? L - 1 : hi, lo);
 }
-
-// ---------------------------------------------------------------------------------------
-// convolution forward (first slice)
-// ---------------------------------------------------------------------------------------
-extern "C" int pl_conv2d_nhwc_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* w,
-                                  int64_t Cout, int KH, int KW, int stride, int pad, const float* scale,
-                                  const float* shift, const float* bias, int relu, const float* resid, float* y,
-                                  void* stream) {
-  if (!x || !w || !y) PL_FAIL(PL_EINVAL, "pl_conv2d_nhwc_fwd: null pointer");
-  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
-    PL_FAIL(PL_ESHAPE, "pl_conv2d_nhwc_fwd: bad geometry");
-  if ((scale != nullptr) != (shift != nullptr)) PL_FAIL(PL_EINVAL, "pl_conv2d_nhwc_fwd: scale without shift");
-  if (relu < 0 || relu > 2) PL_FAIL(PL_EINVAL, "pl_conv2d_nhwc_fwd: relu=%d", relu);
-  const int64_t Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
-  const int64_t M = B * Ho * Wo, K = (int64_t)KH * KW * Cin;
-  if (Ho <= 0 || Wo <= 0 || M > INT32_MAX || K > INT32_MAX || B * H * W * Cin > ((int64_t)1 << 40))
-    PL_FAIL(PL_ESHAPE, "pl_conv2d_nhwc_fwd: output %lldx%lld", (long long)Ho, (long long)Wo);
-  GemmArgs g = {};
-  g.A = x; g.B = w; g.C = y; g.M = (int)M; g.N = (int)Cout; g.K = (int)K;
-  g.lda = (int)K; g.ldb = (int)K; g.ldc = (int)Cout; g.split_k = 1;
-  g.bias = bias; g.col_scale = scale; g.col_shift = shift; g.relu = relu; g.resid = resid;
-  g.arith = PL_BF16X6;
-  hipStream_t s = (hipStream_t)stream;
-  if (KH == 1 && KW == 1 && stride == 1 && pad == 0) return launch_gemm_f32(kNT, g, s);   // a plain GEMM
-  g.conv_cin = (int)Cin; g.conv_h = (int)H; g.conv_w = (int)W; g.conv_ho = (int)Ho; g.conv_wo = (int)Wo;
-  g.conv_kw = KW; g.conv_stride = stride; g.conv_pad = pad;
-  return launch_conv_nhwc(g, s);
-}

@@ -1,0 +1,226 @@
+// Convolution-path forward pieces of the phase4 model (first slice), NHWC throughout.
+//
+//   pl_conv2d_nhwc_fwd       nn.Conv2d (+ folded eval BatchNorm2d, ReLU, residual): implicit GEMM on the
+//                            PL_BF16X6 planes pipeline where the shape allows whole tiles (gemm_f32.hip),
+//                            else explicit im2col into caller scratch + the generic GEMM (7x7 stem with
+//                            Cin = 3, the 64-wide layer1 convolutions)
+//   pl_maxpool3x3s2_nhwc     nn.MaxPool2d(3, 2, 1)                     phase4_joined/Resnet.py:119
+//   pl_deconv4x4s2_nhwc_fwd  nn.ConvTranspose2d(k=4, s=2, p=1, bias=False) (+ folded BN, ReLU)
+//                            phase4_joined/Model.py:47-69: four 2x2-tap convolutions, one per output parity,
+//                            each an implicit GEMM over the INPUT resolution, then one interleave pass
+//   pl_nhwc_to_nchw          the head's output for the soft-argmax, which wants [B][J*D][H][W]
+#include "pl_internal.h"
+
+namespace pl {
+namespace {
+
+constexpr int NTHR = 256;
+
+// col[m][k], m = (b, oh, ow), k = (kh*KW + kw)*Cin + ci, zero outside the image and for k >= K (row padding)
+__global__ __launch_bounds__(NTHR) void im2col_nhwc_kernel(const float* __restrict__ x, int H, int W, int Cin,
+                                                           int Ho, int Wo, int KH, int KW, int stride, int pad,
+                                                           int64_t M, int K, int Kp, float* __restrict__ col) {
+  const int64_t t = (int64_t)blockIdx.x * NTHR + threadIdx.x;
+  if (t >= M * Kp) return;
+  const int64_t m = t / Kp;
+  const int k = (int)(t - m * Kp);
+  float v = 0.f;
+  if (k < K) {
+    const int ci = k % Cin, tap = k / Cin, kw = tap % KW, kh = tap / KW;
+    const int ow = (int)(m % Wo);
+    const int64_t r = m / Wo;
+    const int oh = (int)(r % Ho);
+    const int64_t b = r / Ho;
+    const int ih = oh * stride - pad + kh, iw = ow * stride - pad + kw;
+    if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) v = x[((b * H + ih) * W + iw) * Cin + ci];
+  }
+  col[t] = v;
+}
+
+// weights [Cout][K] -> [Cout][Kp] zero padded (once per call of the fallback path; tiny)
+__global__ void pad_rows_kernel(const float* __restrict__ w, int rows, int K, int Kp, float* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= rows * Kp) return;
+  const int r = t / Kp, k = t - r * Kp;
+  out[t] = k < K ? w[(size_t)r * K + k] : 0.f;
+}
+
+__global__ __launch_bounds__(NTHR) void maxpool3x3s2_nhwc_kernel(const float* __restrict__ x, int H, int W, int C,
+                                                                 int Ho, int Wo, int64_t n4,
+                                                                 float* __restrict__ y) {
+  const int64_t t = (int64_t)blockIdx.x * NTHR + threadIdx.x;     // one float4 of channels per thread
+  if (t >= n4) return;
+  const int c4 = C >> 2;
+  const int c = (int)(t % c4) * 4;
+  int64_t r = t / c4;
+  const int ow = (int)(r % Wo); r /= Wo;
+  const int oh = (int)(r % Ho);
+  const int64_t b = r / Ho;
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+        const float4 v = *reinterpret_cast<const float4*>(x + ((b * H + ih) * W + iw) * C + c);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+  *reinterpret_cast<float4*>(y + t * 4) = m;
+}
+
+// y[b][2a+ph][2c+pw][:] = part[ph*2+pw][b][a][c][:]
+__global__ __launch_bounds__(NTHR) void deconv_interleave_kernel(const float* __restrict__ part, int Hi, int Wi, int C,
+                                                                 int64_t n4_per_part, float* __restrict__ y) {
+  const int64_t t = (int64_t)blockIdx.x * NTHR + threadIdx.x;
+  if (t >= n4_per_part * 4) return;
+  const int par = (int)(t / n4_per_part);
+  int64_t r = t - par * n4_per_part;
+  const int c4 = C >> 2;
+  const int c = (int)(r % c4) * 4; r /= c4;
+  const int cw = (int)(r % Wi); r /= Wi;
+  const int a = (int)(r % Hi);
+  const int64_t b = r / Hi;
+  const int oh = 2 * a + (par >> 1), ow = 2 * cw + (par & 1);
+  const float4 v = *reinterpret_cast<const float4*>(part + t * 4);
+  *reinterpret_cast<float4*>(y + ((b * 2 * Hi + oh) * 2 * Wi + ow) * C + c) = v;
+}
+
+// out[b][c][p] = in[b][p][c]   (p = pixel); 32x32 tiles through LDS, both sides coalesced
+__global__ __launch_bounds__(1024) void nhwc_to_nchw_kernel(const float* __restrict__ in, int P, int C,
+                                                            float* __restrict__ out) {
+  __shared__ float tile[32][33];
+  const int64_t b = blockIdx.z;
+  const int p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  if (p0 + ty < P && c0 + tx < C) tile[ty][tx] = in[(b * P + p0 + ty) * C + c0 + tx];
+  __syncthreads();
+  if (c0 + ty < C && p0 + tx < P) out[(b * C + c0 + ty) * P + p0 + tx] = tile[tx][ty];
+}
+
+bool implicit_ok(int64_t M, int64_t Cin, int64_t Cout, int64_t K) {
+  return Cin % 32 == 0 && Cout % 128 == 0 && M % 128 == 0 && K % 32 == 0;
+}
+
+int conv_core(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* w, int64_t Cout, int KH,
+              int KW, int stride, int pad_h, int pad_w, int64_t Ho, int64_t Wo, const float* scale,
+              const float* shift, const float* bias, int relu, const float* resid, float* y, void* scratch,
+              size_t scratch_bytes, hipStream_t s) {
+  const int64_t M = B * Ho * Wo, K = (int64_t)KH * KW * Cin;
+  if (M > INT32_MAX || K > INT32_MAX) PL_FAIL(PL_ESHAPE, "conv: problem too large");
+  GemmArgs g = {};
+  g.A = x; g.B = w; g.C = y; g.M = (int)M; g.N = (int)Cout; g.K = (int)K;
+  g.lda = (int)K; g.ldb = (int)K; g.ldc = (int)Cout; g.split_k = 1;
+  g.bias = bias; g.col_scale = scale; g.col_shift = shift; g.relu = relu; g.resid = resid;
+  g.arith = PL_BF16X6;
+  if (KH == 1 && KW == 1 && stride == 1 && pad_h == 0 && pad_w == 0) return launch_gemm_f32(kNT, g, s);
+  if (implicit_ok(M, Cin, Cout, K)) {
+    g.conv_cin = (int)Cin; g.conv_h = (int)H; g.conv_w = (int)W; g.conv_ho = (int)Ho; g.conv_wo = (int)Wo;
+    g.conv_kw = KW; g.conv_stride = stride; g.conv_pad_h = pad_h; g.conv_pad_w = pad_w;
+    return launch_conv_nhwc(g, s);
+  }
+  // fallback: explicit im2col (rows padded to a multiple of 4 floats) + the generic GEMM
+  if (pad_h != pad_w) PL_FAIL(PL_ESHAPE, "conv: asymmetric padding only on the implicit path");
+  const int64_t Kp = (K + 3) / 4 * 4;
+  const size_t need = ((size_t)M * Kp + (size_t)Cout * Kp) * sizeof(float);
+  if (!scratch || scratch_bytes < need)
+    PL_FAIL(PL_EWORKSPACE, "conv: this shape takes the im2col path and needs %zu scratch bytes (got %zu)", need,
+            scratch_bytes);
+  float* col = static_cast<float*>(scratch);
+  float* wp = col + (size_t)M * Kp;
+  const int64_t tot = M * Kp;
+  if (tot > (int64_t)INT32_MAX * NTHR) PL_FAIL(PL_ESHAPE, "conv: im2col too large");
+  hipLaunchKernelGGL(im2col_nhwc_kernel, dim3((unsigned)((tot + NTHR - 1) / NTHR)), dim3(NTHR), 0, s, x, (int)H,
+                     (int)W, (int)Cin, (int)Ho, (int)Wo, KH, KW, stride, pad_h, M, (int)K, (int)Kp, col);
+  PL_CHECK_LAUNCH("im2col_nhwc");
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((Cout * Kp + 255) / 256)), dim3(256), 0, s, w, (int)Cout,
+                     (int)K, (int)Kp, wp);
+  PL_CHECK_LAUNCH("pad_rows");
+  g.A = col; g.B = wp; g.K = (int)Kp; g.lda = (int)Kp; g.ldb = (int)Kp;
+  return launch_gemm_f32(kNT, g, s);
+}
+
+}  // namespace
+}  // namespace pl
+
+using namespace pl;
+
+extern "C" size_t pl_conv2d_nhwc_scratch_bytes(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH,
+                                               int KW, int stride, int pad) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return 0;
+  const int64_t Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return 0;
+  const int64_t M = B * Ho * Wo, K = (int64_t)KH * KW * Cin;
+  if ((KH == 1 && KW == 1 && stride == 1 && pad == 0) || implicit_ok(M, Cin, Cout, K)) return 0;
+  const int64_t Kp = (K + 3) / 4 * 4;
+  return ((size_t)M * Kp + (size_t)Cout * Kp) * sizeof(float);
+}
+
+extern "C" int pl_conv2d_nhwc_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* w,
+                                  int64_t Cout, int KH, int KW, int stride, int pad, const float* scale,
+                                  const float* shift, const float* bias, int relu, const float* resid, float* y,
+                                  void* scratch, size_t scratch_bytes, void* stream) {
+  if (!x || !w || !y) PL_FAIL(PL_EINVAL, "pl_conv2d_nhwc_fwd: null pointer");
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
+    PL_FAIL(PL_ESHAPE, "pl_conv2d_nhwc_fwd: bad geometry");
+  if ((scale != nullptr) != (shift != nullptr)) PL_FAIL(PL_EINVAL, "pl_conv2d_nhwc_fwd: scale without shift");
+  if (relu < 0 || relu > 2) PL_FAIL(PL_EINVAL, "pl_conv2d_nhwc_fwd: relu=%d", relu);
+  const int64_t Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) PL_FAIL(PL_ESHAPE, "pl_conv2d_nhwc_fwd: empty output");
+  return conv_core(x, B, H, W, Cin, w, Cout, KH, KW, stride, pad, pad, Ho, Wo, scale, shift, bias, relu, resid, y,
+                   scratch, scratch_bytes, (hipStream_t)stream);
+}
+
+extern "C" int pl_maxpool3x3s2_nhwc(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y,
+                                    void* stream) {
+  if (!x || !y) PL_FAIL(PL_EINVAL, "pl_maxpool3x3s2_nhwc: null pointer");
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) PL_FAIL(PL_ESHAPE, "pl_maxpool3x3s2_nhwc: C %% 4 == 0 needed");
+  const int64_t Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t n4 = B * Ho * Wo * (C >> 2);
+  if (n4 > (int64_t)INT32_MAX * NTHR) PL_FAIL(PL_ESHAPE, "pl_maxpool3x3s2_nhwc: too large");
+  hipLaunchKernelGGL(maxpool3x3s2_nhwc_kernel, dim3((unsigned)((n4 + NTHR - 1) / NTHR)), dim3(NTHR), 0,
+                     (hipStream_t)stream, x, (int)H, (int)W, (int)C, (int)Ho, (int)Wo, n4, y);
+  PL_CHECK_LAUNCH("maxpool3x3s2_nhwc");
+  return PL_OK;
+}
+
+// w_sub: [4 parities][Cout][2][2][Cin], parity = (oh&1)*2 + (ow&1); tap (th, tw) of parity (ph, pw) is
+// ConvTranspose2d weight[ci][co][kh][kw] with kh = ph ? 2 - 2*th : 3 - 2*th, kw likewise (conv.py deconv_subkernels)
+extern "C" size_t pl_deconv4x4s2_nhwc_scratch_bytes(int64_t B, int64_t Hi, int64_t Wi, int64_t Cout) {
+  return B > 0 && Hi > 0 && Wi > 0 && Cout > 0 ? (size_t)4 * B * Hi * Wi * Cout * sizeof(float) : 0;
+}
+
+extern "C" int pl_deconv4x4s2_nhwc_fwd(const float* x, int64_t B, int64_t Hi, int64_t Wi, int64_t Cin,
+                                       const float* w_sub, int64_t Cout, const float* scale, const float* shift,
+                                       int relu, float* y, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!x || !w_sub || !y || !scratch) PL_FAIL(PL_EINVAL, "pl_deconv4x4s2_nhwc_fwd: null pointer");
+  if (B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || (Cout & 3)) PL_FAIL(PL_ESHAPE, "pl_deconv4x4s2_nhwc_fwd: bad geometry");
+  if ((scale != nullptr) != (shift != nullptr)) PL_FAIL(PL_EINVAL, "pl_deconv4x4s2_nhwc_fwd: scale without shift");
+  const size_t part = (size_t)B * Hi * Wi * Cout;
+  if (scratch_bytes < 4 * part * sizeof(float)) PL_FAIL(PL_EWORKSPACE, "pl_deconv4x4s2_nhwc_fwd: scratch too small");
+  if (!implicit_ok(B * Hi * Wi, Cin, Cout, 4 * Cin))
+    PL_FAIL(PL_ESHAPE, "pl_deconv4x4s2_nhwc_fwd: needs Cin %% 32 == 0, Cout %% 128 == 0, B*Hi*Wi %% 128 == 0");
+  hipStream_t s = (hipStream_t)stream;
+  float* tmp = static_cast<float*>(scratch);
+  for (int par = 0; par < 4; ++par) {
+    const int ph = par >> 1, pw = par & 1;
+    // even output rows read input rows a-1, a (pad 1); odd ones a, a+1 (pad 0, the last tap runs off the edge)
+    PL_TRY(conv_core(x, B, Hi, Wi, Cin, w_sub + (size_t)par * Cout * 4 * Cin, Cout, 2, 2, 1, ph ? 0 : 1, pw ? 0 : 1,
+                     Hi, Wi, scale, shift, nullptr, relu, nullptr, tmp + par * part, nullptr, 0, s));
+  }
+  const int64_t n4 = (int64_t)(part >> 2);
+  hipLaunchKernelGGL(deconv_interleave_kernel, dim3((unsigned)((4 * n4 + NTHR - 1) / NTHR)), dim3(NTHR), 0, s, tmp,
+                     (int)Hi, (int)Wi, (int)Cout, n4, y);
+  PL_CHECK_LAUNCH("deconv_interleave");
+  return PL_OK;
+}
+
+extern "C" int pl_nhwc_to_nchw(const float* in, int64_t B, int64_t P, int64_t C, float* out, void* stream) {
+  if (!in || !out || in == out) PL_FAIL(PL_EINVAL, "pl_nhwc_to_nchw: null or aliased pointers");
+  if (B <= 0 || P <= 0 || C <= 0 || B > 65535) PL_FAIL(PL_ESHAPE, "pl_nhwc_to_nchw: bad shape");
+  dim3 grid((unsigned)((P + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(1024), 0, (hipStream_t)stream, in, (int)P, (int)C, out);
+  PL_CHECK_LAUNCH("nhwc_to_nchw");
+  return PL_OK;
+}

@@ -614,8 +614,8 @@ __device__ __forceinline__ ConvRow conv_row(const GemmArgs& p, int m) {
   const int oh = t % p.conv_ho, b = t / p.conv_ho;
   ConvRow r;
   r.base = p.A + (size_t)b * p.conv_h * p.conv_w * p.conv_cin;
-  r.ih0 = oh * p.conv_stride - p.conv_pad;
-  r.iw0 = ow * p.conv_stride - p.conv_pad;
+  r.ih0 = oh * p.conv_stride - p.conv_pad_h;
+  r.iw0 = ow * p.conv_stride - p.conv_pad_w;
   return r;
 }
 

@@ -59,7 +59,7 @@ struct GemmArgs {
   // Implicit-GEMM convolution (launch_conv_nhwc only; conv_cin == 0 otherwise): A is not a matrix but the
   // NHWC input x [B][H][W][Cin]; row m = (b, oh, ow), k = (kh*KW + kw)*Cin + ci, element
   // x[b][oh*stride - pad + kh][ow*stride - pad + kw][ci] or 0 outside the image.  B = weights [N][K] (OHWI).
-  int conv_cin, conv_h, conv_w, conv_ho, conv_wo, conv_kw, conv_stride, conv_pad;
+  int conv_cin, conv_h, conv_w, conv_ho, conv_wo, conv_kw, conv_stride, conv_pad_h, conv_pad_w;
 };
 
 // y = conv2d(x, w) as an implicit GEMM on the PL_BF16X6 planes pipeline; a.A = x, a.B = w [Cout][KH*KW*Cin],

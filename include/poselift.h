@@ -155,20 +155,41 @@ int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const float* target
                             void* workspace, size_t workspace_bytes, uint64_t seed, uint64_t step,
                             float* y, float* loss, float* flat_grads, int hi, int lo, void* stream);
 
-/* ---- convolution (first slice: forward) ---------------------------- */
-/* nn.Conv2d forward in NHWC as an implicit GEMM on the PL_BF16X6 pipeline (fp32-grade products), with the
- * Bottleneck's eval-mode epilogue folded in: phase4_joined/Resnet.py:51-95 (conv1/2/3 + bn + relu + residual),
- * :121-165 (downsample), phase4_joined/Model.py:66-69 (final 1x1 conv with bias).
+/* ---- convolution path (first slice: forward) ------------------------ */
+/* nn.Conv2d forward in NHWC with the Bottleneck's eval-mode epilogue folded in: phase4_joined/Resnet.py:51-95
+ * (conv1/2/3 + bn + relu + residual), :112-118 (7x7 stem), :151-158 (downsample), phase4_joined/Model.py:66-69
+ * (final 1x1 conv with bias).
  *   v = sum_{kh,kw,ci} x[b][oh*stride - pad + kh][ow*stride - pad + kw][ci] * w[co][kh][kw][ci]  (+ bias[co])
  *   v = v * scale[co] + shift[co]          (BatchNorm2d on running statistics, folded; or NULL)
  *   relu 1: v = max(v, 0), then v += resid;   relu 2: v += resid, then max(v, 0);   relu 0: v += resid
- * x [B][H][W][Cin], w [Cout][KH][KW][Cin] (OHWI), resid / y [B][Ho][Wo][Cout].  1x1 stride-1 convolutions are
- * plain GEMMs (any shape); the others need Cin % 32 == 0, Cout % 128 == 0 and B*Ho*Wo % 128 == 0 (PL_ESHAPE
- * otherwise: the 7x7 stem and the 64-wide layer1 convolutions are not covered yet). */
+ * x [B][H][W][Cin], w [Cout][KH][KW][Cin] (OHWI), resid / y [B][Ho][Wo][Cout].
+ * Cin % 32 == 0, Cout % 128 == 0 and B*Ho*Wo % 128 == 0: implicit GEMM on the PL_BF16X6 pipeline (fp32-grade
+ * products, no im2col buffer); 1x1 stride 1: a plain GEMM; anything else (the stem with Cin = 3, the 64-wide
+ * layer1 convolutions): explicit im2col into `scratch` (>= pl_conv2d_nhwc_scratch_bytes, 0 for the others). */
+size_t pl_conv2d_nhwc_scratch_bytes(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH,
+                                    int KW, int stride, int pad);
 int pl_conv2d_nhwc_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* w,
                        int64_t Cout, int KH, int KW, int stride, int pad, const float* scale,
                        const float* shift, const float* bias, int relu, const float* resid, float* y,
-                       void* stream);
+                       void* scratch, size_t scratch_bytes, void* stream);
+
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1)  phase4_joined/Resnet.py:119.  x [B][H][W][C], C % 4 == 0;
+ * y [B][(H-1)/2+1][(W-1)/2+1][C]. */
+int pl_maxpool3x3s2_nhwc(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream);
+
+/* nn.ConvTranspose2d(kernel_size=4, stride=2, padding=1, bias=False) + folded BatchNorm2d + ReLU
+ * phase4_joined/Model.py:47-63: x [B][Hi][Wi][Cin] -> y [B][2Hi][2Wi][Cout].  Each output parity
+ * (oh&1, ow&1) is a 2x2-tap convolution over the input: four implicit GEMMs at the INPUT resolution (no
+ * zero insertion, no wasted MACs) and one interleave pass.  w_sub [4][Cout][2][2][Cin]: parity
+ * (ph, pw) = index ph*2 + pw, tap (th, tw) = weight[ci][co][kh][kw] with kh = (ph ? 2 : 3) - 2*th, kw
+ * likewise.  Cin % 32 == 0, Cout % 128 == 0, B*Hi*Wi % 128 == 0.  scratch >= ..._scratch_bytes. */
+size_t pl_deconv4x4s2_nhwc_scratch_bytes(int64_t B, int64_t Hi, int64_t Wi, int64_t Cout);
+int pl_deconv4x4s2_nhwc_fwd(const float* x, int64_t B, int64_t Hi, int64_t Wi, int64_t Cin,
+                            const float* w_sub, int64_t Cout, const float* scale, const float* shift,
+                            int relu, float* y, void* scratch, size_t scratch_bytes, void* stream);
+
+/* [B][P][C] -> [B][C][P]: the head's NHWC logits to the [B][J*D][H*W] layout of pl_softargmax_fwd. */
+int pl_nhwc_to_nchw(const float* in, int64_t B, int64_t P, int64_t C, float* out, void* stream);
 
 /* ---- batch feed ------------------------------------------------------------------- */
 /* One batch of the DataLoader path (train_1.py:26-31,75-81: shuffle, collate, .float(), .to(device))

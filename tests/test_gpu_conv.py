@@ -45,6 +45,10 @@ def _ref(x_nhwc, w_oihw, stride, pad, scale, shift, bias, relu, resid):
     (2, 16, 512, 128, 1, 1, 0, True, 1, False, False),     # conv1 1x1 = plain GEMM
     (1, 8, 256, 1088, 1, 1, 0, False, 0, False, True),     # final 1x1 with bias, Cout not a tile multiple
     (4, 8, 64, 128, 3, 1, 1, False, 0, False, False),      # borders dominate: 8x8 maps
+    (2, 64, 3, 64, 7, 2, 3, True, 1, False, False),        # the 7x7 stem (Cin = 3): im2col fallback
+    (2, 16, 64, 64, 3, 1, 1, True, 1, False, False),       # layer1 conv2, 64 -> 64: im2col fallback
+    (2, 16, 256, 64, 1, 1, 0, True, 1, False, False),      # layer1 conv1 1x1, Cout = 64: edge GEMM
+    (3, 10, 32, 40, 3, 2, 1, False, 2, True, True),        # nothing aligned
 ])
 def test_conv2d_nhwc_vs_torch(pkg, B, H, Cin, Cout, k, stride, pad, bn, relu, res, bias):
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cin + Cout + k + stride)
@@ -66,9 +70,42 @@ def test_conv2d_nhwc_vs_torch(pkg, B, H, Cin, Cout, k, stride, pad, bn, relu, re
     assert bool((err <= bound).all()), float((err / bound).max())
 
 
-def test_conv2d_nhwc_rejects_what_it_does_not_cover(pkg):
-    x = torch.randn(2, 16, 16, 3, device=DEV)
-    with pytest.raises(pkg.PoseliftError, match="Cin"):
-        pkg.conv.conv2d_nhwc(x, torch.randn(128, 7, 7, 3, device=DEV), 2, 3)          # the 7x7 stem
+def test_conv_path_has_no_cpu_fallback(pkg):
     with pytest.raises(pkg.PoseliftError):
         pkg.conv.conv2d_nhwc(torch.randn(2, 16, 16, 64), torch.randn(128, 3, 3, 64))  # CPU tensors
+    with pytest.raises(pkg.PoseliftError):
+        pkg.conv.maxpool3x3s2_nhwc(torch.randn(2, 16, 16, 64))
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 128, 128, 64), (3, 9, 7, 8)])
+def test_maxpool_vs_torch(pkg, B, H, W, C):
+    x = torch.randn(B, H, W, C)
+    want = F.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    got = pkg.conv.maxpool3x3s2_nhwc(x.to(DEV)).cpu()
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("B,Hi,Cin,Cout,bn", [(2, 8, 2048, 256, True), (2, 16, 256, 256, True), (2, 8, 64, 128, False)])
+def test_deconv4x4s2_vs_torch(pkg, B, Hi, Cin, Cout, bn):
+    """Model.py:47-63 head layers: ConvTranspose2d(k=4, s=2, p=1, bias=False) + BN(eval) + ReLU."""
+    g = torch.Generator().manual_seed(Hi + Cin + Cout)
+    x = torch.randn(B, Hi, Hi, Cin, generator=g)
+    w = torch.randn(Cin, Cout, 4, 4, generator=g) / np.sqrt(Cin * 4)
+    scale = torch.rand(Cout, generator=g) + 0.5 if bn else None
+    shift = torch.randn(Cout, generator=g) if bn else None
+    want = F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), w.double(), stride=2, padding=1)
+    mag = F.conv_transpose2d(x.permute(0, 3, 1, 2).abs().double(), w.abs().double(), stride=2, padding=1)
+    if bn:
+        want = (want * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)).clamp_min(0)
+        mag = mag * scale.double().view(1, -1, 1, 1)
+    dv = lambda t: None if t is None else t.to(DEV)
+    got = pkg.conv.deconv4x4s2_nhwc(x.to(DEV), pkg.conv.deconv_subkernels(w).to(DEV), dv(scale), dv(shift), 1 if bn else 0)
+    assert got.shape == (B, 2 * Hi, 2 * Hi, Cout)
+    err = (got.cpu().double() - want.permute(0, 2, 3, 1)).abs()
+    bound = 4e-6 * mag.permute(0, 2, 3, 1) + 1e-6
+    assert bool((err <= bound).all()), float((err / bound).max())
+
+
+def test_nhwc_to_nchw(pkg):
+    x = torch.randn(3, 5, 7, 37)
+    assert torch.equal(pkg.conv.nhwc_to_nchw(x.to(DEV)).cpu(), x.permute(0, 3, 1, 2).contiguous())
