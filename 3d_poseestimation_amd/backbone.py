@@ -1,0 +1,151 @@
+"""phase4 model, inference path (first slice): ResNet-50 backbone + deconvolution head +
+integral soft-argmax, eval-mode forward on the HIP library, NHWC end to end.
+
+    ResNet    /root/reference/phase4_joined/Resnet.py:98-165  (Bottleneck :51-95)
+    Model_3D  /root/reference/phase4_joined/Model.py:11-137
+
+The modules below are PARAMETER CONTAINERS built from stock nn.Conv2d / nn.BatchNorm2d /
+nn.ConvTranspose2d in the reference's construction order, so `state_dict()` has the reference's keys and
+shapes (a reference checkpoint loads with load_state_dict) -- pinned by tests/golden/g9: the reference's
+ResNet("resnet50") imported and run as-is.  The arithmetic is conv.py's: every convolution with its
+BatchNorm (running statistics), ReLU and residual add folded into one launch.  Training-mode forward
+and backward of this path are not built yet (raises): the next slice of row N2.
+Unlike the reference constructor (Model.py:28-38) nothing is downloaded: weights are whatever is loaded.
+"""
+import torch
+import torch.nn as nn
+
+from . import conv
+from .heads import soft_argmax_3d
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes, momentum=0.1)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes, momentum=0.1)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4, momentum=0.1)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class ResNet(nn.Module):
+    """ResNet("resnet50" | "resnet101" | "resnet152"): the Bottleneck architectures of Resnet.py:104-110."""
+    LAYERS = {"resnet50": [3, 4, 6, 3], "resnet101": [3, 4, 23, 3], "resnet152": [3, 8, 36, 3]}
+
+    def __init__(self, architecture="resnet50"):
+        super().__init__()
+        if architecture not in self.LAYERS:
+            raise ValueError(f"{architecture}: only the Bottleneck ResNets are built (the reference uses resnet50)")
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64, eps=1e-5, momentum=0.1, affine=True)
+        blocks = self.LAYERS[architecture]
+        self.layer1 = self._make_layer(64, blocks[0])
+        self.layer2 = self._make_layer(128, blocks[1], stride=2)
+        self.layer3 = self._make_layer(256, blocks[2], stride=2)
+        self.layer4 = self._make_layer(512, blocks[3], stride=2)
+        self._cache = None
+
+    def _make_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, kernel_size=1, stride=stride, bias=False),
+                                       nn.BatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * 4
+        layers += [Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    # ---- folded weights: OHWI kernels and (scale, shift) per BatchNorm, rebuilt when a parameter changes
+    def _versions(self):
+        return tuple(t._version for t in list(self.parameters()) + list(self.buffers())) + \
+            tuple(t.data_ptr() for t in self.parameters())
+
+    def _folded(self):
+        v = self._versions()
+        if self._cache is None or self._cache[0] != v:
+            f = {}
+            for name, m in self.named_modules():
+                if isinstance(m, nn.Conv2d):
+                    f[name] = conv.to_ohwi(m.weight.detach().float())
+                elif isinstance(m, nn.BatchNorm2d):
+                    f[name] = conv.fold_bn(m)
+            self._cache = (v, {k: (tuple(t.detach() for t in x) if isinstance(x, tuple) else x) for k, x in f.items()})
+        return self._cache[1]
+
+    def forward(self, x_nhwc):
+        """x [B, H, W, 3] fp32 (NHWC, as the phase4 loader delivers frames, Model.py:88) -> [B, H/32, W/32, 2048]."""
+        if self.training:
+            raise NotImplementedError("the training-mode forward/backward of the conv path is not built yet")
+        f = self._folded()
+        with torch.no_grad():
+            s, b = f["bn1"]
+            x = conv.conv2d_nhwc(x_nhwc.float(), f["conv1"], 2, 3, s, b, relu=1)          # Resnet.py:137
+            x = conv.maxpool3x3s2_nhwc(x)
+            for li in (1, 2, 3, 4):
+                for bi, blk in enumerate(getattr(self, f"layer{li}")):
+                    p = f"layer{li}.{bi}"
+                    identity = x
+                    if blk.downsample is not None:                                          # :87-88
+                        s, b = f[p + ".downsample.1"]
+                        identity = conv.conv2d_nhwc(x, f[p + ".downsample.0"], blk.stride, 0, s, b)
+                    s, b = f[p + ".bn1"]
+                    out = conv.conv2d_nhwc(x, f[p + ".conv1"], 1, 0, s, b, relu=1)          # :67
+                    s, b = f[p + ".bn2"]
+                    out = conv.conv2d_nhwc(out, f[p + ".conv2"], blk.stride, 1, s, b, relu=1)   # :69
+                    s, b = f[p + ".bn3"]
+                    x = conv.conv2d_nhwc(out, f[p + ".conv3"], 1, 0, s, b, relu=2, resid=identity)  # :81-91
+        return x
+
+
+class Model_3D(nn.Module):
+    def __init__(self, architecture="resnet50"):
+        super().__init__()
+        self.deconv_dim = [256, 256, 256]
+        self.num_joints, self.depth_dim, self.height_dim, self.width_dim = 17, 64, 64, 64
+        self.preact = ResNet(architecture)
+        self.feature_channel = 2048
+        layers, cin = [], self.feature_channel
+        for cout in self.deconv_dim:                                                        # Model.py:47-69
+            layers += [nn.ConvTranspose2d(cin, cout, kernel_size=4, stride=2, padding=1, bias=False),
+                       nn.BatchNorm2d(cout), nn.ReLU(inplace=True)]
+            cin = cout
+        self.deconv_layers = nn.Sequential(*layers)
+        self.final_layer = nn.Conv2d(self.deconv_dim[2], self.num_joints * self.depth_dim, kernel_size=1)
+        self._cache = None
+
+    def _folded(self):
+        ts = list(self.deconv_layers.parameters()) + list(self.deconv_layers.buffers()) + list(self.final_layer.parameters())
+        v = tuple(t._version for t in ts) + tuple(t.data_ptr() for t in ts)
+        if self._cache is None or self._cache[0] != v:
+            f = {}
+            for i in (0, 3, 6):
+                f[i] = conv.deconv_subkernels(self.deconv_layers[i].weight.detach().float())
+                f[i + 1] = tuple(t.detach() for t in conv.fold_bn(self.deconv_layers[i + 1]))
+            f["final"] = conv.to_ohwi(self.final_layer.weight.detach().float())
+            self._cache = (v, f)
+        return self._cache[1]
+
+    def heatmap_logits(self, x_nhwc):
+        """[B, 256, 256, 3] -> [B, 1088, 64, 64]: everything in front of the soft-argmax."""
+        f = self._folded()
+        x0 = self.preact(x_nhwc)
+        with torch.no_grad():
+            out = x0
+            for i in (0, 3, 6):
+                out = conv.deconv4x4s2_nhwc(out, f[i], f[i + 1][0], f[i + 1][1], relu=1)
+            out = conv.conv2d_nhwc(out, f["final"], 1, 0, bias=self.final_layer.bias.detach())
+            return conv.nhwc_to_nchw(out)
+
+    def forward(self, x):
+        """x [B, 256, 256, 3] NHWC frames -> [B, 51] (x, y, z) per joint in (-1, 1)  (Model.py:83-137)."""
+        if self.training:
+            raise NotImplementedError("the training-mode forward/backward of the conv path is not built yet")
+        with torch.no_grad():
+            return soft_argmax_3d(self.heatmap_logits(x), self.num_joints, self.depth_dim)

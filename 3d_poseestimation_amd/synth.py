@@ -30,3 +30,30 @@ def synthetic_batch(n, seed, device="cpu"):
     y = torch.randn(n, 17, 3, generator=g) * torch.from_numpy(st["std_train_3d"])
     y[:, 0, :] = 0
     return x.to(device), y.to(device)
+
+
+def seeded_state(template, seed):
+    """Deterministic stand-in for a checkpoint: a state_dict with the template's keys and shapes, every tensor
+    drawn from its own torch CPU generator (seed, position).  Used where a fixture would otherwise have to carry
+    the weights themselves (ResNet-50 = 94 MB): tools/make_golden.py fills the REFERENCE model with it, the tests
+    fill ours, and only the reference's outputs are committed.  Conv / linear weights N(0, 2/fan_in), BatchNorm
+    gamma and running_var U(0.5, 1.5), beta / running_mean / biases N(0, 0.1^2)."""
+    out = {}
+    for idx, (k, v) in enumerate(template.items()):
+        g = torch.Generator().manual_seed(int(seed) * 100003 + idx)
+        if k.endswith("num_batches_tracked"):
+            out[k] = torch.tensor(7, dtype=v.dtype)
+        elif k.endswith("running_var") or (v.dim() == 1 and k.endswith(".weight")):
+            out[k] = torch.rand(v.shape, generator=g) + 0.5
+        elif v.dim() == 1:
+            out[k] = torch.randn(v.shape, generator=g) * 0.1
+        else:
+            fan_in = v[0].numel()
+            out[k] = torch.randn(v.shape, generator=g) * (2.0 / fan_in) ** 0.5
+    return out
+
+
+def seeded_frames(batch, seed, size=256):
+    """[batch, size, size, 3] NHWC frames in [0, 1) (the phase4 loader divides by 256)."""
+    g = torch.Generator().manual_seed(int(seed))
+    return torch.rand(batch, size, size, 3, generator=g)

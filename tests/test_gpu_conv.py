@@ -109,3 +109,59 @@ def test_deconv4x4s2_vs_torch(pkg, B, Hi, Cin, Cout, bn):
 def test_nhwc_to_nchw(pkg):
     x = torch.randn(3, 5, 7, 37)
     assert torch.equal(pkg.conv.nhwc_to_nchw(x.to(DEV)).cpu(), x.permute(0, 3, 1, 2).contiguous())
+
+
+def test_g9_resnet50_eval_forward_vs_reference(pkg):
+    """The phase4 backbone against phase4_joined/Resnet.py imported and run as-is (golden g9): same seeded
+    weights and frames (synth.seeded_state / seeded_frames), eval mode, 53 convolutions deep."""
+    from conftest import load_golden
+    g = load_golden("g9_resnet50_eval.npz")
+    net = pkg.ResNet("resnet50").eval()
+    net.load_state_dict(pkg.synth.seeded_state(net.state_dict(), int(g["weight_seed"])))
+    net = net.to(DEV)
+    frames = pkg.synth.seeded_frames(2, int(g["frame_seed"])).to(DEV)
+    feat = net(frames)                                        # NHWC [2, 8, 8, 2048]
+    assert tuple(feat.shape) == (2, 8, 8, 2048)
+    nchw = feat.permute(0, 3, 1, 2).contiguous().cpu()
+    assert tuple(nchw.shape) == tuple(g["shape"])
+    scale = float(g["abs_max"])
+    err = np.abs(nchw.reshape(-1)[::int(g["sample_stride"])].numpy().astype(np.float64) - g["sample"]).max()
+    assert err < 2e-4 * scale, (err, scale)                   # fp32 round-off through 53 layers, relative to the peak
+    cm = nchw.mean(dim=(0, 2, 3)).numpy()
+    assert np.abs(cm - g["channel_mean"]).max() < 2e-4 * scale
+    with pytest.raises(NotImplementedError):
+        net.train()(frames)
+
+
+def test_model3d_eval_forward_vs_torch_cpu(pkg):
+    """Model_3D.forward (phase4_joined/Model.py:83-137) end to end -- backbone, three deconvolutions, final
+    1x1 convolution, integral soft-argmax -- against the same stock nn modules run by PyTorch on the CPU plus
+    the soft-argmax oracle.  Model.py itself cannot be imported here (torchvision, pretrained download):
+    the head is restated from its text, PARITY UNPINNED beyond the backbone (g9)."""
+    from oracle import heads_oracle
+    m = pkg.Model_3D().eval()
+    m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 31))
+    with torch.no_grad():                                     # keep the logits in a range where the softmax is not one-hot
+        m.final_layer.weight.mul_(1e-4)
+        m.final_layer.bias.mul_(0.1)
+    frames = pkg.synth.seeded_frames(2, 32)
+    with torch.no_grad():                                     # plain PyTorch on the CPU, module by module
+        r = m.preact
+        x = frames.permute(0, 3, 1, 2)
+        x = F.max_pool2d(F.relu(r.bn1(r.conv1(x))), 3, 2, 1)
+        for li in (1, 2, 3, 4):
+            for blk in getattr(r, f"layer{li}"):
+                idn = x if blk.downsample is None else blk.downsample(x)
+                o = F.relu(blk.bn1(blk.conv1(x)))
+                o = F.relu(blk.bn2(blk.conv2(o)))
+                x = F.relu(blk.bn3(blk.conv3(o)) + idn)
+        logits_ref = m.final_layer(m.deconv_layers(x))
+    want = heads_oracle.soft_argmax(logits_ref.double().numpy(), 17, 64, True)
+    md = m.to(DEV)
+    logits = md.heatmap_logits(frames.to(DEV))
+    assert tuple(logits.shape) == (2, 1088, 64, 64)
+    lscale = float(logits_ref.abs().max())
+    assert float((logits.cpu() - logits_ref).abs().max()) < 3e-4 * lscale
+    got = md(frames.to(DEV)).cpu().numpy()
+    assert got.shape == (2, 51)
+    assert np.abs(got - want.reshape(2, 51)).max() < 2e-3     # coordinates in (-1, 1): 64 voxels per unit... 2e-3 = 0.06 voxel

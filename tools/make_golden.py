@@ -230,6 +230,25 @@ def main():
             g = leaves[k].grad
             rec[f"{tag}:grad:{k}"] = (g if g is not None else torch.zeros_like(leaves[k])).numpy().copy()
     np.savez_compressed(os.path.join(OUT, "g8_triangle_loss.npz"), **rec)
+    # ---- G9: phase4 backbone, phase4_joined/Resnet.py imported as-is, eval forward ------------
+    # Weights and frames come from synth.seeded_state / seeded_frames (94 MB of weights are not committed);
+    # the fixture holds what the reference computed: a strided sample of the (2, 2048, 8, 8) features,
+    # per-channel means and global moments.
+    import importlib
+    sys.path.insert(0, "/root/reference/phase4_joined")
+    import Resnet as ref_resnet  # noqa: E402  (the reference, imported as-is)
+    synth = importlib.import_module("3d_poseestimation_amd.synth")
+    net = ref_resnet.ResNet("resnet50").eval()
+    net.load_state_dict(synth.seeded_state(net.state_dict(), 909))
+    frames = synth.seeded_frames(2, 910)
+    with torch.no_grad():
+        feat = net(frames.permute(0, 3, 1, 2))                      # Model.py:88 permutes NHWC -> NCHW
+    flat = feat.reshape(-1)
+    np.savez_compressed(os.path.join(OUT, "g9_resnet50_eval.npz"), weight_seed=909, frame_seed=910,
+                        shape=np.array(feat.shape), sample_stride=5, sample=flat[::5].numpy().copy(),
+                        channel_mean=feat.mean(dim=(0, 2, 3)).numpy().copy(),
+                        abs_max=np.float64(feat.abs().max().item()), mean=np.float64(feat.double().mean().item()),
+                        sq_mean=np.float64((feat.double() ** 2).mean().item()))
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 
