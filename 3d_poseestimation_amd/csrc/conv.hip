@@ -100,7 +100,8 @@ __global__ __launch_bounds__(1024) void nhwc_to_nchw_kernel(const float* __restr
 }
 
 bool implicit_ok(int64_t M, int64_t Cin, int64_t Cout, int64_t K) {
-  return Cin % 32 == 0 && Cout % 128 == 0 && M % 128 == 0 && K % 32 == 0;
+  (void)Cout;                            // any width: a ragged last column tile is clamped and masked
+  return Cin % 32 == 0 && M % 128 == 0 && K % 32 == 0;
 }
 
 int conv_core(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* w, int64_t Cout, int KH,
@@ -120,9 +121,9 @@ int conv_core(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, cons
     g.conv_kw = KW; g.conv_stride = stride; g.conv_pad_h = pad_h; g.conv_pad_w = pad_w;
     return launch_conv_nhwc(g, s);
   }
-  // fallback: explicit im2col (rows padded to a multiple of 4 floats) + the generic GEMM
+  // fallback: explicit im2col (rows zero-padded to a multiple of 32 floats = whole K tiles) + the generic GEMM
   if (pad_h != pad_w) PL_FAIL(PL_ESHAPE, "conv: asymmetric padding only on the implicit path");
-  const int64_t Kp = (K + 3) / 4 * 4;
+  const int64_t Kp = (K + 31) / 32 * 32;
   const size_t need = ((size_t)M * Kp + (size_t)Cout * Kp) * sizeof(float);
   if (!scratch || scratch_bytes < need)
     PL_FAIL(PL_EWORKSPACE, "conv: this shape takes the im2col path and needs %zu scratch bytes (got %zu)", need,
@@ -153,7 +154,7 @@ extern "C" size_t pl_conv2d_nhwc_scratch_bytes(int64_t B, int64_t H, int64_t W, 
   if (Ho <= 0 || Wo <= 0) return 0;
   const int64_t M = B * Ho * Wo, K = (int64_t)KH * KW * Cin;
   if ((KH == 1 && KW == 1 && stride == 1 && pad == 0) || implicit_ok(M, Cin, Cout, K)) return 0;
-  const int64_t Kp = (K + 3) / 4 * 4;
+  const int64_t Kp = (K + 31) / 32 * 32;
   return ((size_t)M * Kp + (size_t)Cout * Kp) * sizeof(float);
 }
 
@@ -200,7 +201,7 @@ extern "C" int pl_deconv4x4s2_nhwc_fwd(const float* x, int64_t B, int64_t Hi, in
   const size_t part = (size_t)B * Hi * Wi * Cout;
   if (scratch_bytes < 4 * part * sizeof(float)) PL_FAIL(PL_EWORKSPACE, "pl_deconv4x4s2_nhwc_fwd: scratch too small");
   if (!implicit_ok(B * Hi * Wi, Cin, Cout, 4 * Cin))
-    PL_FAIL(PL_ESHAPE, "pl_deconv4x4s2_nhwc_fwd: needs Cin %% 32 == 0, Cout %% 128 == 0, B*Hi*Wi %% 128 == 0");
+    PL_FAIL(PL_ESHAPE, "pl_deconv4x4s2_nhwc_fwd: needs Cin %% 32 == 0 and B*Hi*Wi %% 128 == 0");
   hipStream_t s = (hipStream_t)stream;
   float* tmp = static_cast<float*>(scratch);
   for (int par = 0; par < 4; ++par) {

@@ -572,13 +572,15 @@ struct PCfg {
 //     BK 16: thread = (row = tid&127, octet = tid>>7):     eight floats;  v0 = k0..3, v1 = k4..7
 template <bool KS, int BKX>
 __device__ __forceinline__ void load_tile_p(Stage& s, const float* __restrict__ base, int ld, int r0, int k0,
-                                            int tid) {
+                                            int tid, int rmax = 0x7fffffff) {
   if (!KS && BKX == 32) {
-    const float* t = base + (size_t)r0 * ld + k0 + (size_t)(tid >> 2) * ld + (tid & 3) * 8;
-    s.v0 = *reinterpret_cast<const float4*>(t);
-    s.v1 = *reinterpret_cast<const float4*>(t + 4);
-    s.v2 = *reinterpret_cast<const float4*>(t + (size_t)64 * ld);
-    s.v3 = *reinterpret_cast<const float4*>(t + (size_t)64 * ld + 4);
+    // rmax: last valid row (N_EDGE launches: a ragged last column tile re-reads it; the epilogue drops those columns)
+    const float* t0 = base + (size_t)min(r0 + (tid >> 2), rmax) * ld + k0 + (tid & 3) * 8;
+    const float* t1 = base + (size_t)min(r0 + (tid >> 2) + 64, rmax) * ld + k0 + (tid & 3) * 8;
+    s.v0 = *reinterpret_cast<const float4*>(t0);
+    s.v1 = *reinterpret_cast<const float4*>(t0 + 4);
+    s.v2 = *reinterpret_cast<const float4*>(t1);
+    s.v3 = *reinterpret_cast<const float4*>(t1 + 4);
   } else if (!KS) {
     const float* t = base + (size_t)r0 * ld + k0 + (size_t)(tid >> 1) * ld + (tid & 1) * 8;
     s.v0 = *reinterpret_cast<const float4*>(t);
@@ -702,7 +704,9 @@ __device__ __forceinline__ void store_half_p(char* __restrict__ op, int tid, con
 //     element through the same L2 path.  Removed again.
 //   PMC (SQ_*): MFMA busy 46 % of wave cycles, WAIT_ANY 22 %, issue time of the ~5.6 non-MFMA instructions
 //   per MFMA gap not hidden (the guide's limit is <= 5 per 32x32x16 gap, hand-placed).
-template <bool A_KS, bool B_KS, int BKX, bool A_CONV = false>
+// N_EDGE (k-contiguous B, BK 32 only): N need not be a multiple of 128 -- the last column tile clamps its B
+// rows and the guarded epilogue drops the columns >= N (the 64-wide layer1 convolutions, the 1088-wide head).
+template <bool A_KS, bool B_KS, int BKX, bool A_CONV = false, bool N_EDGE = false>
 __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int block_id, const int nwork,
                                                  char* __restrict__ lds) {
   using Cf = PCfg<BKX>;
@@ -711,7 +715,9 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tiles_n = p.N / BN;
+  static_assert(!N_EDGE || (!B_KS && BKX == 32), "ragged N only with the k-contiguous BK 32 B loader");
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int nlast = N_EDGE ? p.N - 1 : 0x7fffffff;
   const int splits = p.split_k > 1 ? p.split_k : 1;
   const int ntiles = nwork / splits;
   int w = block_id;
@@ -791,7 +797,7 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
     if (do_load) {
       const int k0 = kbeg + (kt + 3) * BKX;
       load_a(la, k0);
-      load_tile_p<B_KS, BKX>(lb, p.B, p.ldb, n0, k0, tid);
+      load_tile_p<B_KS, BKX>(lb, p.B, p.ldb, n0, k0, tid, nlast);
     }
     if (KSTEPS == 2) {
       PL_FRAGS_P(1, cur, 1);
@@ -831,16 +837,16 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
   if (nk > 0) {
     // prologue: tiles 0 and 1 into stages 0 and 1, tile 2 into register set 0
     load_a(ra0, kbeg);
-    load_tile_p<B_KS, BKX>(rb0, p.B, p.ldb, n0, kbeg, tid);
+    load_tile_p<B_KS, BKX>(rb0, p.B, p.ldb, n0, kbeg, tid, nlast);
     if (nk > 1) {
       load_a(ra1, kbeg + BKX);
-      load_tile_p<B_KS, BKX>(rb1, p.B, p.ldb, n0, kbeg + BKX, tid);
+      load_tile_p<B_KS, BKX>(rb1, p.B, p.ldb, n0, kbeg + BKX, tid, nlast);
     }
     store_a(cur, H0{}, ra0); store_half_p<B_KS, BKX, 0>(cur + Cf::OPP, tid, rb0);
     if (KSTEPS == 2) { store_a(cur, H1{}, ra0); store_half_p<B_KS, BKX, 1>(cur + Cf::OPP, tid, rb0); }
     if (nk > 2) {
       load_a(ra0, kbeg + 2 * BKX);
-      load_tile_p<B_KS, BKX>(rb0, p.B, p.ldb, n0, kbeg + 2 * BKX, tid);
+      load_tile_p<B_KS, BKX>(rb0, p.B, p.ldb, n0, kbeg + 2 * BKX, tid, nlast);
     }
     if (nk > 1) {
       store_a(nx1, H0{}, ra1); store_half_p<B_KS, BKX, 0>(nx1 + Cf::OPP, tid, rb1);
@@ -864,7 +870,7 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
 #undef PL_MF6
 #undef PL_MFMAS_ROW
 #undef PL_MFMAS_P
-  gemm_epilogue<false, 2>(p, C, acc, m0, n0, wm, wn, i, h);
+  gemm_epilogue<N_EDGE, 2>(p, C, acc, m0, n0, wm, wn, i, h);
 }
 
 template <bool A_KS, bool B_KS>
@@ -873,9 +879,15 @@ __global__ __launch_bounds__(256) void gemm_x6_planes_kernel(GemmArgs p) {
   gemm_body_planes<A_KS, B_KS, 32>(p, blockIdx.x, gridDim.x, lds);
 }
 
+template <bool N_EDGE>
 __global__ __launch_bounds__(256) void conv_x6_planes_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[PCfg<32>::LDS];
-  gemm_body_planes<false, false, 32, true>(p, blockIdx.x, gridDim.x, lds);
+  gemm_body_planes<false, false, 32, true, N_EDGE>(p, blockIdx.x, gridDim.x, lds);
+}
+
+__global__ __launch_bounds__(256) void gemm_x6_planes_nedge_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[PCfg<32>::LDS];
+  gemm_body_planes<false, false, 32, false, true>(p, blockIdx.x, gridDim.x, lds);
 }
 
 // backward pair in one launch (see gemm_f32_dual_kernel): BK 16, two workgroups per CU
@@ -1004,13 +1016,15 @@ int launch_gemm_f32_pair(const GemmArgs& nn, const GemmArgs& tn, hipStream_t s) 
 
 int launch_conv_nhwc(const GemmArgs& a, hipStream_t s) {
   if (!a.A || !a.B || !a.C) PL_FAIL(PL_EINVAL, "conv: null operand");
-  if (a.conv_cin <= 0 || a.conv_cin % 32 || a.M % BM || a.N % BN || a.K % BK || a.K % a.conv_cin || a.split_k > 1)
-    PL_FAIL(PL_ESHAPE, "conv: needs Cin %% 32 == 0, Cout %% 128 == 0, B*Ho*Wo %% 128 == 0 (M=%d N=%d K=%d Cin=%d)",
+  if (a.conv_cin <= 0 || a.conv_cin % 32 || a.M % BM || a.N < 1 || a.K % BK || a.K % a.conv_cin || a.split_k > 1)
+    PL_FAIL(PL_ESHAPE, "conv: needs Cin %% 32 == 0 and B*Ho*Wo %% 128 == 0 (M=%d N=%d K=%d Cin=%d)",
             a.M, a.N, a.K, a.conv_cin);
   if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15)
     PL_FAIL(PL_EINVAL, "conv: operands not 16-byte aligned");
   ProfRec* prof = prof_begin(a, s);
-  hipLaunchKernelGGL(conv_x6_planes_kernel, dim3((a.M / BM) * (a.N / BN)), dim3(NTHR), 0, s, a);
+  const dim3 grid((a.M / BM) * ((a.N + BN - 1) / BN));
+  if (a.N % BN) hipLaunchKernelGGL(conv_x6_planes_kernel<true>, grid, dim3(NTHR), 0, s, a);
+  else hipLaunchKernelGGL(conv_x6_planes_kernel<false>, grid, dim3(NTHR), 0, s, a);
   if (prof) (void)hipEventRecord(prof->e1, s);
   PL_CHECK_LAUNCH("conv_x6_planes");
   return PL_OK;
@@ -1044,6 +1058,16 @@ int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s) {
     else if (whole) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false>), grid, block, lds_bytes, s, a);      \
     else hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, true>), grid, block, lds_bytes, s, a);             \
   } while (0)
+  // NT, PL_BF16X6, whole M and K tiles but a ragged N: the planes kernel with clamped B rows + guarded stores
+  const bool nt_ragged_n = layout == kNT && a.arith == 2 && x6_planes_default() && !whole && a.split_k <= 1 &&
+                           a.M % BM == 0 && a.K % BK == 0 && a.lda % 4 == 0 && a.ldb % 4 == 0 &&
+                           ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) == 0;
+  if (nt_ragged_n) {
+    hipLaunchKernelGGL(gemm_x6_planes_nedge_kernel, grid, block, lds_bytes, s, a);
+    if (prof) (void)hipEventRecord(prof->e1, s);
+    PL_CHECK_LAUNCH("gemm_x6_planes_nedge");
+    return PL_OK;
+  }
   switch (layout) {
     case kNT: PL_GEMM_LAUNCH(false, false); break;
     case kNN: PL_GEMM_LAUNCH(false, true); break;
