@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import conv
-from .heads import soft_argmax_3d
+from .heads import soft_argmax_3d, soft_argmax_3d_nhwc
 
 
 class Bottleneck(nn.Module):
@@ -132,20 +132,25 @@ class Model_3D(nn.Module):
             self._cache = (v, f)
         return self._cache[1]
 
-    def heatmap_logits(self, x_nhwc):
-        """[B, 256, 256, 3] -> [B, 1088, 64, 64]: everything in front of the soft-argmax."""
+    def heatmap_logits_nhwc(self, x_nhwc):
+        """[B, 256, 256, 3] -> [B, 64, 64, 1088]: everything in front of the soft-argmax, in the path's layout."""
         f = self._folded()
         x0 = self.preact(x_nhwc)
         with torch.no_grad():
             out = x0
             for i in (0, 3, 6):
                 out = conv.deconv4x4s2_nhwc(out, f[i], f[i + 1][0], f[i + 1][1], relu=1)
-            out = conv.conv2d_nhwc(out, f["final"], 1, 0, bias=self.final_layer.bias.detach())
-            return conv.nhwc_to_nchw(out)
+            return conv.conv2d_nhwc(out, f["final"], 1, 0, bias=self.final_layer.bias.detach())
+
+    def heatmap_logits(self, x_nhwc):
+        """The same in the reference's layout [B, 1088, 64, 64] (Model.py:91)."""
+        return conv.nhwc_to_nchw(self.heatmap_logits_nhwc(x_nhwc))
 
     def forward(self, x):
         """x [B, 256, 256, 3] NHWC frames -> [B, 51] (x, y, z) per joint in (-1, 1)  (Model.py:83-137)."""
         if self.training:
             raise NotImplementedError("the training-mode forward/backward of the conv path is not built yet")
         with torch.no_grad():
+            if self.depth_dim == 64:
+                return soft_argmax_3d_nhwc(self.heatmap_logits_nhwc(x), self.num_joints)
             return soft_argmax_3d(self.heatmap_logits(x), self.num_joints, self.depth_dim)

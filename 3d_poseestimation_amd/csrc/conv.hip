@@ -204,12 +204,21 @@ extern "C" int pl_deconv4x4s2_nhwc_fwd(const float* x, int64_t B, int64_t Hi, in
     PL_FAIL(PL_ESHAPE, "pl_deconv4x4s2_nhwc_fwd: needs Cin %% 32 == 0 and B*Hi*Wi %% 128 == 0");
   hipStream_t s = (hipStream_t)stream;
   float* tmp = static_cast<float*>(scratch);
+  GemmArgs g4[4];
   for (int par = 0; par < 4; ++par) {
     const int ph = par >> 1, pw = par & 1;
+    GemmArgs g = {};
+    g.A = x; g.B = w_sub + (size_t)par * Cout * 4 * Cin; g.C = tmp + par * part;
+    g.M = (int)(B * Hi * Wi); g.N = (int)Cout; g.K = (int)(4 * Cin);
+    g.lda = g.K; g.ldb = g.K; g.ldc = (int)Cout; g.split_k = 1;
+    g.col_scale = scale; g.col_shift = shift; g.relu = relu; g.arith = PL_BF16X6;
+    g.conv_cin = (int)Cin; g.conv_h = (int)Hi; g.conv_w = (int)Wi; g.conv_ho = (int)Hi; g.conv_wo = (int)Wi;
+    g.conv_kw = 2; g.conv_stride = 1;
     // even output rows read input rows a-1, a (pad 1); odd ones a, a+1 (pad 0, the last tap runs off the edge)
-    PL_TRY(conv_core(x, B, Hi, Wi, Cin, w_sub + (size_t)par * Cout * 4 * Cin, Cout, 2, 2, 1, ph ? 0 : 1, pw ? 0 : 1,
-                     Hi, Wi, scale, shift, nullptr, relu, nullptr, tmp + par * part, nullptr, 0, s));
+    g.conv_pad_h = ph ? 0 : 1; g.conv_pad_w = pw ? 0 : 1;
+    g4[par] = g;
   }
+  PL_TRY(launch_conv_nhwc_group4(g4, s));
   const int64_t n4 = (int64_t)(part >> 2);
   hipLaunchKernelGGL(deconv_interleave_kernel, dim3((unsigned)((4 * n4 + NTHR - 1) / NTHR)), dim3(NTHR), 0, s, tmp,
                      (int)Hi, (int)Wi, (int)Cout, n4, y);

@@ -934,6 +934,15 @@ __global__ __launch_bounds__(256) void conv_x6_planes_kernel(GemmArgs p) {
   gemm_body_planes<false, false, 32, true, N_EDGE>(p, blockIdx.x, gridDim.x, lds);
 }
 
+struct GemmArgs4 { GemmArgs g[4]; };
+
+template <bool N_EDGE>
+__global__ __launch_bounds__(256) void conv_x6_planes_group4_kernel(GemmArgs4 P, int per) {
+  __shared__ __attribute__((aligned(16))) char lds[PCfg<32>::LDS];
+  const int g = blockIdx.x / per;
+  gemm_body_planes<false, false, 32, true, N_EDGE>(P.g[g], blockIdx.x - g * per, per, lds);
+}
+
 __global__ __launch_bounds__(256) void gemm_x6_planes_nedge_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[PCfg<32>::LDS];
   gemm_body_planes<false, false, 32, false, true>(p, blockIdx.x, gridDim.x, lds);
@@ -1076,6 +1085,30 @@ int launch_conv_nhwc(const GemmArgs& a, hipStream_t s) {
   else hipLaunchKernelGGL(conv_x6_planes_kernel<false>, grid, dim3(NTHR), 0, s, a);
   if (prof) (void)hipEventRecord(prof->e1, s);
   PL_CHECK_LAUNCH("conv_x6_planes");
+  return PL_OK;
+}
+
+int launch_conv_nhwc_group4(const GemmArgs* a, hipStream_t s) {
+  GemmArgs4 P;
+  for (int g = 0; g < 4; ++g) {
+    const GemmArgs& q = a[g];
+    if (!q.A || !q.B || !q.C) PL_FAIL(PL_EINVAL, "conv group: null operand");
+    if (q.M != a[0].M || q.N != a[0].N || q.K != a[0].K || q.conv_cin != a[0].conv_cin)
+      PL_FAIL(PL_ESHAPE, "conv group: the four problems must have one shape");
+    if (q.conv_cin <= 0 || q.conv_cin % 32 || q.M % BM || q.N < 1 || q.K % BK || q.K % q.conv_cin || q.split_k > 1)
+      PL_FAIL(PL_ESHAPE, "conv group: needs Cin %% 32 == 0 and B*Ho*Wo %% 128 == 0");
+    if ((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.B)) & 15)
+      PL_FAIL(PL_EINVAL, "conv group: operands not 16-byte aligned");
+    P.g[g] = q;
+  }
+  const int per = (a[0].M / BM) * ((a[0].N + BN - 1) / BN);
+  GemmArgs all = a[0];
+  ProfRec* prof = prof_begin(all, s);
+  if (prof) prof->flops *= 4.0;
+  if (a[0].N % BN) hipLaunchKernelGGL(conv_x6_planes_group4_kernel<true>, dim3(4 * per), dim3(NTHR), 0, s, P, per);
+  else hipLaunchKernelGGL(conv_x6_planes_group4_kernel<false>, dim3(4 * per), dim3(NTHR), 0, s, P, per);
+  if (prof) (void)hipEventRecord(prof->e1, s);
+  PL_CHECK_LAUNCH("conv_x6_planes_group4");
   return PL_OK;
 }
 

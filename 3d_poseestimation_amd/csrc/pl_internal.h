@@ -65,6 +65,9 @@ struct GemmArgs {
 // y = conv2d(x, w) as an implicit GEMM on the PL_BF16X6 planes pipeline; a.A = x, a.B = w [Cout][KH*KW*Cin],
 // a.M = B*Ho*Wo, a.N = Cout, a.K = KH*KW*Cin and the conv_* fields filled in; whole tiles only.
 int launch_conv_nhwc(const GemmArgs& a, hipStream_t s);
+// four independent convolutions of identical shape (the four output parities of a stride-2 transposed
+// convolution) in ONE launch: at 8x8 / 16x16 input maps a single one fills a quarter of the CUs
+int launch_conv_nhwc_group4(const GemmArgs* a, hipStream_t s);
 
 int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s);
 int launch_gemm_f32_pair(const GemmArgs& nn, const GemmArgs& tn, hipStream_t s);

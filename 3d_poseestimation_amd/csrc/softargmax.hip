@@ -86,6 +86,66 @@ __global__ __launch_bounds__(NTHR) void softargmax_fwd_kernel(const float* __res
   }
 }
 
+// The same forward on NHWC logits [B][H*W][J*64] (depth 64 = one lane per depth slice): what the conv
+// path's final 1x1 convolution writes, so Model_3D inference needs no NHWC -> NCHW pass (1.1 GB read + written
+// at B = 64).  One workgroup per (batch, joint); a wavefront reads one pixel's 64 depths (256 B) per load.
+__global__ __launch_bounds__(NTHR) void softargmax_nhwc_fwd_kernel(const float* __restrict__ logits, int J, int H,
+                                                                   int W, float* __restrict__ coords,
+                                                                   float* __restrict__ stats) {
+  __shared__ Acc sm[NTHR / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / J, j = blockIdx.x - b * J;
+  const int P = H * W, C = J * 64;
+  const float* __restrict__ src = logits + (size_t)b * P * C + j * 64 + lane;
+  Acc a = {-INFINITY, 0.f, 0.f, 0.f, 0.f};
+  for (int p0 = wave; p0 < P; p0 += 4 * (NTHR / 64)) {
+    float v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = p0 + q * (NTHR / 64);
+      v[q] = p < P ? src[(size_t)p * C] : -INFINITY;
+    }
+    const float mx = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    if (mx > a.m) {
+      const float f = (a.m == -INFINITY) ? 0.f : __expf(a.m - mx);
+      a.s *= f; a.x *= f; a.y *= f; a.z *= f;
+      a.m = mx;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int p = p0 + q * (NTHR / 64);
+      if (p < P) {
+        const float e = __expf(v[q] - a.m);
+        a.s += e;
+        a.x = fmaf(e, (float)(p % W), a.x);
+        a.y = fmaf(e, (float)(p / W), a.y);
+      }
+    }
+  }
+  a.z = a.s * (float)lane;                   // this lane's depth index, weight = its whole mass
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Acc t;
+    t.m = __shfl_xor(a.m, o); t.s = __shfl_xor(a.s, o); t.x = __shfl_xor(a.x, o);
+    t.y = __shfl_xor(a.y, o); t.z = __shfl_xor(a.z, o);
+    merge(a, t);
+  }
+  if (lane == 0) sm[wave] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Acc t = sm[0];
+    for (int w = 1; w < NTHR / 64; ++w) merge(t, sm[w]);
+    const float inv = 1.0f / t.s;
+    const float ex = t.x * inv, ey = t.y * inv, ez = t.z * inv;
+    float* st = stats + (size_t)blockIdx.x * 5;
+    st[0] = t.m; st[1] = t.s; st[2] = ex; st[3] = ey; st[4] = ez;
+    float* c = coords + (size_t)blockIdx.x * 3;
+    c[0] = (ex / (float)W - 0.5f) * 2.f;
+    c[1] = (ey / (float)H - 0.5f) * 2.f;
+    c[2] = (ez / 64.f - 0.5f) * 2.f;
+  }
+}
+
 // grid = (chunks, BJ): dlogit = p * (gx*cx*(w-Ex) + gy*cy*(h-Ey) + gz*cz*(d-Ez))
 __global__ __launch_bounds__(NTHR) void softargmax_bwd_kernel(const float* __restrict__ logits,
                                                               const float* __restrict__ stats,
@@ -156,5 +216,16 @@ extern "C" int pl_softargmax_bwd(const float* logits, const float* stats, const 
   hipLaunchKernelGGL(softargmax_bwd_kernel, dim3(chunks, (unsigned)BJ), dim3(NTHR), 0, (hipStream_t)stream, logits,
                      stats, gcoords, (int)D, (int)H, (int)W, centred, ncoord, dlogits);
   PL_CHECK_LAUNCH("softargmax_bwd");
+  return PL_OK;
+}
+
+extern "C" int pl_softargmax3d_nhwc_fwd(const float* logits, int64_t B, int64_t J, int64_t H, int64_t W,
+                                        float* coords, float* stats, void* stream) {
+  if (!logits || !coords || !stats) PL_FAIL(PL_EINVAL, "pl_softargmax3d_nhwc_fwd: null pointer");
+  if (B <= 0 || J <= 0 || H <= 0 || W <= 0 || B * J > 0x7fffffff || H * W > (1 << 24))
+    PL_FAIL(PL_ESHAPE, "pl_softargmax3d_nhwc_fwd: bad dims");
+  hipLaunchKernelGGL(softargmax_nhwc_fwd_kernel, dim3((unsigned)(B * J)), dim3(NTHR), 0, (hipStream_t)stream, logits,
+                     (int)J, (int)H, (int)W, coords, stats);
+  PL_CHECK_LAUNCH("softargmax_nhwc_fwd");
   return PL_OK;
 }

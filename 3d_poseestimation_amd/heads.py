@@ -53,3 +53,21 @@ def soft_argmax_2d(out, num_joints=17):
         raise ValueError(f"expected {num_joints} channels, got {C}")
     x = out.contiguous().float()
     return _SoftArgmaxFn.apply(x, B * num_joints, 1, H, W, 2, 0).reshape(B, num_joints * 2)
+
+
+@torch.no_grad()
+def soft_argmax_3d_nhwc(out, num_joints=17):
+    """(B, H, W, num_joints*64) NHWC logits (depth_dim 64) -> (B, num_joints*3); inference only (no backward
+    on this layout yet): what Model_3D's final 1x1 convolution writes, read in place."""
+    x = out.contiguous()
+    _lib.require_device_tensor(x, "heat-map logits")
+    B, H, W, C = x.shape
+    if C != num_joints * 64:
+        raise ValueError(f"expected {num_joints * 64} channels (depth 64), got {C}")
+    coords = torch.empty(B * num_joints, 3, dtype=torch.float32, device=x.device)
+    stats = torch.empty(B * num_joints, 5, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().pl_softargmax3d_nhwc_fwd(x.data_ptr(), B, num_joints, H, W, coords.data_ptr(), stats.data_ptr(),
+                                                 _lib.current_stream_ptr())
+    _lib.check(rc, "pl_softargmax3d_nhwc_fwd")
+    return coords.reshape(B, num_joints * 3)

@@ -155,6 +155,11 @@ int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const float* target
                             void* workspace, size_t workspace_bytes, uint64_t seed, uint64_t step,
                             float* y, float* loss, float* flat_grads, int hi, int lo, void* stream);
 
+/* The 3-D head forward on NHWC logits [B][H][W][J*64] (depth_dim 64, the conv path's layout): same
+ * coords [B*J][3] and stats [B*J][5] as pl_softargmax_fwd(ncoord 3, centred 1).  Model.py:94-133. */
+int pl_softargmax3d_nhwc_fwd(const float* logits, int64_t B, int64_t J, int64_t H, int64_t W,
+                             float* coords, float* stats, void* stream);
+
 /* ---- convolution path (first slice: forward) ------------------------ */
 /* nn.Conv2d forward in NHWC with the Bottleneck's eval-mode epilogue folded in: phase4_joined/Resnet.py:51-95
  * (conv1/2/3 + bn + relu + residual), :112-118 (7x7 stem), :151-158 (downsample), phase4_joined/Model.py:66-69

@@ -82,3 +82,14 @@ def test_soft_argmax_properties_and_errors(pkg):
         pkg.soft_argmax_3d(torch.zeros(1, 17 * 63, 64, 64, device=DEV))
     with pytest.raises(pkg.PoseliftError):
         pkg.soft_argmax_2d(torch.zeros(1, 17, 64, 64))              # CPU tensor: no fallback
+
+
+def test_soft_argmax_3d_nhwc_matches_the_nchw_kernel_and_oracle(pkg):
+    """The NHWC-layout forward (what the conv path's final layer writes) against the NCHW kernel and the oracle."""
+    from oracle import heads_oracle
+    torch.manual_seed(5)
+    x = torch.randn(3, 1088, 16, 24) * 3
+    want = heads_oracle.soft_argmax(x.double().numpy(), 17, 64, True)
+    got = pkg.soft_argmax_3d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV)).cpu().numpy()
+    ref = pkg.soft_argmax_3d(x.to(DEV)).cpu().numpy()
+    assert np.abs(got - want).max() < 2e-5 and np.abs(got - ref).max() < 2e-5
