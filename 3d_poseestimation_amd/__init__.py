@@ -9,6 +9,6 @@ from .optim import FlatAdamW  # noqa: F401
 from .train import epoch_mpjpe_mm, eval_step, flip_pose, loss_MPJPE, mse_loss, predict_flip_tta, train_step  # noqa: F401
 from .heads import soft_argmax_2d, soft_argmax_3d, soft_argmax_3d_nhwc  # noqa: F401
 from .losses import TriangleLoss, l1_loss, l1_terms  # noqa: F401
-from .backbone import Model_3D, ResNet  # noqa: F401
+from .backbone import Model_2D, Model_3D, ResNet  # noqa: F401
 from .data import PoseFeeder, epoch_indices  # noqa: F401
 from . import backbone, conv, data, dp, layout, synth  # noqa: F401

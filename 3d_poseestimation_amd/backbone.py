@@ -3,6 +3,7 @@ integral soft-argmax, eval-mode forward on the HIP library, NHWC end to end.
 
     ResNet    /root/reference/phase4_joined/Resnet.py:98-165  (Bottleneck :51-95)
     Model_3D  /root/reference/phase4_joined/Model.py:11-137
+    Model_2D  /root/reference/phase5_loop/Model_2d.py:13-138   (depth_dim 1, 17 heat-maps, coordinates in (0, 1))
 
 The modules below are PARAMETER CONTAINERS built from stock nn.Conv2d / nn.BatchNorm2d /
 nn.ConvTranspose2d in the reference's construction order, so `state_dict()` has the reference's keys and
@@ -16,7 +17,7 @@ import torch
 import torch.nn as nn
 
 from . import conv
-from .heads import soft_argmax_3d, soft_argmax_3d_nhwc
+from .heads import soft_argmax_2d, soft_argmax_3d, soft_argmax_3d_nhwc
 
 
 class Bottleneck(nn.Module):
@@ -104,15 +105,17 @@ class ResNet(nn.Module):
         return x
 
 
-class Model_3D(nn.Module):
-    def __init__(self, architecture="resnet50"):
+class _HeatmapNet(nn.Module):
+    """Backbone + three transposed convolutions + final 1x1 convolution: the part Model_3D and Model_2D share."""
+
+    def __init__(self, depth_dim, architecture="resnet50"):
         super().__init__()
         self.deconv_dim = [256, 256, 256]
-        self.num_joints, self.depth_dim, self.height_dim, self.width_dim = 17, 64, 64, 64
+        self.num_joints, self.depth_dim, self.height_dim, self.width_dim = 17, depth_dim, 64, 64
         self.preact = ResNet(architecture)
         self.feature_channel = 2048
         layers, cin = [], self.feature_channel
-        for cout in self.deconv_dim:                                                        # Model.py:47-69
+        for cout in self.deconv_dim:                                          # Model.py:47-69 / Model_2d.py:48-71
             layers += [nn.ConvTranspose2d(cin, cout, kernel_size=4, stride=2, padding=1, bias=False),
                        nn.BatchNorm2d(cout), nn.ReLU(inplace=True)]
             cin = cout
@@ -133,7 +136,7 @@ class Model_3D(nn.Module):
         return self._cache[1]
 
     def heatmap_logits_nhwc(self, x_nhwc):
-        """[B, 256, 256, 3] -> [B, 64, 64, 1088]: everything in front of the soft-argmax, in the path's layout."""
+        """[B, 256, 256, 3] -> [B, 64, 64, J*depth]: everything in front of the soft-argmax, in the path's layout."""
         f = self._folded()
         x0 = self.preact(x_nhwc)
         with torch.no_grad():
@@ -143,14 +146,34 @@ class Model_3D(nn.Module):
             return conv.conv2d_nhwc(out, f["final"], 1, 0, bias=self.final_layer.bias.detach())
 
     def heatmap_logits(self, x_nhwc):
-        """The same in the reference's layout [B, 1088, 64, 64] (Model.py:91)."""
+        """The same in the reference's layout [B, J*depth, 64, 64] (Model.py:91)."""
         return conv.nhwc_to_nchw(self.heatmap_logits_nhwc(x_nhwc))
+
+    def _check_eval(self):
+        if self.training:
+            raise NotImplementedError("the training-mode forward/backward of the conv path is not built yet")
+
+
+class Model_3D(_HeatmapNet):
+    def __init__(self, architecture="resnet50"):
+        super().__init__(64, architecture)
 
     def forward(self, x):
         """x [B, 256, 256, 3] NHWC frames -> [B, 51] (x, y, z) per joint in (-1, 1)  (Model.py:83-137)."""
-        if self.training:
-            raise NotImplementedError("the training-mode forward/backward of the conv path is not built yet")
+        self._check_eval()
         with torch.no_grad():
-            if self.depth_dim == 64:
-                return soft_argmax_3d_nhwc(self.heatmap_logits_nhwc(x), self.num_joints)
-            return soft_argmax_3d(self.heatmap_logits(x), self.num_joints, self.depth_dim)
+            return soft_argmax_3d_nhwc(self.heatmap_logits_nhwc(x), self.num_joints)
+
+
+class Model_2D(_HeatmapNet):
+    def __init__(self, architecture="resnet50"):
+        super().__init__(1, architecture)
+
+    def forward(self, x):
+        """x [B, 3, 256, 256] NCHW frames (Model_2d.py:91 leaves the permute commented out) -> [B, 34]
+        (x, y) per joint in (0, 1)  (Model_2d.py:87-136)."""
+        self._check_eval()
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"Model_2D expects NCHW frames [B, 3, H, W], got {tuple(x.shape)}")
+        with torch.no_grad():
+            return soft_argmax_2d(self.heatmap_logits(x.permute(0, 2, 3, 1).contiguous()), self.num_joints)

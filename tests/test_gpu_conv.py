@@ -165,3 +165,29 @@ def test_model3d_eval_forward_vs_torch_cpu(pkg):
     got = md(frames.to(DEV)).cpu().numpy()
     assert got.shape == (2, 51)
     assert np.abs(got - want.reshape(2, 51)).max() < 2e-3     # coordinates in (-1, 1): 64 voxels per unit... 2e-3 = 0.06 voxel
+
+
+def test_model2d_eval_forward_vs_torch_cpu(pkg):
+    """Model_2D.forward (phase5_loop/Model_2d.py:87-136: NCHW frames, 17 heat-maps, coordinates c/64 in (0, 1))
+    against the same stock modules on the CPU + the oracle.  Restated from text: PARITY UNPINNED beyond g9."""
+    from oracle import heads_oracle
+    m = pkg.Model_2D().eval()
+    m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 41))
+    with torch.no_grad():
+        m.final_layer.weight.mul_(1e-4)
+    frames = pkg.synth.seeded_frames(2, 42).permute(0, 3, 1, 2).contiguous()          # NCHW
+    with torch.no_grad():
+        r = m.preact
+        x = F.max_pool2d(F.relu(r.bn1(r.conv1(frames))), 3, 2, 1)
+        for li in (1, 2, 3, 4):
+            for blk in getattr(r, f"layer{li}"):
+                idn = x if blk.downsample is None else blk.downsample(x)
+                o = F.relu(blk.bn1(blk.conv1(x)))
+                o = F.relu(blk.bn2(blk.conv2(o)))
+                x = F.relu(blk.bn3(blk.conv3(o)) + idn)
+        logits_ref = m.final_layer(m.deconv_layers(x))
+    want = heads_oracle.soft_argmax(logits_ref.double().numpy(), 17, 1, False)
+    got = m.to(DEV)(frames.to(DEV)).cpu().numpy()
+    assert got.shape == (2, 34) and np.abs(got - want.reshape(2, 34)).max() < 1e-3
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 256, 256, 3, device=DEV))
