@@ -39,10 +39,10 @@ typedef enum PLStatus {
 } PLStatus;
 
 /* arithmetic of the 1024-wide GEMMs (storage is fp32 in every mode):
- *   PL_F32     v_mfma_f32_32x32x2_f32, exact fp32 products                  (parity-gated default)
+ *   PL_F32     v_mfma_f32_32x32x2_f32, exact fp32 products                  (meets the 1e-3 mm gate)
  *   PL_BF16    operands rounded to bf16, v_mfma_f32_32x32x16_bf16           (~1 mm MPJPE)
  *   PL_BF16X6  each fp32 operand split into 3 bf16 pieces, 6 bf16 MFMAs per product term:
- *              fp32-grade results at 6/16 of the fp32 matrix time */
+ *              fp32-grade results (meets the gate too) at 6/16 of the fp32 matrix time; what bench.py runs */
 typedef enum PLDtype { PL_F32 = 0, PL_BF16 = 1, PL_BF16X6 = 2 } PLDtype;
 
 /* Cross-rank BatchNorm statistics ("SyncBN"; data-parallel extension, SURVEY 8e -- the reference is
