@@ -100,8 +100,8 @@ __global__ __launch_bounds__(1024) void nhwc_to_nchw_kernel(const float* __restr
 }
 
 bool implicit_ok(int64_t M, int64_t Cin, int64_t Cout, int64_t K) {
-  (void)Cout;                            // any width: a ragged last column tile is clamped and masked
-  return Cin % 32 == 0 && M % 128 == 0 && K % 32 == 0;
+  (void)Cout; (void)M;                   // any width, any pixel count: ragged last tiles are clamped and masked
+  return Cin % 32 == 0 && K % 32 == 0;
 }
 
 int conv_core(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* w, int64_t Cout, int KH,
@@ -201,7 +201,7 @@ extern "C" int pl_deconv4x4s2_nhwc_fwd(const float* x, int64_t B, int64_t Hi, in
   const size_t part = (size_t)B * Hi * Wi * Cout;
   if (scratch_bytes < 4 * part * sizeof(float)) PL_FAIL(PL_EWORKSPACE, "pl_deconv4x4s2_nhwc_fwd: scratch too small");
   if (!implicit_ok(B * Hi * Wi, Cin, Cout, 4 * Cin))
-    PL_FAIL(PL_ESHAPE, "pl_deconv4x4s2_nhwc_fwd: needs Cin %% 32 == 0 and B*Hi*Wi %% 128 == 0");
+    PL_FAIL(PL_ESHAPE, "pl_deconv4x4s2_nhwc_fwd: needs Cin %% 32 == 0");
   hipStream_t s = (hipStream_t)stream;
   float* tmp = static_cast<float*>(scratch);
   GemmArgs g4[4];

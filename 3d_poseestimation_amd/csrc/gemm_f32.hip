@@ -656,6 +656,7 @@ __device__ __forceinline__ void load_tile_p(Stage& s, const float* __restrict__ 
 struct ConvRow { const float* base; int ih0, iw0; };    // pixel (b, 0, 0) and the tap-(0,0) input coordinates
 
 __device__ __forceinline__ ConvRow conv_row(const GemmArgs& p, int m) {
+  m = min(m, p.M - 1);                      // ragged last row tile: re-read the last pixel, the guarded epilogue drops it
   const int ow = m % p.conv_wo, t = m / p.conv_wo;
   const int oh = t % p.conv_ho, b = t / p.conv_ho;
   ConvRow r;
@@ -750,6 +751,7 @@ __device__ __forceinline__ void store_half_p(char* __restrict__ op, int tid, con
 //   per MFMA gap not hidden (the guide's limit is <= 5 per 32x32x16 gap, hand-placed).
 // N_EDGE (k-contiguous B, BK 32 only): N need not be a multiple of 128 -- the last column tile clamps its B
 // rows and the guarded epilogue drops the columns >= N (the 64-wide layer1 convolutions, the 1088-wide head).
+// With the convolution gather (A_CONV) M may be ragged too: conv_row clamps the pixel index.
 template <bool A_KS, bool B_KS, int BKX, bool A_CONV = false, bool N_EDGE = false>
 __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int block_id, const int nwork,
                                                  char* __restrict__ lds) {
@@ -1074,14 +1076,13 @@ int launch_gemm_f32_pair(const GemmArgs& nn, const GemmArgs& tn, hipStream_t s) 
 
 int launch_conv_nhwc(const GemmArgs& a, hipStream_t s) {
   if (!a.A || !a.B || !a.C) PL_FAIL(PL_EINVAL, "conv: null operand");
-  if (a.conv_cin <= 0 || a.conv_cin % 32 || a.M % BM || a.N < 1 || a.K % BK || a.K % a.conv_cin || a.split_k > 1)
-    PL_FAIL(PL_ESHAPE, "conv: needs Cin %% 32 == 0 and B*Ho*Wo %% 128 == 0 (M=%d N=%d K=%d Cin=%d)",
-            a.M, a.N, a.K, a.conv_cin);
+  if (a.conv_cin <= 0 || a.conv_cin % 32 || a.M < 1 || a.N < 1 || a.K % BK || a.K % a.conv_cin || a.split_k > 1)
+    PL_FAIL(PL_ESHAPE, "conv: needs Cin %% 32 == 0 (M=%d N=%d K=%d Cin=%d)", a.M, a.N, a.K, a.conv_cin);
   if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15)
     PL_FAIL(PL_EINVAL, "conv: operands not 16-byte aligned");
   ProfRec* prof = prof_begin(a, s);
-  const dim3 grid((a.M / BM) * ((a.N + BN - 1) / BN));
-  if (a.N % BN) hipLaunchKernelGGL(conv_x6_planes_kernel<true>, grid, dim3(NTHR), 0, s, a);
+  const dim3 grid(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN));
+  if (a.N % BN || a.M % BM) hipLaunchKernelGGL(conv_x6_planes_kernel<true>, grid, dim3(NTHR), 0, s, a);
   else hipLaunchKernelGGL(conv_x6_planes_kernel<false>, grid, dim3(NTHR), 0, s, a);
   if (prof) (void)hipEventRecord(prof->e1, s);
   PL_CHECK_LAUNCH("conv_x6_planes");
@@ -1095,17 +1096,18 @@ int launch_conv_nhwc_group4(const GemmArgs* a, hipStream_t s) {
     if (!q.A || !q.B || !q.C) PL_FAIL(PL_EINVAL, "conv group: null operand");
     if (q.M != a[0].M || q.N != a[0].N || q.K != a[0].K || q.conv_cin != a[0].conv_cin)
       PL_FAIL(PL_ESHAPE, "conv group: the four problems must have one shape");
-    if (q.conv_cin <= 0 || q.conv_cin % 32 || q.M % BM || q.N < 1 || q.K % BK || q.K % q.conv_cin || q.split_k > 1)
-      PL_FAIL(PL_ESHAPE, "conv group: needs Cin %% 32 == 0 and B*Ho*Wo %% 128 == 0");
+    if (q.conv_cin <= 0 || q.conv_cin % 32 || q.M < 1 || q.N < 1 || q.K % BK || q.K % q.conv_cin || q.split_k > 1)
+      PL_FAIL(PL_ESHAPE, "conv group: needs Cin %% 32 == 0");
     if ((reinterpret_cast<uintptr_t>(q.A) | reinterpret_cast<uintptr_t>(q.B)) & 15)
       PL_FAIL(PL_EINVAL, "conv group: operands not 16-byte aligned");
     P.g[g] = q;
   }
-  const int per = (a[0].M / BM) * ((a[0].N + BN - 1) / BN);
+  const int per = ((a[0].M + BM - 1) / BM) * ((a[0].N + BN - 1) / BN);
   GemmArgs all = a[0];
   ProfRec* prof = prof_begin(all, s);
   if (prof) prof->flops *= 4.0;
-  if (a[0].N % BN) hipLaunchKernelGGL(conv_x6_planes_group4_kernel<true>, dim3(4 * per), dim3(NTHR), 0, s, P, per);
+  if (a[0].N % BN || a[0].M % BM)
+    hipLaunchKernelGGL(conv_x6_planes_group4_kernel<true>, dim3(4 * per), dim3(NTHR), 0, s, P, per);
   else hipLaunchKernelGGL(conv_x6_planes_group4_kernel<false>, dim3(4 * per), dim3(NTHR), 0, s, P, per);
   if (prof) (void)hipEventRecord(prof->e1, s);
   PL_CHECK_LAUNCH("conv_x6_planes_group4");

@@ -168,9 +168,9 @@ int pl_softargmax3d_nhwc_fwd(const float* logits, int64_t B, int64_t J, int64_t 
  *   v = v * scale[co] + shift[co]          (BatchNorm2d on running statistics, folded; or NULL)
  *   relu 1: v = max(v, 0), then v += resid;   relu 2: v += resid, then max(v, 0);   relu 0: v += resid
  * x [B][H][W][Cin], w [Cout][KH][KW][Cin] (OHWI), resid / y [B][Ho][Wo][Cout].
- * Cin % 32 == 0, Cout % 128 == 0 and B*Ho*Wo % 128 == 0: implicit GEMM on the PL_BF16X6 pipeline (fp32-grade
- * products, no im2col buffer); 1x1 stride 1: a plain GEMM; anything else (the stem with Cin = 3, the 64-wide
- * layer1 convolutions): explicit im2col into `scratch` (>= pl_conv2d_nhwc_scratch_bytes, 0 for the others). */
+ * Cin % 32 == 0: implicit GEMM on the PL_BF16X6 pipeline (fp32-grade products, no im2col buffer; ragged last
+ * row / column tiles are clamped and masked); 1x1 stride 1: a plain GEMM; anything else (the stem with Cin = 3):
+ * explicit im2col into `scratch` (>= pl_conv2d_nhwc_scratch_bytes, 0 for the others). */
 size_t pl_conv2d_nhwc_scratch_bytes(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH,
                                     int KW, int stride, int pad);
 int pl_conv2d_nhwc_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* w,
@@ -187,7 +187,7 @@ int pl_maxpool3x3s2_nhwc(const float* x, int64_t B, int64_t H, int64_t W, int64_
  * (oh&1, ow&1) is a 2x2-tap convolution over the input: four implicit GEMMs at the INPUT resolution (no
  * zero insertion, no wasted MACs) and one interleave pass.  w_sub [4][Cout][2][2][Cin]: parity
  * (ph, pw) = index ph*2 + pw, tap (th, tw) = weight[ci][co][kh][kw] with kh = (ph ? 2 : 3) - 2*th, kw
- * likewise.  Cin % 32 == 0, Cout % 128 == 0, B*Hi*Wi % 128 == 0.  scratch >= ..._scratch_bytes. */
+ * likewise.  Cin % 32 == 0.  scratch >= ..._scratch_bytes. */
 size_t pl_deconv4x4s2_nhwc_scratch_bytes(int64_t B, int64_t Hi, int64_t Wi, int64_t Cout);
 int pl_deconv4x4s2_nhwc_fwd(const float* x, int64_t B, int64_t Hi, int64_t Wi, int64_t Cin,
                             const float* w_sub, int64_t Cout, const float* scale, const float* shift,

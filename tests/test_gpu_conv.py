@@ -191,3 +191,19 @@ def test_model2d_eval_forward_vs_torch_cpu(pkg):
     assert got.shape == (2, 34) and np.abs(got - want.reshape(2, 34)).max() < 1e-3
     with pytest.raises(ValueError):
         m(torch.zeros(2, 256, 256, 3, device=DEV))
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_model3d_any_batch_size(pkg, B):
+    """Batch sizes whose deep layers do not make whole 128-row tiles (B = 1: 64 rows at 8x8) fall back to the
+    im2col + edge GEMM path: same result as the rows of a bigger batch."""
+    m = pkg.Model_3D().eval()
+    m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 31))
+    with torch.no_grad():
+        m.final_layer.weight.mul_(1e-4)
+    m = m.to(DEV)
+    frames = pkg.synth.seeded_frames(4, 77).to(DEV)
+    full = m(frames)
+    part = m(frames[:B])
+    assert part.shape == (B, 51)
+    assert float((part - full[:B]).abs().max()) < 2e-4
