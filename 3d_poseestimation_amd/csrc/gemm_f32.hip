@@ -304,7 +304,7 @@ __device__ __forceinline__ void gemm_epilogue_vec(const GemmArgs& p, float* __re
 }
 
 __device__ __forceinline__ bool epilogue_vec_ok(const GemmArgs& p, const float* C) {
-  return p.K <= 512 && p.split_k <= 1 && !p.stat_sum && !p.addend && (p.ldc & 3) == 0 && (p.N & 127) == 0 &&
+  return p.K <= 512 && p.split_k <= 1 && !p.stat_sum && !p.addend && (p.ldc & 3) == 0 &&
          ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(p.resid)) & 15) == 0;
 }
 
@@ -916,7 +916,8 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
 #undef PL_MF6
 #undef PL_MFMAS_ROW
 #undef PL_MFMAS_P
-  if (!N_EDGE && epilogue_vec_ok(p, C)) {       // wave-uniform
+  // wave-uniform: whole output tiles only (a ragged problem's interior tiles qualify, its last row / column tile not)
+  if ((!N_EDGE || (n0 + BN <= p.N && m0 + BM <= p.M)) && epilogue_vec_ok(p, C)) {
     __syncthreads();                            // every wave is done reading operand tiles from LDS
     gemm_epilogue_vec(p, C, acc, m0, n0, wm, wn, i, h, reinterpret_cast<float*>(lds) + wave * 64 * 64);
     return;
