@@ -79,6 +79,10 @@ SIGNATURES = {
                                                   _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "pl_conv2d_nhwc_fwd": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int,
                                       _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _c.c_int, _P, _P, _P, _c.c_size_t, _P]),
+    "pl_conv2d_nhwc_wgrad_scratch_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64,
+                                                        _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "pl_conv2d_nhwc_wgrad": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int,
+                                        _c.c_int, _c.c_int, _c.c_int, _P, _P, _c.c_size_t, _P]),
     "pl_maxpool3x3s2_nhwc": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P]),
     "pl_deconv4x4s2_nhwc_scratch_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64]),
     "pl_deconv4x4s2_nhwc_fwd": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int64, _P, _P,

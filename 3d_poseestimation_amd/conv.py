@@ -79,6 +79,51 @@ def conv2d_nhwc(x, w_ohwi, stride=1, padding=0, scale=None, shift=None, bias=Non
     return y
 
 
+def conv2d_nhwc_wgrad(x, dy, kernel_size, stride=1, padding=0):
+    """Weight gradient of conv2d_nhwc: x [B,H,W,Cin], dy [B,Ho,Wo,Cout] -> dw [Cout,KH,KW,Cin] (OHWI)."""
+    x, dy = x.contiguous(), dy.contiguous()
+    _lib.require_device_tensor(x, "x")
+    _lib.require_device_tensor(dy, "dy")
+    B, H, W, Cin = x.shape
+    KH = KW = int(kernel_size)
+    Cout = dy.shape[3]
+    Ho, Wo = (H + 2 * padding - KH) // stride + 1, (W + 2 * padding - KW) // stride + 1
+    if tuple(dy.shape) != (B, Ho, Wo, Cout):
+        raise ValueError(f"conv2d_nhwc_wgrad: dy {tuple(dy.shape)} does not match the forward output {(B, Ho, Wo, Cout)}")
+    dw = torch.empty(Cout, KH, KW, Cin, dtype=torch.float32, device=x.device)
+    L = _lib.lib()
+    nbytes = L.pl_conv2d_nhwc_wgrad_scratch_bytes(B, H, W, Cin, Cout, KH, KW, stride, padding)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
+    with torch.cuda.device(x.device):
+        rc = L.pl_conv2d_nhwc_wgrad(x.data_ptr(), B, H, W, Cin, dy.data_ptr(), Cout, KH, KW, stride, padding,
+                                    dw.data_ptr(), scratch.data_ptr() if nbytes else None, nbytes,
+                                    _lib.current_stream_ptr())
+    _lib.check(rc, "pl_conv2d_nhwc_wgrad")
+    return dw
+
+
+def conv2d_nhwc_dgrad(dy, w_ohwi, in_hw, stride=1, padding=0):
+    """Input gradient of conv2d_nhwc: dy [B,Ho,Wo,Cout], w [Cout,KH,KW,Cin] -> dx [B,H,W,Cin].  No kernel of its
+    own: stride 1 is the forward convolution of dy with the flipped filter, channels swapped; stride 2 (3x3 pad 1
+    and 1x1 pad 0, the backbone's two cases, even H and W) is the transposed convolution
+    dx[2*oh - pad + kh] += dy[oh] * w[kh], i.e. deconv4x4s2_nhwc with the filter placed inside a 4x4 one."""
+    Cout, KH, KW, Cin = w_ohwi.shape
+    H, W = in_hw
+    if stride == 1:
+        wf = w_ohwi.flip(1, 2).permute(3, 1, 2, 0).contiguous()            # [Cin][KH][KW][Cout]
+        dx = conv2d_nhwc(dy, wf, 1, KH - 1 - padding)
+        if dx.shape[1:3] != (H, W):
+            raise ValueError("conv2d_nhwc_dgrad: input size does not match")
+        return dx
+    if stride == 2 and H % 2 == 0 and W % 2 == 0 and (KH, padding) in ((3, 1), (1, 0)) and KH == KW:
+        # ConvTranspose2d weight [in = Cout][out = Cin][4][4]; with padding 1: kh -> kh, with padding 0: kh -> kh + 1
+        w4 = torch.zeros(Cout, Cin, 4, 4, dtype=torch.float32, device=w_ohwi.device)
+        o = 1 - padding
+        w4[:, :, o:o + KH, o:o + KW] = w_ohwi.permute(0, 3, 1, 2)
+        return deconv4x4s2_nhwc(dy, deconv_subkernels(w4))
+    raise NotImplementedError(f"conv2d_nhwc_dgrad: stride {stride}, kernel {KH}, padding {padding}, input {H}x{W}")
+
+
 def maxpool3x3s2_nhwc(x):
     x = x.contiguous()
     _lib.require_device_tensor(x, "x")

@@ -234,3 +234,70 @@ extern "C" int pl_nhwc_to_nchw(const float* in, int64_t B, int64_t P, int64_t C,
   PL_CHECK_LAUNCH("nhwc_to_nchw");
   return PL_OK;
 }
+
+// ---- weight gradient -----------------------------------------------------------------------
+static int wgrad_splits(int64_t M, int64_t N, int64_t K) {
+  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int s = 1;
+  while (tiles * s < 256 && s < 64 && K % (32 * (s * 2)) == 0 && K / (s * 2) >= 256) s *= 2;
+  return s;
+}
+
+static bool wgrad_implicit_ok(int64_t Cin, int64_t Cout, int64_t N, int64_t K, int64_t Wo) {
+  return Cout % 128 == 0 && N % 128 == 0 && (Cin & 1) == 0 && Wo % 8 == 0 && K % 32 == 0;
+}
+
+// scratch: [split-K slabs: splits x Cout x N] then, on the fallback path, [im2col: pixels x N]
+extern "C" size_t pl_conv2d_nhwc_wgrad_scratch_bytes(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                                                     int KH, int KW, int stride, int pad) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return 0;
+  const int64_t Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  if (Ho <= 0 || Wo <= 0) return 0;
+  const int64_t K = B * Ho * Wo, N = (int64_t)KH * KW * Cin;
+  const int s = wgrad_splits(Cout, N, K);
+  size_t bytes = s > 1 ? (size_t)s * Cout * N * sizeof(float) : 0;
+  if (!wgrad_implicit_ok(Cin, Cout, N, K, Wo)) bytes += (size_t)K * N * sizeof(float);
+  return bytes;
+}
+
+// dw [Cout][KH][KW][Cin] = sum_{b,oh,ow} dy[b][oh][ow][co] * x[b][oh*s - p + kh][ow*s - p + kw][ci]
+extern "C" int pl_conv2d_nhwc_wgrad(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* dy,
+                                    int64_t Cout, int KH, int KW, int stride, int pad, float* dw, void* scratch,
+                                    size_t scratch_bytes, void* stream) {
+  if (!x || !dy || !dw) PL_FAIL(PL_EINVAL, "pl_conv2d_nhwc_wgrad: null pointer");
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
+    PL_FAIL(PL_ESHAPE, "pl_conv2d_nhwc_wgrad: bad geometry");
+  const int64_t Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+  const int64_t K = B * Ho * Wo, N = (int64_t)KH * KW * Cin;
+  if (Ho <= 0 || Wo <= 0 || K > INT32_MAX || N > INT32_MAX) PL_FAIL(PL_ESHAPE, "pl_conv2d_nhwc_wgrad: bad output size");
+  const bool implicit = wgrad_implicit_ok(Cin, Cout, N, K, Wo);
+  const int splits = wgrad_splits(Cout, N, K);
+  const size_t slab_bytes = splits > 1 ? (size_t)splits * Cout * N * sizeof(float) : 0;
+  const size_t need = slab_bytes + (implicit ? 0 : (size_t)K * N * sizeof(float));
+  if (need && (!scratch || scratch_bytes < need))
+    PL_FAIL(PL_EWORKSPACE, "pl_conv2d_nhwc_wgrad: needs %zu scratch bytes (got %zu)", need, scratch_bytes);
+  hipStream_t s = (hipStream_t)stream;
+  float* slabs = static_cast<float*>(scratch);
+  GemmArgs g = {};
+  g.A = dy; g.C = splits > 1 ? slabs : dw;
+  g.M = (int)Cout; g.N = (int)N; g.K = (int)K; g.lda = (int)Cout; g.ldb = (int)N; g.ldc = (int)N;
+  g.split_k = splits; g.arith = PL_BF16X6;
+  if (implicit) {
+    g.B = x;
+    g.conv_cin = (int)Cin; g.conv_h = (int)H; g.conv_w = (int)W; g.conv_ho = (int)Ho; g.conv_wo = (int)Wo;
+    g.conv_kw = KW; g.conv_stride = stride; g.conv_pad_h = pad; g.conv_pad_w = pad;
+    PL_TRY(launch_conv_wgrad(g, s));
+  } else {
+    // shapes without whole tiles (the stem, the 64-wide layer1 convolutions): explicit im2col + the generic TN GEMM
+    float* col = reinterpret_cast<float*>(static_cast<char*>(scratch) + slab_bytes);
+    const int64_t tot = K * N;
+    if (tot > (int64_t)INT32_MAX * NTHR) PL_FAIL(PL_ESHAPE, "pl_conv2d_nhwc_wgrad: im2col too large");
+    hipLaunchKernelGGL(im2col_nhwc_kernel, dim3((unsigned)((tot + NTHR - 1) / NTHR)), dim3(NTHR), 0, s, x, (int)H,
+                       (int)W, (int)Cin, (int)Ho, (int)Wo, KH, KW, stride, pad, K, (int)N, (int)N, col);
+    PL_CHECK_LAUNCH("im2col_nhwc");
+    g.B = col;
+    PL_TRY(launch_gemm_f32(kTN, g, s));
+  }
+  if (splits > 1) return launch_reduce_slabs(slabs, splits, Cout * N, dw, s);
+  return PL_OK;
+}

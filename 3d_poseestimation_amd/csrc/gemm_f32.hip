@@ -687,6 +687,43 @@ __device__ __forceinline__ void load_tile_conv(Stage& s, const GemmArgs& p, cons
   }
 }
 
+// Weight gradient dW[co][(kh,kw,ci)] = sum over pixels p of dy[p][co] * x_gathered[p][(kh,kw,ci)]: the TN GEMM with
+// K = pixels, A = dy [pixels][Cout] as it lies in memory and B gathered from the NHWC input (GemmArgs::conv_*,
+// p.B = x).  k-strided BK 32 loader mapping: thread = (column pair = tid&63, pixel octet = tid>>6).  The column
+// pair fixes (tap, ci) for the whole K loop; Wo % 8 == 0 makes the octet's 8 consecutive pixels share (b, oh), so
+// one div/mod pair per tile decodes them all; each pixel is one 8-byte load or a zero.
+struct WgradCol { int kh, kw, ci; };
+
+__device__ __forceinline__ WgradCol wgrad_col(const GemmArgs& p, int n) {
+  WgradCol c;
+  const int tap = n / p.conv_cin;
+  c.ci = n - tap * p.conv_cin;
+  c.kh = tap / p.conv_kw;
+  c.kw = tap - c.kh * p.conv_kw;
+  return c;
+}
+
+__device__ __forceinline__ void load_tile_wgrad(Stage& s, const GemmArgs& p, const WgradCol& c, int k0, int tid) {
+  const int pix = k0 + (tid >> 6) * 8;
+  const int ow0 = pix % p.conv_wo, q = pix / p.conv_wo;
+  const int oh = q % p.conv_ho, b = q / p.conv_ho;
+  const int ih = oh * p.conv_stride - p.conv_pad_h + c.kh;
+  const bool rok = (unsigned)ih < (unsigned)p.conv_h;
+  const float* row = p.B + ((size_t)b * p.conv_h + (rok ? ih : 0)) * p.conv_w * p.conv_cin + c.ci;
+  float2 v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int iw = (ow0 + j) * p.conv_stride - p.conv_pad_w + c.kw;
+    const bool ok = rok && (unsigned)iw < (unsigned)p.conv_w;
+    const float2 t = *reinterpret_cast<const float2*>(row + (size_t)(ok ? iw : 0) * p.conv_cin);
+    v[j] = ok ? t : make_float2(0.f, 0.f);
+  }
+  s.v0 = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
+  s.v1 = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
+  s.v2 = make_float4(v[4].x, v[4].y, v[5].x, v[5].y);
+  s.v3 = make_float4(v[6].x, v[6].y, v[7].x, v[7].y);
+}
+
 // x = x0 + x1 + x2 exactly, the same RNE split as split3 (results are bit-identical to the fragment path)
 template <int PLANE>
 __device__ __forceinline__ void split8_store(char* __restrict__ dst, const float (&f)[8]) {
@@ -752,7 +789,7 @@ __device__ __forceinline__ void store_half_p(char* __restrict__ op, int tid, con
 // N_EDGE (k-contiguous B, BK 32 only): N need not be a multiple of 128 -- the last column tile clamps its B
 // rows and the guarded epilogue drops the columns >= N (the 64-wide layer1 convolutions, the 1088-wide head).
 // With the convolution gather (A_CONV) M may be ragged too: conv_row clamps the pixel index.
-template <bool A_KS, bool B_KS, int BKX, bool A_CONV = false, bool N_EDGE = false>
+template <bool A_KS, bool B_KS, int BKX, bool A_CONV = false, bool N_EDGE = false, bool B_WGRAD = false>
 __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int block_id, const int nwork,
                                                  char* __restrict__ lds) {
   using Cf = PCfg<BKX>;
@@ -817,6 +854,7 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
   char* nx1 = lds + Cf::STAGE;        // tile kt+1: complete, readable
   char* nx2 = lds + 2 * Cf::STAGE;    // tile kt+2: being written during step kt
   static_assert(!A_CONV || (!A_KS && BKX == 32), "the convolution gather is a k-contiguous BK 32 loader");
+  static_assert(!B_WGRAD || (A_KS && B_KS && BKX == 32 && !A_CONV && !N_EDGE), "wgrad is the TN BK 32 loop");
   using SA = Stage;
   SA ra0, ra1;                        // staging register sets: tile t lives in set t % 2
   Stage rb0, rb1;
@@ -825,6 +863,12 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
   auto load_a = [&](SA& d, const int k0) {
     if constexpr (A_CONV) load_tile_conv(d, p, cr0, cr1, k0, tid);
     else load_tile_p<A_KS, BKX>(d, p.A, p.lda, m0, k0, tid);
+  };
+  WgradCol wcol = {};
+  if (B_WGRAD) wcol = wgrad_col(p, n0 + (tid & 63) * 2);
+  auto load_b = [&](Stage& d, const int k0) {
+    if constexpr (B_WGRAD) load_tile_wgrad(d, p, wcol, k0, tid);
+    else load_tile_p<B_KS, BKX>(d, p.B, p.ldb, n0, k0, tid, nlast);
   };
   auto store_a = [&](char* op, auto half, const SA& g) {
     store_half_p<A_KS, BKX, decltype(half)::value>(op, tid, g);
@@ -843,7 +887,7 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
     if (do_load) {
       const int k0 = kbeg + (kt + 3) * BKX;
       load_a(la, k0);
-      load_tile_p<B_KS, BKX>(lb, p.B, p.ldb, n0, k0, tid, nlast);
+      load_b(lb, k0);
     }
     if (KSTEPS == 2) {
       PL_FRAGS_P(1, cur, 1);
@@ -883,16 +927,16 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
   if (nk > 0) {
     // prologue: tiles 0 and 1 into stages 0 and 1, tile 2 into register set 0
     load_a(ra0, kbeg);
-    load_tile_p<B_KS, BKX>(rb0, p.B, p.ldb, n0, kbeg, tid, nlast);
+    load_b(rb0, kbeg);
     if (nk > 1) {
       load_a(ra1, kbeg + BKX);
-      load_tile_p<B_KS, BKX>(rb1, p.B, p.ldb, n0, kbeg + BKX, tid, nlast);
+      load_b(rb1, kbeg + BKX);
     }
     store_a(cur, H0{}, ra0); store_half_p<B_KS, BKX, 0>(cur + Cf::OPP, tid, rb0);
     if (KSTEPS == 2) { store_a(cur, H1{}, ra0); store_half_p<B_KS, BKX, 1>(cur + Cf::OPP, tid, rb0); }
     if (nk > 2) {
       load_a(ra0, kbeg + 2 * BKX);
-      load_tile_p<B_KS, BKX>(rb0, p.B, p.ldb, n0, kbeg + 2 * BKX, tid, nlast);
+      load_b(rb0, kbeg + 2 * BKX);
     }
     if (nk > 1) {
       store_a(nx1, H0{}, ra1); store_half_p<B_KS, BKX, 0>(nx1 + Cf::OPP, tid, rb1);
@@ -935,6 +979,11 @@ template <bool N_EDGE>
 __global__ __launch_bounds__(256) void conv_x6_planes_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[PCfg<32>::LDS];
   gemm_body_planes<false, false, 32, true, N_EDGE>(p, blockIdx.x, gridDim.x, lds);
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_x6_planes_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[PCfg<32>::LDS];
+  gemm_body_planes<true, true, 32, false, false, true>(p, blockIdx.x, gridDim.x, lds);
 }
 
 struct GemmArgs4 { GemmArgs g[4]; };
@@ -1087,6 +1136,25 @@ int launch_conv_nhwc(const GemmArgs& a, hipStream_t s) {
   else hipLaunchKernelGGL(conv_x6_planes_kernel<false>, grid, dim3(NTHR), 0, s, a);
   if (prof) (void)hipEventRecord(prof->e1, s);
   PL_CHECK_LAUNCH("conv_x6_planes");
+  return PL_OK;
+}
+
+// dW = dy^T x_gathered: a.A = dy [pixels][Cout] (lda = Cout), a.B = x (NHWC), a.C = slabs when split_k > 1,
+// a.M = Cout, a.N = KH*KW*Cin, a.K = B*Ho*Wo; needs Cout % 128 == 0, N % 128 == 0, Cin even, Wo % 8 == 0 and
+// every K slice a multiple of 32 pixels.
+int launch_conv_wgrad(const GemmArgs& a, hipStream_t s) {
+  if (!a.A || !a.B || !a.C) PL_FAIL(PL_EINVAL, "conv wgrad: null operand");
+  const int splits = a.split_k > 1 ? a.split_k : 1;
+  if (a.conv_cin <= 0 || (a.conv_cin & 1) || a.M % BM || a.N % BN || a.N % a.conv_cin || a.conv_wo % 8 ||
+      a.K % (BK * splits) || a.K != (a.K / (a.conv_ho * a.conv_wo)) * a.conv_ho * a.conv_wo || (a.lda & 3))
+    PL_FAIL(PL_ESHAPE, "conv wgrad: needs Cout %% 128 == 0, KH*KW*Cin %% 128 == 0, Wo %% 8 == 0, pixels %% (32*splits) == 0 "
+                       "(M=%d N=%d K=%d Cin=%d Wo=%d splits=%d)", a.M, a.N, a.K, a.conv_cin, a.conv_wo, splits);
+  if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 7))
+    PL_FAIL(PL_EINVAL, "conv wgrad: operands misaligned");
+  ProfRec* prof = prof_begin(a, s);
+  hipLaunchKernelGGL(conv_wgrad_x6_planes_kernel, dim3((a.M / BM) * (a.N / BN) * splits), dim3(NTHR), 0, s, a);
+  if (prof) (void)hipEventRecord(prof->e1, s);
+  PL_CHECK_LAUNCH("conv_wgrad_x6_planes");
   return PL_OK;
 }
 

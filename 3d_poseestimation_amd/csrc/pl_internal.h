@@ -68,6 +68,8 @@ int launch_conv_nhwc(const GemmArgs& a, hipStream_t s);
 // four independent convolutions of identical shape (the four output parities of a stride-2 transposed
 // convolution) in ONE launch: at 8x8 / 16x16 input maps a single one fills a quarter of the CUs
 int launch_conv_nhwc_group4(const GemmArgs* a, hipStream_t s);
+// weight gradient of a convolution: the TN planes GEMM over pixels with the B operand gathered from x
+int launch_conv_wgrad(const GemmArgs& a, hipStream_t s);
 
 int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s);
 int launch_gemm_f32_pair(const GemmArgs& nn, const GemmArgs& tn, hipStream_t s);

@@ -178,6 +178,18 @@ int pl_conv2d_nhwc_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t 
                        const float* shift, const float* bias, int relu, const float* resid, float* y,
                        void* scratch, size_t scratch_bytes, void* stream);
 
+/* Weight gradient of the same convolution (autograd of nn.Conv2d, phase4_joined/train.py:80 loss.backward()):
+ * dw [Cout][KH][KW][Cin] = sum_{b,oh,ow} dy[b][oh][ow][co] * x[b][oh*stride - pad + kh][ow*stride - pad + kw][ci],
+ * the TN GEMM over pixels with x gathered on the fly, split over the pixels so that it fills the chip (fixed-order
+ * slab combine, no float atomics).  Cout % 128 == 0, KH*KW*Cin % 128 == 0, Cin even, Wo % 8 == 0, B*Ho*Wo % 32 == 0
+ * (PL_ESHAPE otherwise).  The input gradient needs no kernel of its own: stride 1 = pl_conv2d_nhwc_fwd on dy with
+ * the flipped, transposed filter; stride 2 = pl_deconv4x4s2_nhwc_fwd (conv.py conv2d_nhwc_dgrad). */
+size_t pl_conv2d_nhwc_wgrad_scratch_bytes(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
+                                          int KH, int KW, int stride, int pad);
+int pl_conv2d_nhwc_wgrad(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* dy,
+                         int64_t Cout, int KH, int KW, int stride, int pad, float* dw, void* scratch,
+                         size_t scratch_bytes, void* stream);
+
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1)  phase4_joined/Resnet.py:119.  x [B][H][W][C], C % 4 == 0;
  * y [B][(H-1)/2+1][(W-1)/2+1][C]. */
 int pl_maxpool3x3s2_nhwc(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream);

@@ -207,3 +207,37 @@ def test_model3d_any_batch_size(pkg, B):
     part = m(frames[:B])
     assert part.shape == (B, 51)
     assert float((part - full[:B]).abs().max()) < 2e-4
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,k,stride,pad", [
+    (4, 32, 128, 128, 3, 1, 1),      # layer2 conv2
+    (4, 32, 128, 128, 3, 2, 1),      # stride on the 3x3
+    (4, 16, 256, 256, 3, 1, 1),
+    (2, 32, 256, 512, 1, 2, 0),      # downsample 1x1 stride 2
+    (2, 16, 512, 128, 1, 1, 0),      # 1x1
+    (2, 16, 64, 128, 3, 1, 1),       # Cin = 64, 576 columns: not whole tiles -> im2col fallback
+    (2, 16, 64, 64, 3, 1, 1),        # layer1 conv2
+    (2, 32, 3, 64, 7, 2, 3),         # the stem (dgrad not needed: x is the image)
+])
+def test_conv2d_backward_vs_torch_autograd(pkg, B, H, Cin, Cout, k, stride, pad):
+    """dgrad and wgrad of the NHWC convolution against torch autograd on the CPU (fp64)."""
+    g = torch.Generator().manual_seed(B + H + Cin + Cout + k + stride)
+    x = torch.randn(B, H, H, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / np.sqrt(Cin * k * k)
+    xr = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    y = F.conv2d(xr, wr, stride=stride, padding=pad)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    dy_nhwc = dy.permute(0, 2, 3, 1).float().contiguous()
+    wo = pkg.conv.to_ohwi(w).to(DEV)
+    dw = pkg.conv.conv2d_nhwc_wgrad(x.to(DEV), dy_nhwc.to(DEV), k, stride, pad)
+    want_dw = wr.grad.permute(0, 2, 3, 1)
+    assert dw.shape == want_dw.shape
+    assert float((dw.cpu().double() - want_dw).abs().max()) < 2e-5 * float(want_dw.abs().max())
+    if k == 7:
+        return
+    dx = pkg.conv.conv2d_nhwc_dgrad(dy_nhwc.to(DEV), wo, (H, H), stride, pad)
+    want_dx = xr.grad.permute(0, 2, 3, 1)
+    assert dx.shape == want_dx.shape
+    assert float((dx.cpu().double() - want_dx).abs().max()) < 2e-5 * float(want_dx.abs().max())
