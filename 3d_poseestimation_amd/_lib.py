@@ -83,7 +83,16 @@ SIGNATURES = {
                                                         _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "pl_conv2d_nhwc_wgrad": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int,
                                         _c.c_int, _c.c_int, _c.c_int, _P, _P, _c.c_size_t, _P]),
+    "pl_bn_train_scratch_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64]),
+    "pl_bn_train_fwd": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _c.c_float, _c.c_float, _P, _P, _P, _c.c_int,
+                                   _P, _P, _P, _P, _P, _P]),
+    "pl_bn_train_bwd": (_c.c_int, [_P, _P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _P, _P, _P, _P, _P]),
+    "pl_add_relu_fwd": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P, _P]),
+    "pl_mask_by_bits": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P]),
     "pl_maxpool3x3s2_nhwc": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P]),
+    "pl_maxpool3x3s2_nhwc_bwd": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P]),
+    "pl_colsum_scratch_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64]),
+    "pl_colsum": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _P]),
     "pl_deconv4x4s2_nhwc_scratch_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64]),
     "pl_deconv4x4s2_nhwc_fwd": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int64, _P, _P,
                                            _c.c_int, _P, _P, _c.c_size_t, _P]),

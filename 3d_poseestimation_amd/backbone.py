@@ -9,8 +9,11 @@ The modules below are PARAMETER CONTAINERS built from stock nn.Conv2d / nn.Batch
 nn.ConvTranspose2d in the reference's construction order, so `state_dict()` has the reference's keys and
 shapes (a reference checkpoint loads with load_state_dict) -- pinned by tests/golden/g9: the reference's
 ResNet("resnet50") imported and run as-is.  The arithmetic is conv.py's: every convolution with its
-BatchNorm (running statistics), ReLU and residual add folded into one launch.  Training-mode forward
-and backward of this path are not built yet (raises): the next slice of row N2.
+BatchNorm (running statistics), ReLU and residual add folded into one launch.  In TRAINING mode the same
+containers run a first, unfused cut of the path (conv.py's differentiable pieces: implicit-GEMM convolution
+with dgrad / wgrad on the library, BatchNorm2d on batch statistics with its backward, max-pool, transposed
+convolution and residual join with theirs): correct against torch autograd, not yet tuned -- the next slice of
+row N2 fuses the statistics into the GEMM epilogue and the BatchNorm backward into dgrad's producer.
 Unlike the reference constructor (Model.py:28-38) nothing is downloaded: weights are whatever is loaded.
 """
 import torch
@@ -80,10 +83,29 @@ class ResNet(nn.Module):
             self._cache = (v, {k: (tuple(t.detach() for t in x) if isinstance(x, tuple) else x) for k, x in f.items()})
         return self._cache[1]
 
+    def _forward_train(self, x):
+        """Training mode: batch statistics, running statistics updated, differentiable (Resnet.py:135-142, :65-93)."""
+        def w(m):
+            return conv.to_ohwi(m.weight.float())
+        bnr = conv.batchnorm_relu_train
+        x = bnr(conv.conv2d_nhwc_autograd(x.float(), w(self.conv1), 2, 3), self.bn1, True)
+        x = conv.maxpool3x3s2_nhwc_autograd(x)
+        for li in (1, 2, 3, 4):
+            for blk in getattr(self, f"layer{li}"):
+                identity = x
+                if blk.downsample is not None:
+                    identity = bnr(conv.conv2d_nhwc_autograd(x, w(blk.downsample[0]), blk.stride, 0),
+                                   blk.downsample[1], False)
+                out = bnr(conv.conv2d_nhwc_autograd(x, w(blk.conv1), 1, 0), blk.bn1, True)
+                out = bnr(conv.conv2d_nhwc_autograd(out, w(blk.conv2), blk.stride, 1), blk.bn2, True)
+                out = bnr(conv.conv2d_nhwc_autograd(out, w(blk.conv3), 1, 0), blk.bn3, False)
+                x = conv.add_relu(out, identity)
+        return x
+
     def forward(self, x_nhwc):
         """x [B, H, W, 3] fp32 (NHWC, as the phase4 loader delivers frames, Model.py:88) -> [B, H/32, W/32, 2048]."""
         if self.training:
-            raise NotImplementedError("the training-mode forward/backward of the conv path is not built yet")
+            return self._forward_train(x_nhwc)
         f = self._folded()
         with torch.no_grad():
             s, b = f["bn1"]
@@ -149,9 +171,14 @@ class _HeatmapNet(nn.Module):
         """The same in the reference's layout [B, J*depth, 64, 64] (Model.py:91)."""
         return conv.nhwc_to_nchw(self.heatmap_logits_nhwc(x_nhwc))
 
-    def _check_eval(self):
-        if self.training:
-            raise NotImplementedError("the training-mode forward/backward of the conv path is not built yet")
+    def _heatmap_logits_train(self, x_nhwc):
+        """Training mode, differentiable: [B, H, W, 3] -> [B, J*depth, H/4, W/4] (NCHW for the soft-argmax)."""
+        out = self.preact(x_nhwc)
+        for i in (0, 3, 6):
+            out = conv.batchnorm_relu_train(conv.deconv4x4s2_nhwc_autograd(out, self.deconv_layers[i].weight),
+                                            self.deconv_layers[i + 1], True)
+        out = conv.conv2d_bias_nhwc_autograd(out, conv.to_ohwi(self.final_layer.weight.float()), self.final_layer.bias)
+        return conv.nhwc_to_nchw_autograd(out)
 
 
 class Model_3D(_HeatmapNet):
@@ -160,7 +187,8 @@ class Model_3D(_HeatmapNet):
 
     def forward(self, x):
         """x [B, 256, 256, 3] NHWC frames -> [B, 51] (x, y, z) per joint in (-1, 1)  (Model.py:83-137)."""
-        self._check_eval()
+        if self.training:
+            return soft_argmax_3d(self._heatmap_logits_train(x), self.num_joints, self.depth_dim)
         with torch.no_grad():
             return soft_argmax_3d_nhwc(self.heatmap_logits_nhwc(x), self.num_joints)
 
@@ -172,8 +200,9 @@ class Model_2D(_HeatmapNet):
     def forward(self, x):
         """x [B, 3, 256, 256] NCHW frames (Model_2d.py:91 leaves the permute commented out) -> [B, 34]
         (x, y) per joint in (0, 1)  (Model_2d.py:87-136)."""
-        self._check_eval()
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError(f"Model_2D expects NCHW frames [B, 3, H, W], got {tuple(x.shape)}")
+        if self.training:
+            return soft_argmax_2d(self._heatmap_logits_train(x.permute(0, 2, 3, 1).contiguous()), self.num_joints)
         with torch.no_grad():
             return soft_argmax_2d(self.heatmap_logits(x.permute(0, 2, 3, 1).contiguous()), self.num_joints)

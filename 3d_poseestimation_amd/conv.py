@@ -168,3 +168,222 @@ def nhwc_to_nchw(x):
         rc = _lib.lib().pl_nhwc_to_nchw(x.data_ptr(), B, H * W, C, y.data_ptr(), _lib.current_stream_ptr())
     _lib.check(rc, "pl_nhwc_to_nchw")
     return y
+
+
+# ---------------------------------------------------------------------------------------------
+# Training-mode building blocks (autograd), NHWC.  The assembly of a trainable ResNet from them -- and the
+# transposed-convolution / max-pool backward it also needs -- is the next slice of SURVEY 8f row N2.
+# ---------------------------------------------------------------------------------------------
+class _Conv2dFn(torch.autograd.Function):
+    """conv2d_nhwc with autograd: dgrad and wgrad run on the library too (conv2d_nhwc_dgrad / _wgrad)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ohwi, stride, padding):
+        ctx.save_for_backward(x, w_ohwi)
+        ctx.geom = (stride, padding)
+        return conv2d_nhwc(x, w_ohwi, stride, padding)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, padding = ctx.geom
+        dy = dy.contiguous()
+        dx = conv2d_nhwc_dgrad(dy, w, x.shape[1:3], stride, padding) if ctx.needs_input_grad[0] else None
+        dw = conv2d_nhwc_wgrad(x, dy, w.shape[1], stride, padding) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None
+
+
+def conv2d_nhwc_autograd(x, w_ohwi, stride=1, padding=0):
+    """Differentiable conv2d_nhwc (no folded epilogue: in training mode BatchNorm needs batch statistics)."""
+    return _Conv2dFn.apply(x, w_ohwi, stride, padding)
+
+
+class _BNReLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, batches, eps, momentum, relu):
+        shape = z.shape
+        C = shape[-1]
+        z2 = z.contiguous().reshape(-1, C)
+        rows = z2.shape[0]
+        for name, t in (("z", z2), ("gamma", gamma), ("beta", beta), ("running_mean", running_mean),
+                        ("running_var", running_var)):
+            _lib.require_device_tensor(t, name)
+        _lib.require_device_tensor(batches, "num_batches_tracked", torch.int64)
+        dev, L = z2.device, _lib.lib()
+        y = torch.empty_like(z2)
+        bits = torch.empty(rows, 4 * ((C + 255) // 256), dtype=torch.int64, device=dev)
+        mean, rstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        scratch = torch.empty(L.pl_bn_train_scratch_bytes(rows, C), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.pl_bn_train_fwd(z2.data_ptr(), rows, C, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
+                                   running_mean.data_ptr(), running_var.data_ptr(), batches.data_ptr(), int(relu),
+                                   y.data_ptr(), bits.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scratch.data_ptr(),
+                                   _lib.current_stream_ptr())
+        _lib.check(rc, "pl_bn_train_fwd")
+        ctx.save_for_backward(z2, bits, mean, rstd, gamma)
+        ctx.shape = shape
+        ctx.mark_non_differentiable(running_mean, running_var, batches)
+        return y.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        z2, bits, mean, rstd, gamma = ctx.saved_tensors
+        rows, C = z2.shape
+        dy2 = dy.contiguous().reshape(rows, C)
+        dev, L = z2.device, _lib.lib()
+        dz, dgamma, dbeta = torch.empty_like(z2), torch.empty(C, device=dev), torch.empty(C, device=dev)
+        scratch = torch.empty(L.pl_bn_train_scratch_bytes(rows, C), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.pl_bn_train_bwd(dy2.data_ptr(), bits.data_ptr(), z2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                   gamma.data_ptr(), rows, C, dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                   scratch.data_ptr(), _lib.current_stream_ptr())
+        _lib.check(rc, "pl_bn_train_bwd")
+        return dz.reshape(ctx.shape), dgamma, dbeta, None, None, None, None, None, None
+
+
+def batchnorm_relu_train(z, bn, relu=True):
+    """Training-mode nn.BatchNorm2d `bn` (+ ReLU) applied to an NHWC feature map z [..., C] (batch statistics over
+    every leading dimension); updates bn.running_mean / running_var / num_batches_tracked in place."""
+    if bn.momentum is None:
+        raise NotImplementedError("cumulative moving average (momentum=None)")
+    return _BNReLUFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                           float(bn.eps), float(bn.momentum), bool(relu))
+
+
+class _AddReLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        if a.shape != b.shape:
+            raise ValueError("add_relu: shapes differ")
+        C = a.shape[-1]
+        a2, b2 = a.contiguous().reshape(-1, C), b.contiguous().reshape(-1, C)
+        _lib.require_device_tensor(a2, "a")
+        _lib.require_device_tensor(b2, "b")
+        rows = a2.shape[0]
+        out = torch.empty_like(a2)
+        bits = torch.empty(rows, 4 * ((C + 255) // 256), dtype=torch.int64, device=a2.device)
+        with torch.cuda.device(a2.device):
+            rc = _lib.lib().pl_add_relu_fwd(a2.data_ptr(), b2.data_ptr(), rows, C, out.data_ptr(), bits.data_ptr(),
+                                            _lib.current_stream_ptr())
+        _lib.check(rc, "pl_add_relu_fwd")
+        ctx.save_for_backward(bits)
+        ctx.shape = a.shape
+        return out.reshape(a.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        (bits,) = ctx.saved_tensors
+        C = ctx.shape[-1]
+        g2 = g.contiguous().reshape(-1, C)
+        dx = torch.empty_like(g2)
+        with torch.cuda.device(g2.device):
+            rc = _lib.lib().pl_mask_by_bits(g2.data_ptr(), bits.data_ptr(), g2.shape[0], C, dx.data_ptr(),
+                                            _lib.current_stream_ptr())
+        _lib.check(rc, "pl_mask_by_bits")
+        dx = dx.reshape(ctx.shape)
+        return dx, dx
+
+
+def add_relu(a, b):
+    """relu(a + b), differentiable: the residual join of a Bottleneck (Resnet.py:90-91)."""
+    return _AddReLUFn.apply(a, b)
+
+
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return maxpool3x3s2_nhwc(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, H, W, C = x.shape
+        dx = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().pl_maxpool3x3s2_nhwc_bwd(x.data_ptr(), dy.data_ptr(), B, H, W, C, dx.data_ptr(),
+                                                     _lib.current_stream_ptr())
+        _lib.check(rc, "pl_maxpool3x3s2_nhwc_bwd")
+        return dx
+
+
+def maxpool3x3s2_nhwc_autograd(x):
+    return _MaxPoolFn.apply(x.contiguous())
+
+
+class _DeconvFn(torch.autograd.Function):
+    """nn.ConvTranspose2d(4, 2, 1, bias=False) on NHWC, weight in torch's [Cin][Cout][4][4] layout.  Its backward
+    needs no kernel of its own: y = C^T x for the stride-2 convolution C with the same filter, so dx = C dy (the
+    forward convolution kernel, stride 2) and dW = wgrad of C with input dy and output gradient x."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return deconv4x4s2_nhwc(x, deconv_subkernels(weight.detach().float()))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_nhwc(dy, weight.detach().permute(0, 2, 3, 1).contiguous(), 2, 1)   # [Cin][4][4][Cout] as OHWI
+        if ctx.needs_input_grad[1]:
+            dw = conv2d_nhwc_wgrad(dy, x, 4, 2, 1).permute(0, 3, 1, 2).contiguous()        # [Cin][4][4][Cout] -> [Cin][Cout][4][4]
+        return dx, dw
+
+
+def deconv4x4s2_nhwc_autograd(x, weight_iohw):
+    return _DeconvFn.apply(x.contiguous(), weight_iohw)
+
+
+class _ConvBiasFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w_ohwi, bias, stride, padding):
+        ctx.save_for_backward(x, w_ohwi)
+        ctx.geom = (stride, padding)
+        return conv2d_nhwc(x, w_ohwi, stride, padding, bias=bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, padding = ctx.geom
+        dy = dy.contiguous()
+        dx = conv2d_nhwc_dgrad(dy, w, x.shape[1:3], stride, padding) if ctx.needs_input_grad[0] else None
+        dw = conv2d_nhwc_wgrad(x, dy, w.shape[1], stride, padding) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.needs_input_grad[2]:
+            C = dy.shape[-1]
+            rows = dy.numel() // C
+            db = torch.empty(C, dtype=torch.float32, device=dy.device)
+            L = _lib.lib()
+            scratch = torch.empty(L.pl_colsum_scratch_bytes(rows, C), dtype=torch.uint8, device=dy.device)
+            with torch.cuda.device(dy.device):
+                rc = L.pl_colsum(dy.data_ptr(), rows, C, db.data_ptr(), scratch.data_ptr(), _lib.current_stream_ptr())
+            _lib.check(rc, "pl_colsum")
+        return dx, dw, db, None, None
+
+
+def conv2d_bias_nhwc_autograd(x, w_ohwi, bias, stride=1, padding=0):
+    return _ConvBiasFn.apply(x, w_ohwi, bias, stride, padding)
+
+
+class _ToNCHWFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return nhwc_to_nchw(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        B, C, H, W = g.shape
+        out = torch.empty(B, H, W, C, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):   # [B][C][P] -> [B][P][C]: the same tiled transpose with the roles swapped
+            rc = _lib.lib().pl_nhwc_to_nchw(g.data_ptr(), B, C, H * W, out.data_ptr(), _lib.current_stream_ptr())
+        _lib.check(rc, "pl_nhwc_to_nchw")
+        return out
+
+
+def nhwc_to_nchw_autograd(x):
+    return _ToNCHWFn.apply(x)

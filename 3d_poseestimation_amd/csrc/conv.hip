@@ -70,6 +70,54 @@ __global__ __launch_bounds__(NTHR) void maxpool3x3s2_nhwc_kernel(const float* __
   *reinterpret_cast<float4*>(y + t * 4) = m;
 }
 
+// backward of the 3x3 / stride 2 / pad 1 max-pool: one thread per INPUT float4; an input pixel lies in at most
+// 2 x 2 windows, and it receives a window's gradient where it is that window's FIRST maximum in (kh, kw) order
+// (torch's tie rule) -- recomputed from x and y, no index tensor, no atomics.
+__global__ __launch_bounds__(NTHR) void maxpool3x3s2_nhwc_bwd_kernel(const float* __restrict__ x,
+                                                                     const float* __restrict__ dy, int H, int W, int C,
+                                                                     int Ho, int Wo, int64_t n4,
+                                                                     float* __restrict__ dx) {
+  const int64_t t = (int64_t)blockIdx.x * NTHR + threadIdx.x;
+  if (t >= n4) return;
+  const int c4 = C >> 2;
+  const int c = (int)(t % c4) * 4;
+  int64_t r = t / c4;
+  const int iw = (int)(r % W); r /= W;
+  const int ih = (int)(r % H);
+  const int64_t b = r / H;
+  const float4 xv = *reinterpret_cast<const float4*>(x + t * 4);
+  const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int oh = max(0, ih / 2); oh <= min(Ho - 1, (ih + 1) / 2); ++oh)
+    for (int ow = max(0, iw / 2); ow <= min(Wo - 1, (iw + 1) / 2); ++ow) {
+      const int kh0 = ih - (oh * 2 - 1), kw0 = iw - (ow * 2 - 1);            // this pixel's tap in that window
+      if (kh0 < 0 || kh0 > 2 || kw0 < 0 || kw0 > 2) continue;
+      const float4 gv = *reinterpret_cast<const float4*>(dy + ((b * Ho + oh) * Wo + ow) * C + c);
+      const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+      bool first[4] = {true, true, true, true};                               // no earlier tap holds a value >= ours
+      bool ismax[4] = {true, true, true, true};                               // no later tap holds a value > ours
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int jh = oh * 2 - 1 + kh, jw = ow * 2 - 1 + kw;
+          if ((unsigned)jh >= (unsigned)H || (unsigned)jw >= (unsigned)W || (kh == kh0 && kw == kw0)) continue;
+          const float4 ov = *reinterpret_cast<const float4*>(x + ((b * H + jh) * W + jw) * C + c);
+          const float os[4] = {ov.x, ov.y, ov.z, ov.w};
+          const bool earlier = kh * 3 + kw < kh0 * 3 + kw0;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (earlier) first[j] = first[j] && !(os[j] >= xs[j]);
+            else ismax[j] = ismax[j] && !(os[j] > xs[j]);
+          }
+        }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (first[j] && ismax[j]) g[j] += gs[j];
+    }
+  *reinterpret_cast<float4*>(dx + t * 4) = make_float4(g[0], g[1], g[2], g[3]);
+}
+
 // y[b][2a+ph][2c+pw][:] = part[ph*2+pw][b][a][c][:]
 __global__ __launch_bounds__(NTHR) void deconv_interleave_kernel(const float* __restrict__ part, int Hi, int Wi, int C,
                                                                  int64_t n4_per_part, float* __restrict__ y) {
@@ -300,4 +348,30 @@ extern "C" int pl_conv2d_nhwc_wgrad(const float* x, int64_t B, int64_t H, int64_
   }
   if (splits > 1) return launch_reduce_slabs(slabs, splits, Cout * N, dw, s);
   return PL_OK;
+}
+
+extern "C" int pl_maxpool3x3s2_nhwc_bwd(const float* x, const float* dy, int64_t B, int64_t H, int64_t W, int64_t C,
+                                        float* dx, void* stream) {
+  if (!x || !dy || !dx) PL_FAIL(PL_EINVAL, "pl_maxpool3x3s2_nhwc_bwd: null pointer");
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) PL_FAIL(PL_ESHAPE, "pl_maxpool3x3s2_nhwc_bwd: C %% 4 == 0 needed");
+  const int64_t Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int64_t n4 = B * H * W * (C >> 2);
+  if (n4 > (int64_t)INT32_MAX * NTHR) PL_FAIL(PL_ESHAPE, "pl_maxpool3x3s2_nhwc_bwd: too large");
+  hipLaunchKernelGGL(maxpool3x3s2_nhwc_bwd_kernel, dim3((unsigned)((n4 + NTHR - 1) / NTHR)), dim3(NTHR), 0,
+                     (hipStream_t)stream, x, dy, (int)H, (int)W, (int)C, (int)Ho, (int)Wo, n4, dx);
+  PL_CHECK_LAUNCH("maxpool3x3s2_nhwc_bwd");
+  return PL_OK;
+}
+
+// out[c] = sum_r X[r][c]: the bias gradient of a convolution (fixed-order two-stage sum)
+extern "C" size_t pl_colsum_scratch_bytes(int64_t rows, int64_t cols) {
+  return rows > 0 && cols > 0 ? (size_t)colsum_chunks((int)rows) * cols * sizeof(float) : 0;
+}
+
+extern "C" int pl_colsum(const float* X, int64_t rows, int64_t cols, float* out, void* scratch, void* stream) {
+  if (!X || !out || !scratch) PL_FAIL(PL_EINVAL, "pl_colsum: null pointer");
+  if (rows <= 0 || rows > INT32_MAX || cols <= 0 || cols > INT32_MAX) PL_FAIL(PL_ESHAPE, "pl_colsum: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  PL_TRY(launch_colsum_partial(X, (int)rows, (int)cols, static_cast<float*>(scratch), s));
+  return launch_reduce_slabs(static_cast<const float*>(scratch), colsum_chunks((int)rows), cols, out, s);
 }

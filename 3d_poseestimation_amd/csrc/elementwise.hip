@@ -93,6 +93,107 @@ __global__ __launch_bounds__(NTHR) void bn_finalize_kernel(
   if (batches && blockIdx.x == 0 && threadIdx.x == 0) batches[0] += 1;
 }
 
+// block-level combine of per-wave float4 column partials; wave 0 returns the total
+__device__ __forceinline__ float4 combine4(float4 v, float4 (*sm)[64], int wave, int lane) {
+  sm[wave][lane] = v;
+  __syncthreads();
+  float4 t = sm[0][lane];
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+      const float4 u = sm[w][lane];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+  }
+  __syncthreads();
+  return t;
+}
+
+// Column statistics of a [B][H] matrix in the layout bn_finalize merges: per 64-row group the column sums
+// and the sums of squares about the group mean (what the GEMM epilogue emits for the lifter; the conv path's
+// BatchNorm2d over [B*H*W][C] computes them here).  grid = (ceil(H/256), ceil(B/64)).
+__global__ __launch_bounds__(NTHR) void bn_colstats_kernel(const float* __restrict__ z, int B, int H,
+                                                           float* __restrict__ stat_sum, float* __restrict__ stat_m2) {
+  __shared__ float4 sm[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const bool active = c < H;
+  const int r0 = blockIdx.y * 64, r1 = min(B, r0 + 64);
+  float4 s = make_float4(0, 0, 0, 0);
+  if (active)
+    for (int r = r0 + wave; r < r1; r += 4) {
+      const float4 v = ld4(z + (size_t)r * H + c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  float4 t = combine4(s, sm, wave, lane);
+  if (wave == 0) sm[0][lane] = t;
+  __syncthreads();
+  t = sm[0][lane];
+  __syncthreads();
+  const float inv = 1.0f / (float)(r1 - r0);
+  const float4 mu = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+  float4 m2 = make_float4(0, 0, 0, 0);
+  if (active)
+    for (int r = r0 + wave; r < r1; r += 4) {
+      const float4 v = ld4(z + (size_t)r * H + c);
+      const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
+      m2.x = fmaf(dx, dx, m2.x); m2.y = fmaf(dy, dy, m2.y); m2.z = fmaf(dz, dz, m2.z); m2.w = fmaf(dw, dw, m2.w);
+    }
+  const float4 q = combine4(m2, sm, wave, lane);
+  if (wave == 0 && active) {
+    st4(stat_sum + (size_t)blockIdx.y * H + c, t);
+    st4(stat_m2 + (size_t)blockIdx.y * H + c, q);
+  }
+}
+
+// out = relu(a + b), bitmap of (out > 0): the residual join of a Bottleneck (Resnet.py:90-91) in training mode
+__global__ __launch_bounds__(NTHR) void add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                        float* __restrict__ out, uint64_t* __restrict__ bits, int B,
+                                                        int H) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int strip = blockIdx.x;
+  const int c = strip * 256 + lane * 4;
+  const bool active = c < H;
+  const int wpr = ((H + 255) >> 8) * 4;
+  for (int r = blockIdx.y * 4 + wave; r < B; r += gridDim.y * 4) {
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+      const float4 u = ld4(a + (size_t)r * H + c), v = ld4(b + (size_t)r * H + c);
+      o[0] = u.x + v.x; o[1] = u.y + v.y; o[2] = u.z + v.z; o[3] = u.w + v.w;
+    }
+    uint64_t word = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool on = active && o[j] > 0.f;
+      o[j] = on ? o[j] : 0.f;
+      const uint64_t m = __ballot(on);
+      if (lane == j) word = m;
+    }
+    if (lane < 4) bits[(size_t)r * wpr + strip * 4 + lane] = word;
+    if (active) st4(out + (size_t)r * H + c, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
+// dx = g where the bitmap says the forward output was positive, else 0 (backward of add_relu: both inputs get it)
+__global__ __launch_bounds__(NTHR) void mask_by_bits_kernel(const float* __restrict__ g, const uint64_t* __restrict__ bits,
+                                                            float* __restrict__ dx, int B, int H) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int strip = blockIdx.x;
+  const int c = strip * 256 + lane * 4;
+  if (c >= H) return;
+  const int wpr = ((H + 255) >> 8) * 4;
+  for (int r = blockIdx.y * 4 + wave; r < B; r += gridDim.y * 4) {
+    const float4 v = ld4(g + (size_t)r * H + c);
+    const uint64_t* bw = bits + (size_t)r * wpr + strip * 4;
+    float4 d;
+    d.x = ((bw[0] >> lane) & 1ull) ? v.x : 0.f;
+    d.y = ((bw[1] >> lane) & 1ull) ? v.y : 0.f;
+    d.z = ((bw[2] >> lane) & 1ull) ? v.z : 0.f;
+    d.w = ((bw[3] >> lane) & 1ull) ? v.w : 0.f;
+    st4(dx + (size_t)r * H + c, d);
+  }
+}
+
 // -------------------------------------------------------------------------------------
 // act = [resid +] dropout(relu(z*scale + shift)); bitmap of (positive & kept).
 // grid = (ceil(H/256), gy), block = 256: wave w walks rows blockIdx.y*4+w, +4*gy, ...
@@ -103,7 +204,9 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(
     const float* resid, float* act, uint64_t* __restrict__ bits, int B, int H, int mode,
     uint32_t thr, float kscale, uint32_t k0, uint32_t k1, uint32_t c3, uint32_t layer,
     const uint64_t* __restrict__ inject) {
-  // mode: 0 keep all, 1 philox, 2 injected bitmap, 3 drop all
+  // mode: 0 keep all, 1 philox, 2 injected bitmap, 3 drop all; + 8: no ReLU (BatchNorm alone; bitmap all ones)
+  const bool norelu = (mode & 8) != 0;
+  mode &= 7;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int strip = blockIdx.x;
   const int c = strip * 256 + lane * 4;
@@ -136,7 +239,7 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      on[j] = active && keep[j] && (y[j] > 0.f);
+      on[j] = active && keep[j] && (norelu || y[j] > 0.f);
       o[j] = on[j] ? y[j] * kscale : 0.f;
     }
     uint64_t word = 0;
@@ -155,22 +258,6 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(
       st4(act + off, out);
     }
   }
-}
-
-// block-level combine of per-wave float4 column partials; wave 0 returns the total
-__device__ __forceinline__ float4 combine4(float4 v, float4 (*sm)[64], int wave, int lane) {
-  sm[wave][lane] = v;
-  __syncthreads();
-  float4 t = sm[0][lane];
-  if (wave == 0) {
-#pragma unroll
-    for (int w = 1; w < 4; ++w) {
-      const float4 u = sm[w][lane];
-      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-    }
-  }
-  __syncthreads();
-  return t;
 }
 
 // -------------------------------------------------------------------------------------
@@ -900,5 +987,78 @@ extern "C" int pl_l1_terms_fwd_bwd(const PLL1Term* terms, int nterms, float grad
   PL_CHECK_LAUNCH("l1_partial");
   hipLaunchKernelGGL(l1_final_kernel, dim3(nterms), dim3(64), 0, s, (const float*)scratch, T, losses);
   PL_CHECK_LAUNCH("l1_final");
+  return PL_OK;
+}
+
+// =====================================================================================
+// BatchNorm over the rows of a [rows][C] matrix as stand-alone entry points (the conv path: an NHWC feature
+// map IS that matrix, BatchNorm2d = BatchNorm1d over its rows).  Same kernels as the lifter's layers.
+// =====================================================================================
+static int bn_groups(int64_t rows) { return (int)((rows + 63) / 64); }
+
+extern "C" size_t pl_bn_train_scratch_bytes(int64_t rows, int64_t C) {
+  if (rows <= 0 || C <= 0) return 0;
+  const size_t fwd = ((size_t)2 * bn_groups(rows) * C + 2 * (size_t)C) * sizeof(float);
+  const int rc = bwd_row_chunks((int)rows);
+  const size_t bwd = ((size_t)2 * rc * C + 3 * (size_t)C + (size_t)rc * C) * sizeof(float);
+  return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int pl_bn_train_fwd(const float* z, int64_t rows, int64_t C, const float* gamma, const float* beta, float eps,
+                               float momentum, float* running_mean, float* running_var, int64_t* batches, int relu,
+                               float* y, uint64_t* bits, float* mean, float* rstd, void* scratch, void* stream) {
+  if (!z || !gamma || !beta || !y || !bits || !mean || !rstd || !scratch) PL_FAIL(PL_EINVAL, "pl_bn_train_fwd: null pointer");
+  if (rows < 2 || rows > INT32_MAX || C <= 0 || (C & 3)) PL_FAIL(rows < 2 ? PL_EBATCH : PL_ESHAPE, "pl_bn_train_fwd: rows=%lld C=%lld (C %% 4 == 0, rows >= 2)", (long long)rows, (long long)C);
+  hipStream_t s = (hipStream_t)stream;
+  const int G = bn_groups(rows), B = (int)rows, H = (int)C;
+  float* stat = static_cast<float*>(scratch);
+  float* scale = stat + (size_t)2 * G * H;
+  float* shift = scale + H;
+  hipLaunchKernelGGL(bn_colstats_kernel, dim3((H + 255) / 256, G), dim3(NTHR), 0, s, z, B, H, stat, stat + (size_t)G * H);
+  PL_CHECK_LAUNCH("bn_colstats");
+  PL_TRY(launch_bn_finalize(stat, G, 1, B, H, gamma, beta, eps, momentum, running_mean, running_var, batches, mean, rstd,
+                            scale, shift, s));
+  const int strips = (H + 255) / 256;
+  dim3 grid(strips, stream_rows_grid(B, strips));
+  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NTHR), 0, s, z, scale, shift, (const float*)nullptr, y, bits, B, H,
+                     relu ? 0 : 8, 0u, 1.0f, 0u, 0u, 0u, 0u, (const uint64_t*)nullptr);
+  PL_CHECK_LAUNCH("bn_apply");
+  return PL_OK;
+}
+
+extern "C" int pl_bn_train_bwd(const float* dy, const uint64_t* bits, const float* z, const float* mean, const float* rstd,
+                               const float* gamma, int64_t rows, int64_t C, float* dz, float* dgamma, float* dbeta,
+                               void* scratch, void* stream) {
+  if (!dy || !bits || !z || !mean || !rstd || !gamma || !dz || !dgamma || !dbeta || !scratch)
+    PL_FAIL(PL_EINVAL, "pl_bn_train_bwd: null pointer");
+  if (rows < 2 || rows > INT32_MAX || C <= 0 || (C & 3)) PL_FAIL(PL_ESHAPE, "pl_bn_train_bwd: rows=%lld C=%lld", (long long)rows, (long long)C);
+  hipStream_t s = (hipStream_t)stream;
+  const int B = (int)rows, H = (int)C, RC = bwd_row_chunks(B);
+  float* part = static_cast<float*>(scratch);
+  float* coef = part + (size_t)2 * RC * H;
+  float* part_db = coef + 3 * (size_t)H;
+  PL_TRY(launch_bn_bwd_reduce(dy, bits, z, mean, rstd, 1.0f, B, H, part, part + (size_t)RC * H, s));
+  PL_TRY(launch_bn_bwd_finalize(part, RC, 1, 0, B, H, gamma, rstd, coef, dgamma, dbeta, s));
+  return launch_bn_bwd_dz(dy, bits, z, mean, rstd, coef, 1.0f, 1, B, H, dz, part_db, s);
+}
+
+extern "C" int pl_add_relu_fwd(const float* a, const float* b, int64_t rows, int64_t C, float* out, uint64_t* bits,
+                               void* stream) {
+  if (!a || !b || !out || !bits) PL_FAIL(PL_EINVAL, "pl_add_relu_fwd: null pointer");
+  if (rows <= 0 || rows > INT32_MAX || C <= 0 || (C & 3)) PL_FAIL(PL_ESHAPE, "pl_add_relu_fwd: rows=%lld C=%lld", (long long)rows, (long long)C);
+  const int strips = ((int)C + 255) / 256;
+  dim3 grid(strips, stream_rows_grid((int)rows, strips));
+  hipLaunchKernelGGL(add_relu_kernel, grid, dim3(NTHR), 0, (hipStream_t)stream, a, b, out, bits, (int)rows, (int)C);
+  PL_CHECK_LAUNCH("add_relu");
+  return PL_OK;
+}
+
+extern "C" int pl_mask_by_bits(const float* g, const uint64_t* bits, int64_t rows, int64_t C, float* dx, void* stream) {
+  if (!g || !bits || !dx) PL_FAIL(PL_EINVAL, "pl_mask_by_bits: null pointer");
+  if (rows <= 0 || rows > INT32_MAX || C <= 0 || (C & 3)) PL_FAIL(PL_ESHAPE, "pl_mask_by_bits: rows=%lld C=%lld", (long long)rows, (long long)C);
+  const int strips = ((int)C + 255) / 256;
+  dim3 grid(strips, stream_rows_grid((int)rows, strips));
+  hipLaunchKernelGGL(mask_by_bits_kernel, grid, dim3(NTHR), 0, (hipStream_t)stream, g, bits, dx, (int)rows, (int)C);
+  PL_CHECK_LAUNCH("mask_by_bits");
   return PL_OK;
 }

@@ -190,9 +190,35 @@ int pl_conv2d_nhwc_wgrad(const float* x, int64_t B, int64_t H, int64_t W, int64_
                          int64_t Cout, int KH, int KW, int stride, int pad, float* dw, void* scratch,
                          size_t scratch_bytes, void* stream);
 
+/* Training-mode BatchNorm (+ ReLU) over the rows of a [rows][C] fp32 matrix: nn.BatchNorm2d on an NHWC feature map
+ * ([B*H*W][C]; phase4_joined/Resnet.py:56-63, Model.py:52-58) -- or BatchNorm1d -- with batch statistics, running
+ * statistics updated as torch does (momentum, unbiased variance, num_batches += 1).  C % 4 == 0, rows >= 2.
+ *   fwd: y = [relu](gamma * (z - mean) * rstd + beta); bits [rows][4*ceil(C/256)] 64-bit words (the layout of
+ *        pl_workspace_view which = 2): 1 where the output passed the ReLU (all ones without it); mean, rstd [C] saved.
+ *   bwd: dz, dgamma [C], dbeta [C] from dy and what fwd saved.
+ * scratch >= pl_bn_train_scratch_bytes(rows, C) for both. */
+size_t pl_bn_train_scratch_bytes(int64_t rows, int64_t C);
+int pl_bn_train_fwd(const float* z, int64_t rows, int64_t C, const float* gamma, const float* beta, float eps,
+                    float momentum, float* running_mean, float* running_var, int64_t* batches, int relu,
+                    float* y, uint64_t* bits, float* mean, float* rstd, void* scratch, void* stream);
+int pl_bn_train_bwd(const float* dy, const uint64_t* bits, const float* z, const float* mean, const float* rstd,
+                    const float* gamma, int64_t rows, int64_t C, float* dz, float* dgamma, float* dbeta,
+                    void* scratch, void* stream);
+/* The residual join of a Bottleneck in training mode (Resnet.py:90-91): out = relu(a + b) and its bitmap;
+ * backward: both inputs receive pl_mask_by_bits(g). */
+int pl_add_relu_fwd(const float* a, const float* b, int64_t rows, int64_t C, float* out, uint64_t* bits, void* stream);
+int pl_mask_by_bits(const float* g, const uint64_t* bits, int64_t rows, int64_t C, float* dx, void* stream);
+
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1)  phase4_joined/Resnet.py:119.  x [B][H][W][C], C % 4 == 0;
  * y [B][(H-1)/2+1][(W-1)/2+1][C]. */
 int pl_maxpool3x3s2_nhwc(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream);
+/* its backward: dx [B][H][W][C] from the forward input x and dy [B][Ho][Wo][C]; a window's gradient goes to its first
+ * maximum in (kh, kw) order, recomputed from x (no index tensor, no atomics). */
+int pl_maxpool3x3s2_nhwc_bwd(const float* x, const float* dy, int64_t B, int64_t H, int64_t W, int64_t C,
+                             float* dx, void* stream);
+/* out[c] = sum_r X[r][c] (fixed order): the bias gradient of the final 1x1 convolution (Model.py:66-69). */
+size_t pl_colsum_scratch_bytes(int64_t rows, int64_t cols);
+int pl_colsum(const float* X, int64_t rows, int64_t cols, float* out, void* scratch, void* stream);
 
 /* nn.ConvTranspose2d(kernel_size=4, stride=2, padding=1, bias=False) + folded BatchNorm2d + ReLU
  * phase4_joined/Model.py:47-63: x [B][Hi][Wi][Cin] -> y [B][2Hi][2Wi][Cout].  Each output parity

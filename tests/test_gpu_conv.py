@@ -129,8 +129,6 @@ def test_g9_resnet50_eval_forward_vs_reference(pkg):
     assert err < 2e-4 * scale, (err, scale)                   # fp32 round-off through 53 layers, relative to the peak
     cm = nchw.mean(dim=(0, 2, 3)).numpy()
     assert np.abs(cm - g["channel_mean"]).max() < 2e-4 * scale
-    with pytest.raises(NotImplementedError):
-        net.train()(frames)
 
 
 def test_model3d_eval_forward_vs_torch_cpu(pkg):
@@ -241,3 +239,142 @@ def test_conv2d_backward_vs_torch_autograd(pkg, B, H, Cin, Cout, k, stride, pad)
     want_dx = xr.grad.permute(0, 2, 3, 1)
     assert dx.shape == want_dx.shape
     assert float((dx.cpu().double() - want_dx).abs().max()) < 2e-5 * float(want_dx.abs().max())
+
+
+@pytest.mark.parametrize("rows,C,relu", [(2 * 16 * 16, 256, True), (3 * 7 * 5, 64, False), (4096, 2048, True)])
+def test_batchnorm2d_train_fwd_bwd_vs_torch(pkg, rows, C, relu):
+    """Training-mode BatchNorm2d (+ ReLU) over an NHWC map = BatchNorm over the rows of [rows][C]: forward, running
+    statistics and all three gradients against torch's batch_norm on the CPU (fp64)."""
+    g = torch.Generator().manual_seed(rows + C)
+    z = torch.randn(rows, C, generator=g) * 2 + 0.5
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5); bn.bias.copy_(torch.randn(C, generator=g) * 0.2)
+        bn.running_mean.copy_(torch.randn(C, generator=g) * 0.1); bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    ref = torch.nn.BatchNorm2d(C).double()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    zr = z.double().requires_grad_(True)
+    yr = ref.train()(zr.t().reshape(1, C, rows, 1))
+    yr = torch.relu(yr) if relu else yr
+    dy = torch.randn(rows, C, generator=g)
+    yr.backward(dy.double().t().reshape(1, C, rows, 1))
+    bnd = bn.to(DEV).train()
+    zd = z.to(DEV).requires_grad_(True)
+    y = pkg.conv.batchnorm_relu_train(zd.reshape(1, rows, 1, C), bnd, relu)
+    y.backward(dy.to(DEV).reshape(1, rows, 1, C))
+    want = yr.reshape(C, rows).t()
+    assert float((y.detach().reshape(rows, C).cpu().double() - want.detach()).abs().max()) < 2e-5
+    assert float((bnd.running_mean.cpu().double() - ref.running_mean).abs().max()) < 1e-6
+    assert float((bnd.running_var.cpu().double() - ref.running_var).abs().max()) < 1e-5
+    assert int(bnd.num_batches_tracked) == 1
+    gz = zr.grad
+    assert float((zd.grad.cpu().double() - gz).abs().max()) < 2e-5 * max(1.0, float(gz.abs().max()))
+    for ours, theirs in ((bnd.weight.grad, ref.weight.grad), (bnd.bias.grad, ref.bias.grad)):
+        assert float((ours.cpu().double() - theirs).abs().max()) < 2e-5 * max(1.0, float(theirs.abs().max()))
+
+
+def test_bottleneck_train_step_from_the_building_blocks_vs_torch(pkg):
+    """One Bottleneck (Resnet.py:51-95) in TRAINING mode assembled from the library's differentiable pieces --
+    conv2d_nhwc_autograd, batchnorm_relu_train, add_relu -- against the same stock module under torch autograd on the
+    CPU: output and every parameter / input gradient."""
+    torch.manual_seed(3)
+    blk = pkg.backbone.Bottleneck(256, 64, stride=1).train()
+    x = torch.randn(2, 16, 16, 256)
+    dy = torch.randn(2, 16, 16, 256)
+    # reference: stock PyTorch, NCHW, CPU
+    import copy
+    ref = copy.deepcopy(blk).double()
+    xr = x.permute(0, 3, 1, 2).double().requires_grad_(True)
+    o = torch.relu(ref.bn1(ref.conv1(xr)))
+    o = torch.relu(ref.bn2(ref.conv2(o)))
+    out_ref = torch.relu(ref.bn3(ref.conv3(o)) + xr)
+    out_ref.backward(dy.permute(0, 3, 1, 2).double())
+    # ours
+    b = blk.to(DEV)
+    ws = {n: pkg.conv.to_ohwi(getattr(b, n).weight.detach()).requires_grad_(True) for n in ("conv1", "conv2", "conv3")}
+    xd = x.to(DEV).requires_grad_(True)
+    o = pkg.conv.batchnorm_relu_train(pkg.conv.conv2d_nhwc_autograd(xd, ws["conv1"], 1, 0), b.bn1, True)
+    o = pkg.conv.batchnorm_relu_train(pkg.conv.conv2d_nhwc_autograd(o, ws["conv2"], 1, 1), b.bn2, True)
+    o = pkg.conv.batchnorm_relu_train(pkg.conv.conv2d_nhwc_autograd(o, ws["conv3"], 1, 0), b.bn3, False)
+    out = pkg.conv.add_relu(o, xd)
+    out.backward(dy.to(DEV))
+    close = lambda a, r, tol: float((a.cpu().double() - r).abs().max()) < tol * max(1.0, float(r.abs().max()))
+    assert close(out.detach(), out_ref.permute(0, 2, 3, 1), 5e-5)
+    assert close(xd.grad, xr.grad.permute(0, 2, 3, 1), 2e-4)
+    for n in ("conv1", "conv2", "conv3"):
+        assert close(ws[n].grad, getattr(ref, n).weight.grad.permute(0, 2, 3, 1), 2e-4), n
+    for n in ("bn1", "bn2", "bn3"):
+        assert close(getattr(b, n).weight.grad, getattr(ref, n).weight.grad, 2e-4), n
+        assert close(getattr(b, n).bias.grad, getattr(ref, n).bias.grad, 2e-4), n
+        assert close(getattr(b, n).running_var, getattr(ref, n).running_var, 1e-5), n
+
+
+def test_maxpool_backward_vs_torch(pkg):
+    x = torch.randn(2, 12, 10, 8)
+    x[0, 2:4, 2:4] = 1.5                                       # ties inside windows: first maximum wins, as in torch
+    xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    y = F.max_pool2d(xr, 3, 2, 1)
+    dy = torch.randn(y.shape)
+    y.backward(dy)
+    xd = x.to(DEV).requires_grad_(True)
+    yd = pkg.conv.maxpool3x3s2_nhwc_autograd(xd)
+    yd.backward(dy.permute(0, 2, 3, 1).contiguous().to(DEV))
+    assert torch.equal(xd.grad.cpu(), xr.grad.permute(0, 2, 3, 1))
+
+
+def test_model3d_train_step_vs_torch_autograd(pkg):
+    """Model_3D in TRAINING mode end to end on the library's differentiable pieces (53 convolutions with dgrad and
+    wgrad, 56 BatchNorms on batch statistics, max-pool, three transposed convolutions, biased 1x1, soft-argmax)
+    against the same stock modules under torch autograd on the CPU in fp64: loss and parameter gradients."""
+    import copy
+    torch.manual_seed(7)
+    m = pkg.Model_3D().train()
+    m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 51))
+    with torch.no_grad():
+        m.final_layer.weight.mul_(1e-3)
+    frames = pkg.synth.seeded_frames(2, 52, size=64)
+    target = torch.randn(2, 51)
+    def torch_step(dtype):
+        ref = copy.deepcopy(m).to(dtype)
+        r = ref.preact
+        x = frames.permute(0, 3, 1, 2).to(dtype)
+        x = F.max_pool2d(F.relu(r.bn1(r.conv1(x))), 3, 2, 1)
+        for li in (1, 2, 3, 4):
+            for blk in getattr(r, f"layer{li}"):
+                idn = x if blk.downsample is None else blk.downsample(x)
+                o = F.relu(blk.bn1(blk.conv1(x)))
+                o = F.relu(blk.bn2(blk.conv2(o)))
+                x = F.relu(blk.bn3(blk.conv3(o)) + idn)
+        out = ref.final_layer(ref.deconv_layers(x))
+        B, _, H, W = out.shape
+        hm = torch.softmax(out.reshape(B, 17, -1), 2).reshape(B, 17, 64, H, W)
+        cx = (hm.sum((2, 3)) * torch.arange(W, dtype=dtype)).sum(2, keepdim=True)
+        cy = (hm.sum((2, 4)) * torch.arange(H, dtype=dtype)).sum(2, keepdim=True)
+        cz = (hm.sum((3, 4)) * torch.arange(64, dtype=dtype)).sum(2, keepdim=True)
+        pred = torch.cat(((cx / W - .5) * 2, (cy / H - .5) * 2, (cz / 64 - .5) * 2), 2).reshape(B, 51)
+        loss = ((pred - target.to(dtype)) ** 2).mean()
+        loss.backward()
+        return ref, loss
+
+    ref, loss_ref = torch_step(torch.float64)
+    ref32, _ = torch_step(torch.float32)        # the noise floor: stock fp32 against its own fp64 (batch statistics over
+    r = ref.preact                              # as few as 8 rows amplify round-off through 50 layers)
+    md = m.to(DEV)
+    pred = md(frames.to(DEV))
+    loss = ((pred - target.to(DEV)) ** 2).mean()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-4 * max(1.0, abs(float(loss_ref.detach())))
+    checked = 0
+    for (k, p), (_, q), (_, q32) in zip(md.named_parameters(), ref.named_parameters(), ref32.named_parameters()):
+        if p.grad is None:
+            continue
+        gr = q.grad
+        scale = float(gr.abs().max())
+        if scale < 1e-12:
+            continue
+        err = float((p.grad.cpu().double() - gr).abs().max())
+        floor = float((q32.grad.double() - gr).abs().max())
+        assert err < 4 * floor + 1e-3 * scale, (k, err, floor, scale)
+        checked += 1
+    assert checked > 150
+    assert float((md.preact.bn1.running_mean.cpu().double() - r.bn1.running_mean).abs().max()) < 1e-5
