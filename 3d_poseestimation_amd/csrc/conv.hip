@@ -118,6 +118,29 @@ __global__ __launch_bounds__(NTHR) void maxpool3x3s2_nhwc_bwd_kernel(const float
   *reinterpret_cast<float4*>(dx + t * 4) = make_float4(g[0], g[1], g[2], g[3]);
 }
 
+// part[chunk][c] = sum over the chunk's rows of X[r][c]; grid = (ceil(cols/256), chunks), rows interleaved by 4*chunks
+__global__ __launch_bounds__(NTHR) void colsum_wide_kernel(const float* __restrict__ X, int rows, int cols,
+                                                           float* __restrict__ part) {
+  __shared__ float4 sm[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const bool active = c < cols;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active)
+    for (int r = blockIdx.y * 4 + wave; r < rows; r += gridDim.y * 4) {
+      const float4 v = *reinterpret_cast<const float4*>(X + (size_t)r * cols + c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  sm[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && active) {
+    float4 t = sm[0][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) { t.x += sm[w][lane].x; t.y += sm[w][lane].y; t.z += sm[w][lane].z; t.w += sm[w][lane].w; }
+    *reinterpret_cast<float4*>(part + (size_t)blockIdx.y * cols + c) = t;
+  }
+}
+
 // y[b][2a+ph][2c+pw][:] = part[ph*2+pw][b][a][c][:]
 __global__ __launch_bounds__(NTHR) void deconv_interleave_kernel(const float* __restrict__ part, int Hi, int Wi, int C,
                                                                  int64_t n4_per_part, float* __restrict__ y) {
@@ -292,7 +315,8 @@ static int wgrad_splits(int64_t M, int64_t N, int64_t K) {
 }
 
 static bool wgrad_implicit_ok(int64_t Cin, int64_t Cout, int64_t N, int64_t K, int64_t Wo) {
-  return Cout % 128 == 0 && N % 128 == 0 && (Cin & 1) == 0 && Wo % 8 == 0 && K % 32 == 0;
+  (void)N;                               // ragged Cout / KH*KW*Cin tiles are clamped and masked
+  return (Cout & 1) == 0 && (Cin & 1) == 0 && Wo % 8 == 0 && K % 32 == 0;
 }
 
 // scratch: [split-K slabs: splits x Cout x N] then, on the fallback path, [im2col: pixels x N]
@@ -363,15 +387,32 @@ extern "C" int pl_maxpool3x3s2_nhwc_bwd(const float* x, const float* dy, int64_t
   return PL_OK;
 }
 
-// out[c] = sum_r X[r][c]: the bias gradient of a convolution (fixed-order two-stage sum)
+// out[c] = sum_r X[r][c]: the bias gradient of a convolution (fixed-order two-stage sum).  cols % 4 == 0 takes a
+// strip-parallel pass (256 columns x a row chunk per workgroup, float4 per lane); the generic kernel walks all
+// columns in one workgroup per row chunk (3.5 ms for the head's 131072 x 1088 gradient).
+static int colsum_wide_chunks(int64_t rows) {
+  int64_t rc = (rows + 255) / 256;
+  if (rc > 128) rc = 128;
+  return rc < 1 ? 1 : (int)rc;
+}
+
 extern "C" size_t pl_colsum_scratch_bytes(int64_t rows, int64_t cols) {
-  return rows > 0 && cols > 0 ? (size_t)colsum_chunks((int)rows) * cols * sizeof(float) : 0;
+  if (rows <= 0 || cols <= 0) return 0;
+  const int rc = colsum_chunks((int)rows) > colsum_wide_chunks(rows) ? colsum_chunks((int)rows) : colsum_wide_chunks(rows);
+  return (size_t)rc * cols * sizeof(float);
 }
 
 extern "C" int pl_colsum(const float* X, int64_t rows, int64_t cols, float* out, void* scratch, void* stream) {
   if (!X || !out || !scratch) PL_FAIL(PL_EINVAL, "pl_colsum: null pointer");
   if (rows <= 0 || rows > INT32_MAX || cols <= 0 || cols > INT32_MAX) PL_FAIL(PL_ESHAPE, "pl_colsum: bad shape");
   hipStream_t s = (hipStream_t)stream;
+  if ((cols & 3) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+    const int rc = colsum_wide_chunks(rows);
+    hipLaunchKernelGGL(colsum_wide_kernel, dim3((unsigned)((cols + 255) / 256), rc), dim3(NTHR), 0, s, X, (int)rows,
+                       (int)cols, static_cast<float*>(scratch));
+    PL_CHECK_LAUNCH("colsum_wide");
+    return launch_reduce_slabs(static_cast<const float*>(scratch), rc, cols, out, s);
+  }
   PL_TRY(launch_colsum_partial(X, (int)rows, (int)cols, static_cast<float*>(scratch), s));
   return launch_reduce_slabs(static_cast<const float*>(scratch), colsum_chunks((int)rows), cols, out, s);
 }

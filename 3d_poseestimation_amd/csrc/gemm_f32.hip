@@ -630,7 +630,8 @@ __device__ __forceinline__ void load_tile_p(Stage& s, const float* __restrict__ 
     s.v0 = *reinterpret_cast<const float4*>(t);
     s.v1 = *reinterpret_cast<const float4*>(t + 4);
   } else if (BKX == 32) {
-    const float* t = base + (size_t)(k0 + (tid >> 6) * 8) * ld + r0 + (tid & 63) * 2;
+    // rmax (ragged wgrad launches): the last valid column; a pair past it re-reads the last pair
+    const float* t = base + (size_t)(k0 + (tid >> 6) * 8) * ld + min(r0 + (tid & 63) * 2, rmax - 1);
     float2 q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) q[j] = *reinterpret_cast<const float2*>(t + (size_t)j * ld);
@@ -789,6 +790,7 @@ __device__ __forceinline__ void store_half_p(char* __restrict__ op, int tid, con
 // N_EDGE (k-contiguous B, BK 32 only): N need not be a multiple of 128 -- the last column tile clamps its B
 // rows and the guarded epilogue drops the columns >= N (the 64-wide layer1 convolutions, the 1088-wide head).
 // With the convolution gather (A_CONV) M may be ragged too: conv_row clamps the pixel index.
+// B_WGRAD + N_EDGE: ragged Cout (M) and KH*KW*Cin (N): both loaders clamp, the guarded epilogue drops the rest.
 template <bool A_KS, bool B_KS, int BKX, bool A_CONV = false, bool N_EDGE = false, bool B_WGRAD = false>
 __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int block_id, const int nwork,
                                                  char* __restrict__ lds) {
@@ -798,9 +800,9 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
   const int lane = tid & 63, wave = tid >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  static_assert(!N_EDGE || (!B_KS && BKX == 32), "ragged N only with the k-contiguous BK 32 B loader");
+  static_assert(!N_EDGE || ((!B_KS || B_WGRAD) && BKX == 32), "ragged N only with the k-contiguous or gathered BK 32 B loader");
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int nlast = N_EDGE ? p.N - 1 : 0x7fffffff;
+  const int nlast = (N_EDGE && !B_WGRAD) ? p.N - 1 : 0x7fffffff;
   const int splits = p.split_k > 1 ? p.split_k : 1;
   const int ntiles = nwork / splits;
   int w = block_id;
@@ -854,7 +856,7 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
   char* nx1 = lds + Cf::STAGE;        // tile kt+1: complete, readable
   char* nx2 = lds + 2 * Cf::STAGE;    // tile kt+2: being written during step kt
   static_assert(!A_CONV || (!A_KS && BKX == 32), "the convolution gather is a k-contiguous BK 32 loader");
-  static_assert(!B_WGRAD || (A_KS && B_KS && BKX == 32 && !A_CONV && !N_EDGE), "wgrad is the TN BK 32 loop");
+  static_assert(!B_WGRAD || (A_KS && B_KS && BKX == 32 && !A_CONV), "wgrad is the TN BK 32 loop");
   using SA = Stage;
   SA ra0, ra1;                        // staging register sets: tile t lives in set t % 2
   Stage rb0, rb1;
@@ -862,10 +864,10 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
   if (A_CONV) { cr0 = conv_row(p, m0 + (tid >> 2)); cr1 = conv_row(p, m0 + (tid >> 2) + 64); }
   auto load_a = [&](SA& d, const int k0) {
     if constexpr (A_CONV) load_tile_conv(d, p, cr0, cr1, k0, tid);
-    else load_tile_p<A_KS, BKX>(d, p.A, p.lda, m0, k0, tid);
+    else load_tile_p<A_KS, BKX>(d, p.A, p.lda, m0, k0, tid, (B_WGRAD && N_EDGE) ? p.M - 1 : 0x7fffffff);
   };
   WgradCol wcol = {};
-  if (B_WGRAD) wcol = wgrad_col(p, n0 + (tid & 63) * 2);
+  if (B_WGRAD) wcol = wgrad_col(p, N_EDGE ? min(n0 + (tid & 63) * 2, p.N - 2) : n0 + (tid & 63) * 2);
   auto load_b = [&](Stage& d, const int k0) {
     if constexpr (B_WGRAD) load_tile_wgrad(d, p, wcol, k0, tid);
     else load_tile_p<B_KS, BKX>(d, p.B, p.ldb, n0, k0, tid, nlast);
@@ -981,9 +983,10 @@ __global__ __launch_bounds__(256) void conv_x6_planes_kernel(GemmArgs p) {
   gemm_body_planes<false, false, 32, true, N_EDGE>(p, blockIdx.x, gridDim.x, lds);
 }
 
+template <bool MN_EDGE>
 __global__ __launch_bounds__(256) void conv_wgrad_x6_planes_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[PCfg<32>::LDS];
-  gemm_body_planes<true, true, 32, false, false, true>(p, blockIdx.x, gridDim.x, lds);
+  gemm_body_planes<true, true, 32, false, MN_EDGE, true>(p, blockIdx.x, gridDim.x, lds);
 }
 
 struct GemmArgs4 { GemmArgs g[4]; };
@@ -1145,14 +1148,16 @@ int launch_conv_nhwc(const GemmArgs& a, hipStream_t s) {
 int launch_conv_wgrad(const GemmArgs& a, hipStream_t s) {
   if (!a.A || !a.B || !a.C) PL_FAIL(PL_EINVAL, "conv wgrad: null operand");
   const int splits = a.split_k > 1 ? a.split_k : 1;
-  if (a.conv_cin <= 0 || (a.conv_cin & 1) || a.M % BM || a.N % BN || a.N % a.conv_cin || a.conv_wo % 8 ||
-      a.K % (BK * splits) || a.K != (a.K / (a.conv_ho * a.conv_wo)) * a.conv_ho * a.conv_wo || (a.lda & 3))
-    PL_FAIL(PL_ESHAPE, "conv wgrad: needs Cout %% 128 == 0, KH*KW*Cin %% 128 == 0, Wo %% 8 == 0, pixels %% (32*splits) == 0 "
+  if (a.conv_cin <= 0 || (a.conv_cin & 1) || a.M < 2 || (a.M & 1) || a.N < 2 || a.N % a.conv_cin || a.conv_wo % 8 ||
+      a.K % (BK * splits) || a.K != (a.K / (a.conv_ho * a.conv_wo)) * a.conv_ho * a.conv_wo || (a.lda & 1))
+    PL_FAIL(PL_ESHAPE, "conv wgrad: needs even Cout and Cin, Wo %% 8 == 0, pixels %% (32*splits) == 0 "
                        "(M=%d N=%d K=%d Cin=%d Wo=%d splits=%d)", a.M, a.N, a.K, a.conv_cin, a.conv_wo, splits);
-  if ((reinterpret_cast<uintptr_t>(a.A) & 15) || (reinterpret_cast<uintptr_t>(a.B) & 7))
+  if ((reinterpret_cast<uintptr_t>(a.A) & 7) || (reinterpret_cast<uintptr_t>(a.B) & 7))
     PL_FAIL(PL_EINVAL, "conv wgrad: operands misaligned");
   ProfRec* prof = prof_begin(a, s);
-  hipLaunchKernelGGL(conv_wgrad_x6_planes_kernel, dim3((a.M / BM) * (a.N / BN) * splits), dim3(NTHR), 0, s, a);
+  const dim3 grid(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * splits);
+  if (a.M % BM || a.N % BN) hipLaunchKernelGGL(conv_wgrad_x6_planes_kernel<true>, grid, dim3(NTHR), 0, s, a);
+  else hipLaunchKernelGGL(conv_wgrad_x6_planes_kernel<false>, grid, dim3(NTHR), 0, s, a);
   if (prof) (void)hipEventRecord(prof->e1, s);
   PL_CHECK_LAUNCH("conv_wgrad_x6_planes");
   return PL_OK;

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""phase4 train step (BASELINE configs[3] shape: 256x256 frames; phase4_joined/train.py:69-89: forward, MSE, backward,
+Adam lr 1e-3) -- this library's first, unfused cut of the conv path beside PyTorch-ROCm eager of the same stock modules.
+    python tools/bench_model3d_train.py [--B 32] [--iters 5]"""
+import argparse, copy, importlib, os, sys, time, torch
+import torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("3d_poseestimation_amd")
+from tools.bench_model3d import torch_forward  # noqa: E402
+
+
+def timed(step, iters):
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=32); ap.add_argument("--iters", type=int, default=5)
+    a = ap.parse_args()
+    m = pkg.Model_3D().train()
+    m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 31))
+    with torch.no_grad():
+        m.final_layer.weight.mul_(1e-3)
+    ours = copy.deepcopy(m).to("cuda")
+    eager = copy.deepcopy(m).to("cuda")
+    frames = pkg.synth.seeded_frames(a.B, 5).to("cuda")
+    target = torch.randn(a.B, 51, device="cuda")
+    opt_o = torch.optim.Adam(ours.parameters(), lr=1e-3)
+    opt_e = torch.optim.Adam(eager.parameters(), lr=1e-3)
+
+    def step_ours():
+        opt_o.zero_grad()
+        F.mse_loss(ours(frames), target).backward()
+        opt_o.step()
+
+    xn = frames.permute(0, 3, 1, 2).contiguous()
+
+    def step_eager():
+        opt_e.zero_grad()
+        F.mse_loss(torch_forward(eager, xn), target).backward()
+        opt_e.step()
+
+    t = timed(step_ours, a.iters)
+    print(f"B={a.B} this library (unfused first cut, fp32-grade) : {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
+    t = timed(step_eager, a.iters)
+    print(f"B={a.B} PyTorch-ROCm eager fp32                      : {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
+
+
+if __name__ == "__main__":
+    main()
