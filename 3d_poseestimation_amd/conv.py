@@ -115,6 +115,15 @@ def conv2d_nhwc_dgrad(dy, w_ohwi, in_hw, stride=1, padding=0):
         if dx.shape[1:3] != (H, W):
             raise ValueError("conv2d_nhwc_dgrad: input size does not match")
         return dx
+    if stride == 2 and H % 2 == 0 and W % 2 == 0 and KH == 1 and KW == 1 and padding == 0:
+        # dy W on the even pixels: one GEMM ([M][Cout] x [Cout][Cin], the OHWI filter read as [Cin][1][1][Cout]^T)
+        B, Ho, Wo, _ = dy.shape
+        t = conv2d_nhwc(dy, w_ohwi.reshape(Cout, Cin).t().contiguous().reshape(Cin, 1, 1, Cout), 1, 0)
+        dx = torch.empty(B, H, W, Cin, dtype=torch.float32, device=dy.device)
+        with torch.cuda.device(dy.device):
+            rc = _lib.lib().pl_upsample2x_zero_nhwc(t.data_ptr(), B, Ho, Wo, Cin, dx.data_ptr(), _lib.current_stream_ptr())
+        _lib.check(rc, "pl_upsample2x_zero_nhwc")
+        return dx
     if stride == 2 and H % 2 == 0 and W % 2 == 0 and (KH, padding) in ((3, 1), (1, 0)) and KH == KW:
         # ConvTranspose2d weight [in = Cout][out = Cin][4][4]; with padding 1: kh -> kh, with padding 0: kh -> kh + 1
         w4 = torch.zeros(Cout, Cin, 4, 4, dtype=torch.float32, device=w_ohwi.device)

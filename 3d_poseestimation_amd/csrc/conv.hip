@@ -141,6 +141,23 @@ __global__ __launch_bounds__(NTHR) void colsum_wide_kernel(const float* __restri
   }
 }
 
+// y[b][2a][2c][:] = x[b][a][c][:], zero elsewhere: the input gradient of a 1x1 stride-2 convolution is dy W placed
+// on the even pixels
+__global__ __launch_bounds__(NTHR) void upsample2x_zero_kernel(const float* __restrict__ x, int Hi, int Wi, int C,
+                                                               int64_t n4_out, float* __restrict__ y) {
+  const int64_t t = (int64_t)blockIdx.x * NTHR + threadIdx.x;
+  if (t >= n4_out) return;
+  const int c4 = C >> 2;
+  const int c = (int)(t % c4) * 4;
+  int64_t r = t / c4;
+  const int ow = (int)(r % (2 * Wi)); r /= 2 * Wi;
+  const int oh = (int)(r % (2 * Hi));
+  const int64_t b = r / (2 * Hi);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!(oh & 1) && !(ow & 1)) v = *reinterpret_cast<const float4*>(x + ((b * Hi + (oh >> 1)) * Wi + (ow >> 1)) * C + c);
+  *reinterpret_cast<float4*>(y + t * 4) = v;
+}
+
 // y[b][2a+ph][2c+pw][:] = part[ph*2+pw][b][a][c][:]
 __global__ __launch_bounds__(NTHR) void deconv_interleave_kernel(const float* __restrict__ part, int Hi, int Wi, int C,
                                                                  int64_t n4_per_part, float* __restrict__ y) {
@@ -415,4 +432,16 @@ extern "C" int pl_colsum(const float* X, int64_t rows, int64_t cols, float* out,
   }
   PL_TRY(launch_colsum_partial(X, (int)rows, (int)cols, static_cast<float*>(scratch), s));
   return launch_reduce_slabs(static_cast<const float*>(scratch), colsum_chunks((int)rows), cols, out, s);
+}
+
+extern "C" int pl_upsample2x_zero_nhwc(const float* x, int64_t B, int64_t Hi, int64_t Wi, int64_t C, float* y,
+                                       void* stream) {
+  if (!x || !y) PL_FAIL(PL_EINVAL, "pl_upsample2x_zero_nhwc: null pointer");
+  if (B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0 || (C & 3)) PL_FAIL(PL_ESHAPE, "pl_upsample2x_zero_nhwc: C %% 4 == 0 needed");
+  const int64_t n4 = B * 4 * Hi * Wi * (C >> 2);
+  if (n4 > (int64_t)INT32_MAX * NTHR) PL_FAIL(PL_ESHAPE, "pl_upsample2x_zero_nhwc: too large");
+  hipLaunchKernelGGL(upsample2x_zero_kernel, dim3((unsigned)((n4 + NTHR - 1) / NTHR)), dim3(NTHR), 0,
+                     (hipStream_t)stream, x, (int)Hi, (int)Wi, (int)C, n4, y);
+  PL_CHECK_LAUNCH("upsample2x_zero");
+  return PL_OK;
 }

@@ -46,7 +46,7 @@ __device__ __forceinline__ float parts_sum(float v, float (*red)[RCOLS], int cl,
 // so the result is the one a single process gets on the concatenated batch (when Br % 128 == 0 even
 // bit for bit: same partials, same order).
 __global__ __launch_bounds__(NTHR) void bn_finalize_kernel(
-    const float* __restrict__ stat, int G, int world, int Br, int H,
+    const float* __restrict__ stat, int G, int world, int Br, int H, int gs,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* running_mean, float* running_var, int64_t* batches, float* mean_out, float* rstd_out,
     float* scale_out, float* shift_out) {
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(NTHR) void bn_finalize_kernel(
   if (ok)
     for (int g = part; g < GT; g += RPARTS) {
       const int r = g / G, gl = g - r * G;
-      const int n = max(0, min(64, Br - gl * 64));
+      const int n = max(0, min(gs, Br - gl * gs));
       if (n > 0) {
         const size_t at = (size_t)r * 2 * GH + (size_t)gl * H + c;
         const float d = stat[at] / (float)n - mean;
@@ -112,13 +112,13 @@ __device__ __forceinline__ float4 combine4(float4 v, float4 (*sm)[64], int wave,
 // Column statistics of a [B][H] matrix in the layout bn_finalize merges: per 64-row group the column sums
 // and the sums of squares about the group mean (what the GEMM epilogue emits for the lifter; the conv path's
 // BatchNorm2d over [B*H*W][C] computes them here).  grid = (ceil(H/256), ceil(B/64)).
-__global__ __launch_bounds__(NTHR) void bn_colstats_kernel(const float* __restrict__ z, int B, int H,
+__global__ __launch_bounds__(NTHR) void bn_colstats_kernel(const float* __restrict__ z, int B, int H, int gs,
                                                            float* __restrict__ stat_sum, float* __restrict__ stat_m2) {
   __shared__ float4 sm[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 256 + lane * 4;
   const bool active = c < H;
-  const int r0 = blockIdx.y * 64, r1 = min(B, r0 + 64);
+  const int r0 = blockIdx.y * gs, r1 = min(B, r0 + gs);
   float4 s = make_float4(0, 0, 0, 0);
   if (active)
     for (int r = r0 + wave; r < r1; r += 4) {
@@ -703,9 +703,9 @@ inline int stream_rows_grid(int B, int strips) {
 int launch_bn_finalize(const float* stat, int G, int world, int B, int H,
                        const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, int64_t* batches, float* mean,
-                       float* rstd, float* scale, float* shift, hipStream_t s) {
+                       float* rstd, float* scale, float* shift, hipStream_t s, int group_rows) {
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((H + RCOLS - 1) / RCOLS), dim3(NTHR), 0, s, stat, G, world, B,
-                     H, gamma, beta, eps, momentum, running_mean, running_var, batches, mean, rstd,
+                     H, group_rows, gamma, beta, eps, momentum, running_mean, running_var, batches, mean, rstd,
                      scale, shift);
   PL_CHECK_LAUNCH("bn_finalize");
   return PL_OK;
@@ -994,7 +994,10 @@ extern "C" int pl_l1_terms_fwd_bwd(const PLL1Term* terms, int nterms, float grad
 // BatchNorm over the rows of a [rows][C] matrix as stand-alone entry points (the conv path: an NHWC feature
 // map IS that matrix, BatchNorm2d = BatchNorm1d over its rows).  Same kernels as the lifter's layers.
 // =====================================================================================
-static int bn_groups(int64_t rows) { return (int)((rows + 63) / 64); }
+// rows per statistics group: 64 (the GEMM epilogue's unit) up to 16 K rows, then 1024 -- a 131072-row map would
+// otherwise hand the finalize kernel 2048 partials per column (38 us per layer)
+static int bn_group_rows(int64_t rows) { return rows > 16384 ? 1024 : 64; }
+static int bn_groups(int64_t rows) { const int gs = bn_group_rows(rows); return (int)((rows + gs - 1) / gs); }
 
 extern "C" size_t pl_bn_train_scratch_bytes(int64_t rows, int64_t C) {
   if (rows <= 0 || C <= 0) return 0;
@@ -1014,10 +1017,11 @@ extern "C" int pl_bn_train_fwd(const float* z, int64_t rows, int64_t C, const fl
   float* stat = static_cast<float*>(scratch);
   float* scale = stat + (size_t)2 * G * H;
   float* shift = scale + H;
-  hipLaunchKernelGGL(bn_colstats_kernel, dim3((H + 255) / 256, G), dim3(NTHR), 0, s, z, B, H, stat, stat + (size_t)G * H);
+  const int gs = bn_group_rows(rows);
+  hipLaunchKernelGGL(bn_colstats_kernel, dim3((H + 255) / 256, G), dim3(NTHR), 0, s, z, B, H, gs, stat, stat + (size_t)G * H);
   PL_CHECK_LAUNCH("bn_colstats");
   PL_TRY(launch_bn_finalize(stat, G, 1, B, H, gamma, beta, eps, momentum, running_mean, running_var, batches, mean, rstd,
-                            scale, shift, s));
+                            scale, shift, s, gs));
   const int strips = (H + 255) / 256;
   dim3 grid(strips, stream_rows_grid(B, strips));
   hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NTHR), 0, s, z, scale, shift, (const float*)nullptr, y, bits, B, H,

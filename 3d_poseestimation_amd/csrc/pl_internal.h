@@ -87,7 +87,7 @@ inline int bitmap_words_per_row(int H) { return ((H + 255) / 256) * 4; }
 int launch_bn_finalize(const float* stat, int G, int world, int B, int H,
                        const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, int64_t* batches,
-                       float* mean, float* rstd, float* scale, float* shift, hipStream_t s);
+                       float* mean, float* rstd, float* scale, float* shift, hipStream_t s, int group_rows = 64);
 
 // act = [resid +] dropout(relu(z*scale + shift)); bits = keep&positive bitmap
 int launch_bn_apply(const float* z, const float* scale, const float* shift, const float* resid,

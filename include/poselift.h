@@ -216,6 +216,9 @@ int pl_maxpool3x3s2_nhwc(const float* x, int64_t B, int64_t H, int64_t W, int64_
  * maximum in (kh, kw) order, recomputed from x (no index tensor, no atomics). */
 int pl_maxpool3x3s2_nhwc_bwd(const float* x, const float* dy, int64_t B, int64_t H, int64_t W, int64_t C,
                              float* dx, void* stream);
+/* y [B][2Hi][2Wi][C]: x on the even pixels, zero elsewhere -- the input gradient of a 1x1 stride-2 convolution
+ * (the downsample branches, Resnet.py:151-158) is dy W (a GEMM) placed this way. */
+int pl_upsample2x_zero_nhwc(const float* x, int64_t B, int64_t Hi, int64_t Wi, int64_t C, float* y, void* stream);
 /* out[c] = sum_r X[r][c] (fixed order): the bias gradient of the final 1x1 convolution (Model.py:66-69). */
 size_t pl_colsum_scratch_bytes(int64_t rows, int64_t cols);
 int pl_colsum(const float* X, int64_t rows, int64_t cols, float* out, void* scratch, void* stream);
