@@ -994,9 +994,9 @@ extern "C" int pl_l1_terms_fwd_bwd(const PLL1Term* terms, int nterms, float grad
 // BatchNorm over the rows of a [rows][C] matrix as stand-alone entry points (the conv path: an NHWC feature
 // map IS that matrix, BatchNorm2d = BatchNorm1d over its rows).  Same kernels as the lifter's layers.
 // =====================================================================================
-// rows per statistics group: 64 (the GEMM epilogue's unit) up to 16 K rows, then 1024 -- a 131072-row map would
+// rows per statistics group: 64 (the GEMM epilogue's unit) up to 16 K rows, then 256 -- a 131072-row map would
 // otherwise hand the finalize kernel 2048 partials per column (38 us per layer)
-static int bn_group_rows(int64_t rows) { return rows > 16384 ? 1024 : 64; }
+static int bn_group_rows(int64_t rows) { return rows > 16384 ? 256 : 64; }
 static int bn_groups(int64_t rows) { const int gs = bn_group_rows(rows); return (int)((rows + gs - 1) / gs); }
 
 extern "C" size_t pl_bn_train_scratch_bytes(int64_t rows, int64_t C) {
