@@ -231,7 +231,6 @@ class _BNReLUFn(torch.autograd.Function):
         _lib.check(rc, "pl_bn_train_fwd")
         ctx.save_for_backward(z2, bits, mean, rstd, gamma)
         ctx.shape = shape
-        ctx.mark_non_differentiable(running_mean, running_var, batches)
         return y.reshape(shape)
 
     @staticmethod
