@@ -181,6 +181,21 @@ class _HeatmapNet(nn.Module):
         return conv.nhwc_to_nchw_autograd(out)
 
 
+    def predict_nhwc(self, x_nhwc):
+        """Coordinates from NHWC frames, in whichever mode the module is in (phase5's cycle step feeds BOTH networks
+        the same frames; their reference forwards disagree about the input layout, this entry point does not)."""
+        if self.training:
+            logits = self._heatmap_logits_train(x_nhwc)
+            return (soft_argmax_3d(logits, self.num_joints, self.depth_dim) if self.depth_dim > 1
+                    else soft_argmax_2d(logits, self.num_joints))
+        with torch.no_grad():
+            if self.depth_dim == 64:
+                return soft_argmax_3d_nhwc(self.heatmap_logits_nhwc(x_nhwc), self.num_joints)
+            logits = self.heatmap_logits(x_nhwc)
+            return (soft_argmax_3d(logits, self.num_joints, self.depth_dim) if self.depth_dim > 1
+                    else soft_argmax_2d(logits, self.num_joints))
+
+
 class Model_3D(_HeatmapNet):
     def __init__(self, architecture="resnet50"):
         super().__init__(64, architecture)

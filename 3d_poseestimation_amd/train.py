@@ -4,6 +4,7 @@
   eval_step         /root/reference/phase1_lifting/train_1.py:112-145
   loss_MPJPE        /root/reference/phase1_lifting/train_1.py:19-23
   epoch_mpjpe_mm    /root/reference/phase1_lifting/train_1.py:100-104
+  cycle_step        /root/reference/phase5_loop/train_5 copy.py:147-236 (the Triangle branch, without its Flip pass)
 All arithmetic is in libposelift.so; tensors must live on the ROCm device.
 """
 import torch
@@ -157,3 +158,30 @@ def eval_step(model, y1, y2, metric_out=None, flip=False):
     loss = mse_loss(y2_hat, y2)
     metric = loss_MPJPE(y2_hat, y2, out=metric_out)
     return loss, metric, y2_hat
+
+
+def cycle_step(model_2d, model_3d, model_lift, optimizers, frame_nhwc, y1, y2, loss_function, model_proj=None):
+    """One phase5 cycle step (train_5 copy.py:147-236, `Triangle` on, `Flip` off): zero_grad on every optimizer;
+    y1^ = model_2d(frame), y2^ = model_3d(frame); the lifter on the predicted AND on the ground-truth 2-D pose (two
+    calls in one graph: its input gradient flows back into model_2d); optionally the projector on y2^ and y2;
+    TriangleLoss; ONE backward; every optimizer steps.  frame_nhwc [B, H, W, 3]; y1 [B, 17, 2]; y2 [B, 17, 3].
+    Returns (loss, y1_hat, y2_hat) as device tensors (the reference's `.cpu().item()` per step is the caller's choice)."""
+    for opt in optimizers:
+        opt.zero_grad()
+    B = y1.shape[0]
+    y1, y2 = y1.float(), y2.float()
+    frame = frame_nhwc.float()
+    y1_hat = model_2d.predict_nhwc(frame).reshape(B, 17, 2)
+    y2_hat = model_3d.predict_nhwc(frame).reshape(B, 17, 3)
+    lift_2d_pred = model_lift(y1_hat).reshape(B, 17, 3)
+    lift_2d_gt = model_lift(y1).reshape(B, 17, 3)
+    kw = {}
+    if model_proj is not None:
+        kw = dict(proj_3d_pred=model_proj(y2_hat).reshape(B, 17, 2), proj_3d_gt=model_proj(y2).reshape(B, 17, 2))
+    out = loss_function(predicted_2d=y1_hat, predicted_3d=y2_hat, lift_2d_gt=lift_2d_gt, lift_2d_pred=lift_2d_pred,
+                        gt_2d=y1, gt_3d=y2, **kw)
+    loss = out[0] if isinstance(out, tuple) else out
+    loss.backward()
+    for opt in optimizers:
+        opt.step()
+    return loss.detach(), y1_hat.detach(), y2_hat.detach()

@@ -378,3 +378,42 @@ def test_model3d_train_step_vs_torch_autograd(pkg):
         checked += 1
     assert checked > 150
     assert float((md.preact.bn1.running_mean.cpu().double() - r.bn1.running_mean).abs().max()) < 1e-5
+
+
+def test_phase5_cycle_step_runs_and_couples_the_networks(pkg):
+    """train_5 copy.py:147-236 assembled from the library's pieces: Model_2D + Model_3D (training mode) on the same
+    NHWC frames, the lifter called on the predicted and on the true 2-D pose, the projector LinearModel(51, 34, 64),
+    TriangleLoss, one backward, four optimizers.  Checks the plumbing every component test cannot: the lifter's input
+    gradient reaches the 2-D network, every model's parameters move, the loss goes down on a repeated batch."""
+    torch.manual_seed(0)
+    m2 = pkg.Model_2D().train()
+    m3 = pkg.Model_3D().train()
+    for m, seed in ((m2, 61), (m3, 62)):
+        m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), seed))
+        with torch.no_grad():
+            m.final_layer.weight.mul_(1e-3)
+    m2, m3 = m2.to(DEV), m3.to(DEV)
+    lift = pkg.LinearModel(34, 51, linear_size=256, p_dropout=0.0).to(DEV).train()
+    proj = pkg.LinearModel(51, 34, linear_size=64, p_dropout=0.0).to(DEV).train()
+    opts = [torch.optim.Adam(m2.parameters(), lr=1e-4), torch.optim.Adam(m3.parameters(), lr=1e-4),
+            pkg.FlatAdamW(lift, lr=1e-3), pkg.FlatAdamW(proj, lr=1e-3)]
+    frames = pkg.synth.seeded_frames(4, 63, size=64).to(DEV)
+    y1, y2 = pkg.synth.synthetic_batch(4, 64, DEV)
+    crit = pkg.TriangleLoss(Project=True, era="lifter")
+    before = [m2.final_layer.bias.detach().clone(), m3.final_layer.bias.detach().clone(), lift.flat_params.clone(),
+              proj.flat_params.clone()]
+    losses = []
+    for _ in range(4):
+        loss, y1_hat, y2_hat = pkg.cycle_step(m2, m3, lift, opts, frames, y1, y2, crit, model_proj=proj)
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+    assert y1_hat.shape == (4, 17, 2) and y2_hat.shape == (4, 17, 3)
+    after = [m2.final_layer.bias.detach(), m3.final_layer.bias.detach(), lift.flat_params, proj.flat_params]
+    assert all(not torch.equal(a, b) for a, b in zip(before, after))
+    # the lifter's input gradient is the ONLY path from the lift terms into the 2-D network
+    for opt in opts:
+        opt.zero_grad()
+    y1_hat = m2.predict_nhwc(frames).reshape(4, 17, 2)
+    pkg.l1_loss(lift(y1_hat).reshape(4, 17, 3), y2).backward()
+    assert float(m2.final_layer.bias.grad.abs().max()) > 0
+    assert len(crit.term_means()) == 6
