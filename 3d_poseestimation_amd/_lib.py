@@ -78,7 +78,8 @@ SIGNATURES = {
     "pl_conv2d_nhwc_scratch_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64,
                                                   _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "pl_conv2d_nhwc_fwd": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int,
-                                      _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _c.c_int, _P, _P, _P, _c.c_size_t, _P]),
+                                      _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _c.c_int, _P, _P, _c.c_int, _P, _c.c_size_t,
+                                      _P]),
     "pl_conv2d_nhwc_wgrad_scratch_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64,
                                                         _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "pl_conv2d_nhwc_wgrad": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int,
@@ -96,7 +97,7 @@ SIGNATURES = {
     "pl_colsum": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _P]),
     "pl_deconv4x4s2_nhwc_scratch_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64]),
     "pl_deconv4x4s2_nhwc_fwd": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int64, _P, _P,
-                                           _c.c_int, _P, _P, _c.c_size_t, _P]),
+                                           _c.c_int, _P, _c.c_int, _P, _c.c_size_t, _P]),
     "pl_nhwc_to_nchw": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P]),
     "pl_gather_rows2": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _P, _c.c_int64, _c.c_int64, _P, _P, _P]),
     "pl_flip_tta_pack": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P]),

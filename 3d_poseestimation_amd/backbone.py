@@ -42,8 +42,9 @@ class ResNet(nn.Module):
     """ResNet("resnet50" | "resnet101" | "resnet152"): the Bottleneck architectures of Resnet.py:104-110."""
     LAYERS = {"resnet50": [3, 4, 6, 3], "resnet101": [3, 4, 23, 3], "resnet152": [3, 8, 36, 3]}
 
-    def __init__(self, architecture="resnet50"):
+    def __init__(self, architecture="resnet50", compute_dtype="bf16x6"):
         super().__init__()
+        self.compute_dtype = compute_dtype          # eval-mode arithmetic: "bf16x6" (fp32-grade) or "bf16"
         if architecture not in self.LAYERS:
             raise ValueError(f"{architecture}: only the Bottleneck ResNets are built (the reference uses resnet50)")
         self.inplanes = 64
@@ -107,9 +108,10 @@ class ResNet(nn.Module):
         if self.training:
             return self._forward_train(x_nhwc)
         f = self._folded()
+        ar = self.compute_dtype
         with torch.no_grad():
             s, b = f["bn1"]
-            x = conv.conv2d_nhwc(x_nhwc.float(), f["conv1"], 2, 3, s, b, relu=1)          # Resnet.py:137
+            x = conv.conv2d_nhwc(x_nhwc.float(), f["conv1"], 2, 3, s, b, relu=1, arith=ar)   # Resnet.py:137
             x = conv.maxpool3x3s2_nhwc(x)
             for li in (1, 2, 3, 4):
                 for bi, blk in enumerate(getattr(self, f"layer{li}")):
@@ -117,24 +119,25 @@ class ResNet(nn.Module):
                     identity = x
                     if blk.downsample is not None:                                          # :87-88
                         s, b = f[p + ".downsample.1"]
-                        identity = conv.conv2d_nhwc(x, f[p + ".downsample.0"], blk.stride, 0, s, b)
+                        identity = conv.conv2d_nhwc(x, f[p + ".downsample.0"], blk.stride, 0, s, b, arith=ar)
                     s, b = f[p + ".bn1"]
-                    out = conv.conv2d_nhwc(x, f[p + ".conv1"], 1, 0, s, b, relu=1)          # :67
+                    out = conv.conv2d_nhwc(x, f[p + ".conv1"], 1, 0, s, b, relu=1, arith=ar)   # :67
                     s, b = f[p + ".bn2"]
-                    out = conv.conv2d_nhwc(out, f[p + ".conv2"], blk.stride, 1, s, b, relu=1)   # :69
+                    out = conv.conv2d_nhwc(out, f[p + ".conv2"], blk.stride, 1, s, b, relu=1, arith=ar)   # :69
                     s, b = f[p + ".bn3"]
-                    x = conv.conv2d_nhwc(out, f[p + ".conv3"], 1, 0, s, b, relu=2, resid=identity)  # :81-91
+                    x = conv.conv2d_nhwc(out, f[p + ".conv3"], 1, 0, s, b, relu=2, resid=identity, arith=ar)  # :81-91
         return x
 
 
 class _HeatmapNet(nn.Module):
     """Backbone + three transposed convolutions + final 1x1 convolution: the part Model_3D and Model_2D share."""
 
-    def __init__(self, depth_dim, architecture="resnet50"):
+    def __init__(self, depth_dim, architecture="resnet50", compute_dtype="bf16x6"):
         super().__init__()
+        self.compute_dtype = compute_dtype
         self.deconv_dim = [256, 256, 256]
         self.num_joints, self.depth_dim, self.height_dim, self.width_dim = 17, depth_dim, 64, 64
-        self.preact = ResNet(architecture)
+        self.preact = ResNet(architecture, compute_dtype)
         self.feature_channel = 2048
         layers, cin = [], self.feature_channel
         for cout in self.deconv_dim:                                          # Model.py:47-69 / Model_2d.py:48-71
@@ -164,8 +167,8 @@ class _HeatmapNet(nn.Module):
         with torch.no_grad():
             out = x0
             for i in (0, 3, 6):
-                out = conv.deconv4x4s2_nhwc(out, f[i], f[i + 1][0], f[i + 1][1], relu=1)
-            return conv.conv2d_nhwc(out, f["final"], 1, 0, bias=self.final_layer.bias.detach())
+                out = conv.deconv4x4s2_nhwc(out, f[i], f[i + 1][0], f[i + 1][1], relu=1, arith=self.compute_dtype)
+            return conv.conv2d_nhwc(out, f["final"], 1, 0, bias=self.final_layer.bias.detach(), arith=self.compute_dtype)
 
     def heatmap_logits(self, x_nhwc):
         """The same in the reference's layout [B, J*depth, 64, 64] (Model.py:91)."""
@@ -197,8 +200,8 @@ class _HeatmapNet(nn.Module):
 
 
 class Model_3D(_HeatmapNet):
-    def __init__(self, architecture="resnet50"):
-        super().__init__(64, architecture)
+    def __init__(self, architecture="resnet50", compute_dtype="bf16x6"):
+        super().__init__(64, architecture, compute_dtype)
 
     def forward(self, x):
         """x [B, 256, 256, 3] NHWC frames -> [B, 51] (x, y, z) per joint in (-1, 1)  (Model.py:83-137)."""
@@ -209,8 +212,8 @@ class Model_3D(_HeatmapNet):
 
 
 class Model_2D(_HeatmapNet):
-    def __init__(self, architecture="resnet50"):
-        super().__init__(1, architecture)
+    def __init__(self, architecture="resnet50", compute_dtype="bf16x6"):
+        super().__init__(1, architecture, compute_dtype)
 
     def forward(self, x):
         """x [B, 3, 256, 256] NCHW frames (Model_2d.py:91 leaves the permute commented out) -> [B, 34]

@@ -54,8 +54,13 @@ def _opt(t, name, n):
     return t
 
 
-def conv2d_nhwc(x, w_ohwi, stride=1, padding=0, scale=None, shift=None, bias=None, relu=0, resid=None):
-    """x [B,H,W,Cin] fp32 -> [B,Ho,Wo,Cout] fp32.  relu: 0 none, 1 ReLU then + resid, 2 + resid then ReLU."""
+ARITH = {"bf16x6": _lib.PL_BF16X6, "bf16": _lib.PL_BF16}
+
+
+def conv2d_nhwc(x, w_ohwi, stride=1, padding=0, scale=None, shift=None, bias=None, relu=0, resid=None,
+                arith="bf16x6"):
+    """x [B,H,W,Cin] fp32 -> [B,Ho,Wo,Cout] fp32.  relu: 0 none, 1 ReLU then + resid, 2 + resid then ReLU.
+    arith: "bf16x6" (fp32-grade) or "bf16" (operands rounded to bf16: the throughput mode)."""
     x, w = x.contiguous(), w_ohwi.contiguous()
     _lib.require_device_tensor(x, "x")
     _lib.require_device_tensor(w, "weight")
@@ -73,7 +78,7 @@ def conv2d_nhwc(x, w_ohwi, stride=1, padding=0, scale=None, shift=None, bias=Non
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     with torch.cuda.device(x.device):
         rc = L.pl_conv2d_nhwc_fwd(x.data_ptr(), B, H, W, Cin, w.data_ptr(), Cout, KH, KW, stride, padding,
-                                  ptr[0], ptr[1], ptr[2], relu, ptr[3], y.data_ptr(),
+                                  ptr[0], ptr[1], ptr[2], relu, ptr[3], y.data_ptr(), ARITH[arith],
                                   scratch.data_ptr() if nbytes else None, nbytes, _lib.current_stream_ptr())
     _lib.check(rc, "pl_conv2d_nhwc_fwd")
     return y
@@ -144,7 +149,7 @@ def maxpool3x3s2_nhwc(x):
     return y
 
 
-def deconv4x4s2_nhwc(x, w_sub, scale=None, shift=None, relu=0):
+def deconv4x4s2_nhwc(x, w_sub, scale=None, shift=None, relu=0, arith="bf16x6"):
     """x [B,Hi,Wi,Cin] -> [B,2Hi,2Wi,Cout]; w_sub from deconv_subkernels()."""
     x, w = x.contiguous(), w_sub.contiguous()
     _lib.require_device_tensor(x, "x")
@@ -161,7 +166,7 @@ def deconv4x4s2_nhwc(x, w_sub, scale=None, shift=None, relu=0):
     with torch.cuda.device(x.device):
         rc = L.pl_deconv4x4s2_nhwc_fwd(x.data_ptr(), B, Hi, Wi, Cin, w.data_ptr(), Cout,
                                        scale.data_ptr() if scale is not None else None,
-                                       shift.data_ptr() if shift is not None else None, relu, y.data_ptr(),
+                                       shift.data_ptr() if shift is not None else None, relu, y.data_ptr(), ARITH[arith],
                                        scratch.data_ptr(), nbytes, _lib.current_stream_ptr())
     _lib.check(rc, "pl_deconv4x4s2_nhwc_fwd")
     return y

@@ -195,15 +195,19 @@ bool implicit_ok(int64_t M, int64_t Cin, int64_t Cout, int64_t K) {
 int conv_core(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* w, int64_t Cout, int KH,
               int KW, int stride, int pad_h, int pad_w, int64_t Ho, int64_t Wo, const float* scale,
               const float* shift, const float* bias, int relu, const float* resid, float* y, void* scratch,
-              size_t scratch_bytes, hipStream_t s) {
+              size_t scratch_bytes, hipStream_t s, int arith = PL_BF16X6) {
   const int64_t M = B * Ho * Wo, K = (int64_t)KH * KW * Cin;
   if (M > INT32_MAX || K > INT32_MAX) PL_FAIL(PL_ESHAPE, "conv: problem too large");
   GemmArgs g = {};
   g.A = x; g.B = w; g.C = y; g.M = (int)M; g.N = (int)Cout; g.K = (int)K;
   g.lda = (int)K; g.ldb = (int)K; g.ldc = (int)Cout; g.split_k = 1;
   g.bias = bias; g.col_scale = scale; g.col_shift = shift; g.relu = relu; g.resid = resid;
-  g.arith = PL_BF16X6;
-  if (KH == 1 && KW == 1 && stride == 1 && pad_h == 0 && pad_w == 0) return launch_gemm_f32(kNT, g, s);
+  g.arith = arith;
+  const int gemm_arith = arith == PL_BF16 ? 7 : arith;     // PL_BF16 on the planes pipeline (gemm_f32.hip)
+  if (KH == 1 && KW == 1 && stride == 1 && pad_h == 0 && pad_w == 0) {
+    g.arith = gemm_arith;
+    return launch_gemm_f32(kNT, g, s);
+  }
   if (implicit_ok(M, Cin, Cout, K)) {
     g.conv_cin = (int)Cin; g.conv_h = (int)H; g.conv_w = (int)W; g.conv_ho = (int)Ho; g.conv_wo = (int)Wo;
     g.conv_kw = KW; g.conv_stride = stride; g.conv_pad_h = pad_h; g.conv_pad_w = pad_w;
@@ -227,6 +231,7 @@ int conv_core(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, cons
                      (int)K, (int)Kp, wp);
   PL_CHECK_LAUNCH("pad_rows");
   g.A = col; g.B = wp; g.K = (int)Kp; g.lda = (int)Kp; g.ldb = (int)Kp;
+  g.arith = gemm_arith;
   return launch_gemm_f32(kNT, g, s);
 }
 
@@ -249,8 +254,9 @@ extern "C" size_t pl_conv2d_nhwc_scratch_bytes(int64_t B, int64_t H, int64_t W, 
 extern "C" int pl_conv2d_nhwc_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* w,
                                   int64_t Cout, int KH, int KW, int stride, int pad, const float* scale,
                                   const float* shift, const float* bias, int relu, const float* resid, float* y,
-                                  void* scratch, size_t scratch_bytes, void* stream) {
+                                  int arith, void* scratch, size_t scratch_bytes, void* stream) {
   if (!x || !w || !y) PL_FAIL(PL_EINVAL, "pl_conv2d_nhwc_fwd: null pointer");
+  if (arith != PL_BF16X6 && arith != PL_BF16) PL_FAIL(PL_EDTYPE, "pl_conv2d_nhwc_fwd: arith %d (PL_BF16X6 or PL_BF16)", arith);
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
     PL_FAIL(PL_ESHAPE, "pl_conv2d_nhwc_fwd: bad geometry");
   if ((scale != nullptr) != (shift != nullptr)) PL_FAIL(PL_EINVAL, "pl_conv2d_nhwc_fwd: scale without shift");
@@ -258,7 +264,7 @@ extern "C" int pl_conv2d_nhwc_fwd(const float* x, int64_t B, int64_t H, int64_t 
   const int64_t Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   if (Ho <= 0 || Wo <= 0) PL_FAIL(PL_ESHAPE, "pl_conv2d_nhwc_fwd: empty output");
   return conv_core(x, B, H, W, Cin, w, Cout, KH, KW, stride, pad, pad, Ho, Wo, scale, shift, bias, relu, resid, y,
-                   scratch, scratch_bytes, (hipStream_t)stream);
+                   scratch, scratch_bytes, (hipStream_t)stream, arith);
 }
 
 extern "C" int pl_maxpool3x3s2_nhwc(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y,
@@ -282,8 +288,10 @@ extern "C" size_t pl_deconv4x4s2_nhwc_scratch_bytes(int64_t B, int64_t Hi, int64
 
 extern "C" int pl_deconv4x4s2_nhwc_fwd(const float* x, int64_t B, int64_t Hi, int64_t Wi, int64_t Cin,
                                        const float* w_sub, int64_t Cout, const float* scale, const float* shift,
-                                       int relu, float* y, void* scratch, size_t scratch_bytes, void* stream) {
+                                       int relu, float* y, int arith, void* scratch, size_t scratch_bytes,
+                                       void* stream) {
   if (!x || !w_sub || !y || !scratch) PL_FAIL(PL_EINVAL, "pl_deconv4x4s2_nhwc_fwd: null pointer");
+  if (arith != PL_BF16X6 && arith != PL_BF16) PL_FAIL(PL_EDTYPE, "pl_deconv4x4s2_nhwc_fwd: arith %d", arith);
   if (B <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0 || (Cout & 3)) PL_FAIL(PL_ESHAPE, "pl_deconv4x4s2_nhwc_fwd: bad geometry");
   if ((scale != nullptr) != (shift != nullptr)) PL_FAIL(PL_EINVAL, "pl_deconv4x4s2_nhwc_fwd: scale without shift");
   const size_t part = (size_t)B * Hi * Wi * Cout;
@@ -299,7 +307,7 @@ extern "C" int pl_deconv4x4s2_nhwc_fwd(const float* x, int64_t B, int64_t Hi, in
     g.A = x; g.B = w_sub + (size_t)par * Cout * 4 * Cin; g.C = tmp + par * part;
     g.M = (int)(B * Hi * Wi); g.N = (int)Cout; g.K = (int)(4 * Cin);
     g.lda = g.K; g.ldb = g.K; g.ldc = (int)Cout; g.split_k = 1;
-    g.col_scale = scale; g.col_shift = shift; g.relu = relu; g.arith = PL_BF16X6;
+    g.col_scale = scale; g.col_shift = shift; g.relu = relu; g.arith = arith;
     g.conv_cin = (int)Cin; g.conv_h = (int)Hi; g.conv_w = (int)Wi; g.conv_ho = (int)Hi; g.conv_wo = (int)Wi;
     g.conv_kw = 2; g.conv_stride = 1;
     // even output rows read input rows a-1, a (pad 1); odd ones a, a+1 (pad 0, the last tap runs off the edge)

@@ -726,8 +726,15 @@ __device__ __forceinline__ void load_tile_wgrad(Stage& s, const GemmArgs& p, con
 }
 
 // x = x0 + x1 + x2 exactly, the same RNE split as split3 (results are bit-identical to the fragment path)
-template <int PLANE>
+template <int PLANE, int NPL = 3>
 __device__ __forceinline__ void split8_store(char* __restrict__ dst, const float (&f)[8]) {
+  if (NPL == 1) {                          // PL_BF16: one plane, operands rounded to bf16 (RNE)
+    bf16x8 q;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = (__bf16)f[j];
+    *reinterpret_cast<bf16x8*>(dst) = q;
+    return;
+  }
   // stage-major over the eight values: every instruction's operands were produced a whole stage
   // (>= 4 instructions) earlier.  Written value-major, hipcc emits one serial cvt -> shift -> sub -> cvt
   // chain per value pair and every instruction waits on its predecessor (PMC: a third of the wave's
@@ -750,28 +757,28 @@ __device__ __forceinline__ void split8_store(char* __restrict__ dst, const float
 }
 
 // Split + store one half (HALF = 0, 1) of a staged operand tile; BK 16 has a single half (0).
-template <bool KS, int BKX, int HALF>
+template <bool KS, int BKX, int HALF, int NPL = 3>
 __device__ __forceinline__ void store_half_p(char* __restrict__ op, int tid, const Stage& g) {
   using Cf = PCfg<BKX>;
   if (!KS && BKX == 32) {
     char* d = op + (tid & 3) * Cf::OCTS + (tid >> 2) * 16 + HALF * 64 * 16;
     const float4 u = HALF ? g.v2 : g.v0, v = HALF ? g.v3 : g.v1;
     const float a[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
-    split8_store<Cf::PLANE>(d, a);
+    split8_store<Cf::PLANE, NPL>(d, a);
   } else if (!KS) {
     char* d = op + (tid & 1) * Cf::OCTS + (tid >> 1) * 16;
     const float a[8] = {g.v0.x, g.v0.y, g.v0.z, g.v0.w, g.v1.x, g.v1.y, g.v1.z, g.v1.w};
-    split8_store<Cf::PLANE>(d, a);
+    split8_store<Cf::PLANE, NPL>(d, a);
   } else if (BKX == 32) {
     char* d = op + (tid >> 6) * Cf::OCTS + (tid & 63) * 32 + HALF * 16;
     float a[8];
     if (HALF == 0) { a[0] = g.v0.x; a[1] = g.v0.z; a[2] = g.v1.x; a[3] = g.v1.z; a[4] = g.v2.x; a[5] = g.v2.z; a[6] = g.v3.x; a[7] = g.v3.z; }
     else           { a[0] = g.v0.y; a[1] = g.v0.w; a[2] = g.v1.y; a[3] = g.v1.w; a[4] = g.v2.y; a[5] = g.v2.w; a[6] = g.v3.y; a[7] = g.v3.w; }
-    split8_store<Cf::PLANE>(d, a);
+    split8_store<Cf::PLANE, NPL>(d, a);
   } else {
     char* d = op + (tid >> 7) * Cf::OCTS + (tid & 127) * 16;
     const float a[8] = {g.v0.x, g.v0.y, g.v0.z, g.v0.w, g.v1.x, g.v1.y, g.v1.z, g.v1.w};
-    split8_store<Cf::PLANE>(d, a);
+    split8_store<Cf::PLANE, NPL>(d, a);
   }
 }
 
@@ -791,7 +798,9 @@ __device__ __forceinline__ void store_half_p(char* __restrict__ op, int tid, con
 // rows and the guarded epilogue drops the columns >= N (the 64-wide layer1 convolutions, the 1088-wide head).
 // With the convolution gather (A_CONV) M may be ragged too: conv_row clamps the pixel index.
 // B_WGRAD + N_EDGE: ragged Cout (M) and KH*KW*Cin (N): both loaders clamp, the guarded epilogue drops the rest.
-template <bool A_KS, bool B_KS, int BKX, bool A_CONV = false, bool N_EDGE = false, bool B_WGRAD = false>
+// NPL = 3: PL_BF16X6 (three planes, six products).  NPL = 1: PL_BF16 on the same pipeline (plane 0 only, one product
+// per tile pair, operands rounded to bf16 while staged): the conv path's throughput mode.
+template <bool A_KS, bool B_KS, int BKX, bool A_CONV = false, bool N_EDGE = false, bool B_WGRAD = false, int NPL = 3>
 __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int block_id, const int nwork,
                                                  char* __restrict__ lds) {
   using Cf = PCfg<BKX>;
@@ -830,14 +839,14 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
   // fragment sets: BK 32: set s = 16-deep step s of the tile in flight; BK 16: set = tile parity
-  bf16x8 fa[2][2][3], fb[2][2][3];
+  bf16x8 fa[2][2][NPL], fb[2][2][NPL];
   const int arow = (wm * 64 + i) * 16, brow = (wn * 64 + i) * 16;
 #define PL_FRAGS_P(set, buf, s16)                                                                        \
   do {                                                                                                   \
     const char* qa = (buf) + (2 * (s16) + h) * Cf::OCTS + arow;                                          \
     const char* qb = (buf) + Cf::OPP + (2 * (s16) + h) * Cf::OCTS + brow;                                \
     _Pragma("unroll") for (int t2 = 0; t2 < 2; ++t2)                                                     \
-    _Pragma("unroll") for (int pl = 0; pl < 3; ++pl) {                                                   \
+    _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                                 \
       fa[set][t2][pl] = *reinterpret_cast<const bf16x8*>(qa + t2 * 32 * 16 + pl * Cf::PLANE);            \
       fb[set][t2][pl] = *reinterpret_cast<const bf16x8*>(qb + t2 * 32 * 16 + pl * Cf::PLANE);            \
     }                                                                                                    \
@@ -846,8 +855,11 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
   acc[aa][bb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][aa][ia], fb[set][bb][ib], acc[aa][bb], 0, 0, 0)
 #define PL_MF6(set, aa, bb)                                                                      \
   do {                                                                                           \
-    PL_MFP(set, aa, bb, 2, 0); PL_MFP(set, aa, bb, 1, 1); PL_MFP(set, aa, bb, 0, 2);             \
-    PL_MFP(set, aa, bb, 1, 0); PL_MFP(set, aa, bb, 0, 1); PL_MFP(set, aa, bb, 0, 0);             \
+    if constexpr (NPL == 3) {                                                                    \
+      PL_MFP(set, aa, bb, 2, 0); PL_MFP(set, aa, bb, 1, 1); PL_MFP(set, aa, bb, 0, 2);           \
+      PL_MFP(set, aa, bb, 1, 0); PL_MFP(set, aa, bb, 0, 1);                                      \
+    }                                                                                            \
+    PL_MFP(set, aa, bb, 0, 0);                                                                   \
   } while (0)
 #define PL_MFMAS_ROW(set, aa) do { PL_MF6(set, aa, 0); PL_MF6(set, aa, 1); } while (0)
 #define PL_MFMAS_P(set) do { PL_MFMAS_ROW(set, 0); PL_MFMAS_ROW(set, 1); } while (0)
@@ -873,7 +885,7 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
     else load_tile_p<B_KS, BKX>(d, p.B, p.ldb, n0, k0, tid, nlast);
   };
   auto store_a = [&](char* op, auto half, const SA& g) {
-    store_half_p<A_KS, BKX, decltype(half)::value>(op, tid, g);
+    store_half_p<A_KS, BKX, decltype(half)::value, NPL>(op, tid, g);
   };
   using H0 = std::integral_constant<int, 0>;
   using H1 = std::integral_constant<int, 1>;
@@ -893,16 +905,16 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
     }
     if (KSTEPS == 2) {
       PL_FRAGS_P(1, cur, 1);
-      if (do_split) { store_a(nx2, H0{}, sa); store_half_p<B_KS, BKX, 0>(nx2 + Cf::OPP, tid, sb); }
+      if (do_split) { store_a(nx2, H0{}, sa); store_half_p<B_KS, BKX, 0, NPL>(nx2 + Cf::OPP, tid, sb); }
       PL_MFMAS_P(0);
       if (has_next) PL_FRAGS_P(0, nx1, 0);
-      if (do_split) { store_a(nx2, H1{}, sa); store_half_p<B_KS, BKX, 1>(nx2 + Cf::OPP, tid, sb); }
+      if (do_split) { store_a(nx2, H1{}, sa); store_half_p<B_KS, BKX, 1, NPL>(nx2 + Cf::OPP, tid, sb); }
       PL_MFMAS_P(1);
     } else {
       if (has_next) PL_FRAGS_P(1 - P, nx1, 0);
       if (do_split) store_a(nx2, H0{}, sa);
       PL_MFMAS_ROW(P, 0);
-      if (do_split) store_half_p<B_KS, BKX, 0>(nx2 + Cf::OPP, tid, sb);
+      if (do_split) store_half_p<B_KS, BKX, 0, NPL>(nx2 + Cf::OPP, tid, sb);
       PL_MFMAS_ROW(P, 1);
     }
     if (STEADY) {
@@ -911,7 +923,7 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
       // loads up front, the fragment reads and the plane writes threaded between.
       constexpr int NG = (A_KS ? 8 : BKX / 8) + (B_KS ? 8 : BKX / 8);      // global loads per step
 #pragma unroll
-      for (int q = 0; q < 24 * KSTEPS; ++q) {
+      for (int q = 0; q < (NPL == 3 ? 24 : 4) * KSTEPS; ++q) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         if (q < NG) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -934,15 +946,15 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
       load_a(ra1, kbeg + BKX);
       load_b(rb1, kbeg + BKX);
     }
-    store_a(cur, H0{}, ra0); store_half_p<B_KS, BKX, 0>(cur + Cf::OPP, tid, rb0);
-    if (KSTEPS == 2) { store_a(cur, H1{}, ra0); store_half_p<B_KS, BKX, 1>(cur + Cf::OPP, tid, rb0); }
+    store_a(cur, H0{}, ra0); store_half_p<B_KS, BKX, 0, NPL>(cur + Cf::OPP, tid, rb0);
+    if (KSTEPS == 2) { store_a(cur, H1{}, ra0); store_half_p<B_KS, BKX, 1, NPL>(cur + Cf::OPP, tid, rb0); }
     if (nk > 2) {
       load_a(ra0, kbeg + 2 * BKX);
       load_b(rb0, kbeg + 2 * BKX);
     }
     if (nk > 1) {
-      store_a(nx1, H0{}, ra1); store_half_p<B_KS, BKX, 0>(nx1 + Cf::OPP, tid, rb1);
-      if (KSTEPS == 2) { store_a(nx1, H1{}, ra1); store_half_p<B_KS, BKX, 1>(nx1 + Cf::OPP, tid, rb1); }
+      store_a(nx1, H0{}, ra1); store_half_p<B_KS, BKX, 0, NPL>(nx1 + Cf::OPP, tid, rb1);
+      if (KSTEPS == 2) { store_a(nx1, H1{}, ra1); store_half_p<B_KS, BKX, 1, NPL>(nx1 + Cf::OPP, tid, rb1); }
     }
     __syncthreads();
     PL_FRAGS_P(0, cur, 0);
@@ -989,13 +1001,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_planes_kernel(GemmArgs p) {
   gemm_body_planes<true, true, 32, false, MN_EDGE, true>(p, blockIdx.x, gridDim.x, lds);
 }
 
-struct GemmArgs4 { GemmArgs g[4]; };
+// PL_BF16 on the planes pipeline (conv path throughput mode): the same bodies with NPL = 1
+template <bool N_EDGE>
+__global__ __launch_bounds__(256) void conv_bf16_planes_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[PCfg<32>::LDS];
+  gemm_body_planes<false, false, 32, true, N_EDGE, false, 1>(p, blockIdx.x, gridDim.x, lds);
+}
 
 template <bool N_EDGE>
+__global__ __launch_bounds__(256) void gemm_bf16_planes_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) char lds[PCfg<32>::LDS];
+  gemm_body_planes<false, false, 32, false, N_EDGE, false, 1>(p, blockIdx.x, gridDim.x, lds);
+}
+
+struct GemmArgs4 { GemmArgs g[4]; };
+
+template <bool N_EDGE, int NPL>
 __global__ __launch_bounds__(256) void conv_x6_planes_group4_kernel(GemmArgs4 P, int per) {
   __shared__ __attribute__((aligned(16))) char lds[PCfg<32>::LDS];
   const int g = blockIdx.x / per;
-  gemm_body_planes<false, false, 32, true, N_EDGE>(P.g[g], blockIdx.x - g * per, per, lds);
+  gemm_body_planes<false, false, 32, true, N_EDGE, false, NPL>(P.g[g], blockIdx.x - g * per, per, lds);
 }
 
 __global__ __launch_bounds__(256) void gemm_x6_planes_nedge_kernel(GemmArgs p) {
@@ -1135,7 +1160,11 @@ int launch_conv_nhwc(const GemmArgs& a, hipStream_t s) {
     PL_FAIL(PL_EINVAL, "conv: operands not 16-byte aligned");
   ProfRec* prof = prof_begin(a, s);
   const dim3 grid(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN));
-  if (a.N % BN || a.M % BM) hipLaunchKernelGGL(conv_x6_planes_kernel<true>, grid, dim3(NTHR), 0, s, a);
+  const bool edge = a.N % BN || a.M % BM;
+  if (a.arith == 1) {
+    if (edge) hipLaunchKernelGGL(conv_bf16_planes_kernel<true>, grid, dim3(NTHR), 0, s, a);
+    else hipLaunchKernelGGL(conv_bf16_planes_kernel<false>, grid, dim3(NTHR), 0, s, a);
+  } else if (edge) hipLaunchKernelGGL(conv_x6_planes_kernel<true>, grid, dim3(NTHR), 0, s, a);
   else hipLaunchKernelGGL(conv_x6_planes_kernel<false>, grid, dim3(NTHR), 0, s, a);
   if (prof) (void)hipEventRecord(prof->e1, s);
   PL_CHECK_LAUNCH("conv_x6_planes");
@@ -1180,9 +1209,11 @@ int launch_conv_nhwc_group4(const GemmArgs* a, hipStream_t s) {
   GemmArgs all = a[0];
   ProfRec* prof = prof_begin(all, s);
   if (prof) prof->flops *= 4.0;
-  if (a[0].N % BN || a[0].M % BM)
-    hipLaunchKernelGGL(conv_x6_planes_group4_kernel<true>, dim3(4 * per), dim3(NTHR), 0, s, P, per);
-  else hipLaunchKernelGGL(conv_x6_planes_group4_kernel<false>, dim3(4 * per), dim3(NTHR), 0, s, P, per);
+  const bool edge = a[0].N % BN || a[0].M % BM, bf = a[0].arith == 1;
+  if (edge && bf) hipLaunchKernelGGL((conv_x6_planes_group4_kernel<true, 1>), dim3(4 * per), dim3(NTHR), 0, s, P, per);
+  else if (edge) hipLaunchKernelGGL((conv_x6_planes_group4_kernel<true, 3>), dim3(4 * per), dim3(NTHR), 0, s, P, per);
+  else if (bf) hipLaunchKernelGGL((conv_x6_planes_group4_kernel<false, 1>), dim3(4 * per), dim3(NTHR), 0, s, P, per);
+  else hipLaunchKernelGGL((conv_x6_planes_group4_kernel<false, 3>), dim3(4 * per), dim3(NTHR), 0, s, P, per);
   if (prof) (void)hipEventRecord(prof->e1, s);
   PL_CHECK_LAUNCH("conv_x6_planes_group4");
   return PL_OK;
@@ -1216,6 +1247,15 @@ int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s) {
     else if (whole) hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, false>), grid, block, lds_bytes, s, a);      \
     else hipLaunchKernelGGL((gemm_f32_kernel<AKS, BKS, true>), grid, block, lds_bytes, s, a);             \
   } while (0)
+  // conv path, PL_BF16 on the planes pipeline (GemmArgs::arith 7, NT only)
+  if (layout == kNT && a.arith == 7 && a.split_k <= 1 && a.M % BM == 0 && a.K % BK == 0 && a.lda % 4 == 0 &&
+      a.ldb % 4 == 0 && ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) == 0) {
+    if (a.N % BN) hipLaunchKernelGGL(gemm_bf16_planes_kernel<true>, grid, block, lds_bytes, s, a);
+    else hipLaunchKernelGGL(gemm_bf16_planes_kernel<false>, grid, block, lds_bytes, s, a);
+    if (prof) (void)hipEventRecord(prof->e1, s);
+    PL_CHECK_LAUNCH("gemm_bf16_planes");
+    return PL_OK;
+  }
   // NT, PL_BF16X6, whole M and K tiles but a ragged N: the planes kernel with clamped B rows + guarded stores
   const bool nt_ragged_n = layout == kNT && a.arith == 2 && x6_planes_default() && !whole && a.split_k <= 1 &&
                            a.M % BM == 0 && a.K % BK == 0 && a.lda % 4 == 0 && a.ldb % 4 == 0 &&

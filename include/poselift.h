@@ -170,13 +170,15 @@ int pl_softargmax3d_nhwc_fwd(const float* logits, int64_t B, int64_t J, int64_t 
  * x [B][H][W][Cin], w [Cout][KH][KW][Cin] (OHWI), resid / y [B][Ho][Wo][Cout].
  * Cin % 32 == 0: implicit GEMM on the PL_BF16X6 pipeline (fp32-grade products, no im2col buffer; ragged last
  * row / column tiles are clamped and masked); 1x1 stride 1: a plain GEMM; anything else (the stem with Cin = 3):
- * explicit im2col into `scratch` (>= pl_conv2d_nhwc_scratch_bytes, 0 for the others). */
+ * explicit im2col into `scratch` (>= pl_conv2d_nhwc_scratch_bytes, 0 for the others).
+ * arith: PL_BF16X6 (fp32-grade) or PL_BF16 (operands rounded to bf16 while staged, one MFMA product: the
+ * throughput mode; storage stays fp32). */
 size_t pl_conv2d_nhwc_scratch_bytes(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH,
                                     int KW, int stride, int pad);
 int pl_conv2d_nhwc_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* w,
                        int64_t Cout, int KH, int KW, int stride, int pad, const float* scale,
                        const float* shift, const float* bias, int relu, const float* resid, float* y,
-                       void* scratch, size_t scratch_bytes, void* stream);
+                       int arith, void* scratch, size_t scratch_bytes, void* stream);
 
 /* Weight gradient of the same convolution (autograd of nn.Conv2d, phase4_joined/train.py:80 loss.backward()):
  * dw [Cout][KH][KW][Cin] = sum_{b,oh,ow} dy[b][oh][ow][co] * x[b][oh*stride - pad + kh][ow*stride - pad + kw][ci],
@@ -232,7 +234,7 @@ int pl_colsum(const float* X, int64_t rows, int64_t cols, float* out, void* scra
 size_t pl_deconv4x4s2_nhwc_scratch_bytes(int64_t B, int64_t Hi, int64_t Wi, int64_t Cout);
 int pl_deconv4x4s2_nhwc_fwd(const float* x, int64_t B, int64_t Hi, int64_t Wi, int64_t Cin,
                             const float* w_sub, int64_t Cout, const float* scale, const float* shift,
-                            int relu, float* y, void* scratch, size_t scratch_bytes, void* stream);
+                            int relu, float* y, int arith, void* scratch, size_t scratch_bytes, void* stream);
 
 /* [B][P][C] -> [B][C][P]: the head's NHWC logits to the [B][J*D][H*W] layout of pl_softargmax_fwd. */
 int pl_nhwc_to_nchw(const float* in, int64_t B, int64_t P, int64_t C, float* out, void* stream);

@@ -417,3 +417,27 @@ def test_phase5_cycle_step_runs_and_couples_the_networks(pkg):
     pkg.l1_loss(lift(y1_hat).reshape(4, 17, 3), y2).backward()
     assert float(m2.final_layer.bias.grad.abs().max()) > 0
     assert len(crit.term_means()) == 6
+
+
+def test_bf16_arithmetic_mode_of_the_conv_path(pkg):
+    """arith="bf16" (operands rounded to bf16 while staged, one product): bf16-sized error on a convolution, and
+    Model_3D(compute_dtype="bf16") stays within a fraction of a voxel of the fp32-grade model."""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 32, 32, 128, generator=g)
+    w = torch.randn(128, 128, 3, 3, generator=g) / np.sqrt(128 * 9)
+    want = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), padding=1).permute(0, 2, 3, 1)
+    got = pkg.conv.conv2d_nhwc(x.to(DEV), pkg.conv.to_ohwi(w).to(DEV), 1, 1, arith="bf16").cpu().double()
+    err = float((got - want).abs().max())
+    assert 1e-4 < err < 5e-2, err                                # really bf16, and only bf16
+    m = pkg.Model_3D().eval()
+    m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 31))
+    with torch.no_grad():
+        m.final_layer.weight.mul_(1e-4)
+    m = m.to(DEV)
+    frames = pkg.synth.seeded_frames(2, 32).to(DEV)
+    ref = m(frames)
+    m.compute_dtype = m.preact.compute_dtype = "bf16"
+    fast = m(frames)
+    assert float((fast - ref).abs().max()) < 2e-2                # coordinates in (-1, 1): 0.6 voxel of 64
+    with pytest.raises(KeyError):
+        pkg.conv.conv2d_nhwc(x.to(DEV), pkg.conv.to_ohwi(w).to(DEV), 1, 1, arith="fp16")
