@@ -187,6 +187,68 @@ __global__ __launch_bounds__(1024) void nhwc_to_nchw_kernel(const float* __restr
   if (c0 + ty < C && p0 + tx < P) out[(b * C + c0 + ty) * P + p0 + tx] = tile[tx][ty];
 }
 
+// The 7x7 / stride 2 / pad 3 stem on 3 input channels (Resnet.py:112-113): K = 147 is no multiple of anything the
+// matrix pipeline likes and the explicit im2col it needed cost more than the GEMM it fed (0.6 + 0.56 ms at
+// B = 64).  Direct form on the vector ALU, exact fp32: one thread = one output pixel x all 64 channels, the
+// 37.6 KB filter in LDS as [tap][ci][64 co] so a tap's 64 weights are 16 broadcast ds_read_b128; 147 x 64 FMAs
+// per pixel (19.7 GFLOP per 64 frames) with BatchNorm + ReLU folded into the store.
+__global__ __launch_bounds__(NTHR) void stem7x7_c3_kernel(const float* __restrict__ x, int H, int W, int Ho, int Wo,
+                                                          int64_t npix, const float* __restrict__ w,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int relu,
+                                                          float* __restrict__ y) {
+  __shared__ __attribute__((aligned(16))) float ws[147 * 64];     // [(kh*7 + kw)*3 + ci][co]
+  for (int e = threadIdx.x; e < 147 * 64; e += NTHR) {
+    const int co = e & 63, k = e >> 6;                            // w is OHWI: [co][kh][kw][ci] = [co][k]
+    ws[e] = w[co * 147 + k];
+  }
+  __syncthreads();
+  const int64_t p = (int64_t)blockIdx.x * NTHR + threadIdx.x;
+  if (p >= npix) return;
+  const int ow = (int)(p % Wo);
+  const int64_t r = p / Wo;
+  const int oh = (int)(r % Ho);
+  const int64_t b = r / Ho;
+  float acc[64];
+#pragma unroll
+  for (int c = 0; c < 64; ++c) acc[c] = 0.f;
+  const float* xb = x + b * H * W * 3;
+  for (int kh = 0; kh < 7; ++kh) {
+    const int ih = oh * 2 - 3 + kh;
+    if ((unsigned)ih >= (unsigned)H) continue;
+    for (int kw = 0; kw < 7; ++kw) {
+      const int iw = ow * 2 - 3 + kw;
+      if ((unsigned)iw >= (unsigned)W) continue;
+      const float* px = xb + ((size_t)ih * W + iw) * 3;
+      const float v[3] = {px[0], px[1], px[2]};
+      const float4* wt = reinterpret_cast<const float4*>(ws + (kh * 7 + kw) * 3 * 64);
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float4 f = wt[ci * 16 + q];
+          acc[4 * q + 0] = fmaf(v[ci], f.x, acc[4 * q + 0]);
+          acc[4 * q + 1] = fmaf(v[ci], f.y, acc[4 * q + 1]);
+          acc[4 * q + 2] = fmaf(v[ci], f.z, acc[4 * q + 2]);
+          acc[4 * q + 3] = fmaf(v[ci], f.w, acc[4 * q + 3]);
+        }
+    }
+  }
+  float4* out = reinterpret_cast<float4*>(y + p * 64);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t = acc[4 * q + j];
+      if (scale) t = fmaf(t, scale[4 * q + j], shift[4 * q + j]);
+      if (relu) t = fmaxf(t, 0.f);
+      o[j] = t;
+    }
+    out[q] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 bool implicit_ok(int64_t M, int64_t Cin, int64_t Cout, int64_t K) {
   (void)Cout; (void)M;                   // any width, any pixel count: ragged last tiles are clamped and masked
   return Cin % 32 == 0 && K % 32 == 0;
@@ -203,6 +265,13 @@ int conv_core(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, cons
   g.lda = (int)K; g.ldb = (int)K; g.ldc = (int)Cout; g.split_k = 1;
   g.bias = bias; g.col_scale = scale; g.col_shift = shift; g.relu = relu; g.resid = resid;
   g.arith = arith;
+  if (Cin == 3 && KH == 7 && KW == 7 && stride == 2 && pad_h == 3 && pad_w == 3 && Cout == 64 && !bias && !resid &&
+      relu != 2) {                                           // the stem: direct fp32 kernel, no im2col
+    hipLaunchKernelGGL(stem7x7_c3_kernel, dim3((unsigned)((M + NTHR - 1) / NTHR)), dim3(NTHR), 0, s, x, (int)H, (int)W,
+                       (int)Ho, (int)Wo, M, w, scale, shift, relu, y);
+    PL_CHECK_LAUNCH("stem7x7_c3");
+    return PL_OK;
+  }
   const int gemm_arith = arith == PL_BF16 ? 7 : arith;     // PL_BF16 on the planes pipeline (gemm_f32.hip)
   if (KH == 1 && KW == 1 && stride == 1 && pad_h == 0 && pad_w == 0) {
     g.arith = gemm_arith;
@@ -247,6 +316,7 @@ extern "C" size_t pl_conv2d_nhwc_scratch_bytes(int64_t B, int64_t H, int64_t W, 
   if (Ho <= 0 || Wo <= 0) return 0;
   const int64_t M = B * Ho * Wo, K = (int64_t)KH * KW * Cin;
   if ((KH == 1 && KW == 1 && stride == 1 && pad == 0) || implicit_ok(M, Cin, Cout, K)) return 0;
+  if (Cin == 3 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && Cout == 64) return 0;      // stem7x7_c3_kernel
   const int64_t Kp = (K + 31) / 32 * 32;
   return ((size_t)M * Kp + (size_t)Cout * Kp) * sizeof(float);
 }
