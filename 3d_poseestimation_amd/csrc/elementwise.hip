@@ -112,8 +112,11 @@ __device__ __forceinline__ float4 combine4(float4 v, float4 (*sm)[64], int wave,
 // Column statistics of a [B][H] matrix in the layout bn_finalize merges: per 64-row group the column sums
 // and the sums of squares about the group mean (what the GEMM epilogue emits for the lifter; the conv path's
 // BatchNorm2d over [B*H*W][C] computes them here).  grid = (ceil(H/256), ceil(B/64)).
-__global__ __launch_bounds__(NTHR) void bn_colstats_kernel(const float* __restrict__ z, int B, int H, int gs,
-                                                           float* __restrict__ stat_sum, float* __restrict__ stat_m2) {
+// Narrow maps (C = 64, 128): the caller views [rows][C] as [rows/R][R*C] so that every lane of a 256-column strip
+// works; virtual column vc is replica vc / Hc of real column vc % Hc, and the partials are written replica-major
+// ([R][2][G][Hc]) -- exactly the [world][2][G][H] layout bn_finalize merges, with the replicas in the role of ranks.
+__global__ __launch_bounds__(NTHR) void bn_colstats_kernel(const float* __restrict__ z, int B, int H, int gs, int Hc,
+                                                           float* __restrict__ stat) {
   __shared__ float4 sm[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 256 + lane * 4;
@@ -141,8 +144,11 @@ __global__ __launch_bounds__(NTHR) void bn_colstats_kernel(const float* __restri
     }
   const float4 q = combine4(m2, sm, wave, lane);
   if (wave == 0 && active) {
-    st4(stat_sum + (size_t)blockIdx.y * H + c, t);
-    st4(stat_m2 + (size_t)blockIdx.y * H + c, q);
+    const int rep = c / Hc, cc = c - rep * Hc;
+    const size_t GH = (size_t)gridDim.y * Hc;
+    float* base = stat + (size_t)rep * 2 * GH + (size_t)blockIdx.y * Hc + cc;
+    st4(base, t);
+    st4(base + GH, q);
   }
 }
 
@@ -203,7 +209,8 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(
     const float* __restrict__ z, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* resid, float* act, uint64_t* __restrict__ bits, int B, int H, int mode,
     uint32_t thr, float kscale, uint32_t k0, uint32_t k1, uint32_t c3, uint32_t layer,
-    const uint64_t* __restrict__ inject) {
+    const uint64_t* __restrict__ inject, int Hc) {
+  // Hc: real columns behind the H virtual ones (bn_colstats_kernel); Hc == H for the lifter
   // mode: 0 keep all, 1 philox, 2 injected bitmap, 3 drop all; + 8: no ReLU (BatchNorm alone; bitmap all ones)
   const bool norelu = (mode & 8) != 0;
   mode &= 7;
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(
   const bool active = c < H;
   const int wpr = ((H + 255) >> 8) * 4;
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (active && scale) { sc = ld4(scale + c); sh = ld4(shift + c); }
+  if (active && scale) { sc = ld4(scale + c % Hc); sh = ld4(shift + c % Hc); }
   for (int r = blockIdx.y * 4 + wave; r < B; r += gridDim.y * 4) {
     const size_t off = (size_t)r * H + c;
     float y[4] = {0.f, 0.f, 0.f, 0.f};
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(
 __global__ __launch_bounds__(NTHR) void bn_bwd_reduce_kernel(
     const float* __restrict__ g, const uint64_t* __restrict__ bits, const float* __restrict__ z,
     const float* __restrict__ mean, const float* __restrict__ rstd, float kscale, int B, int H,
-    float* __restrict__ part_dy, float* __restrict__ part_dyz) {
+    float* __restrict__ part_dy, float* __restrict__ part_dyz, int Hc) {
   __shared__ float4 sm[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int strip = blockIdx.x;
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_reduce_kernel(
   const bool active = c < H;
   const int wpr = ((H + 255) >> 8) * 4;
   float4 mu = make_float4(0, 0, 0, 0), rs = mu, s1 = mu, s2 = mu;
-  if (active) { mu = ld4(mean + c); rs = ld4(rstd + c); }
+  if (active) { mu = ld4(mean + c % Hc); rs = ld4(rstd + c % Hc); }
   for (int r = blockIdx.y * 4 + wave; r < B; r += gridDim.y * 4) {
     if (!active) continue;
     const size_t off = (size_t)r * H + c;
@@ -293,8 +300,11 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_reduce_kernel(
   const float4 t1 = combine4(s1, sm, wave, lane);
   const float4 t2 = combine4(s2, sm, wave, lane);
   if (wave == 0 && active) {
-    st4(part_dy + (size_t)blockIdx.y * H + c, t1);
-    st4(part_dyz + (size_t)blockIdx.y * H + c, t2);
+    // replica-major when Hc < H: [R][2][RC][Hc] (part_dyz = part_dy + RC*Hc); plain [2][RC][H] otherwise
+    const int rep = c / Hc, cc = c - rep * Hc;
+    const size_t off = (size_t)rep * 2 * gridDim.y * Hc + (size_t)blockIdx.y * Hc + cc;
+    st4(part_dy + off, t1);
+    st4(part_dyz + off, t2);
   }
 }
 
@@ -310,7 +320,8 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_finalize_kernel(
   const int c = blockIdx.x * RCOLS + cl;
   const bool ok = c < H;
   const size_t RH = (size_t)RC * H;
-  const float* mine = part_all + (size_t)rank * 2 * RH;
+  // rank < 0: the "ranks" are replicas of a narrow map (bn_colstats_kernel): every partial is this process's own
+  const float* mine = part_all + (size_t)max(rank, 0) * 2 * RH;
   float a = 0.f, b = 0.f;
   if (ok)
     for (int k = part; k < RC; k += RPARTS) {
@@ -336,8 +347,8 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_finalize_kernel(
     coef[c] = gamma[c] * rstd[c];
     coef[H + c] = tdy / Bt;
     coef[2 * H + c] = tdyz / Bt;
-    dgamma[c] = sdyz;
-    dbeta[c] = sdy;
+    dgamma[c] = rank < 0 ? tdyz : sdyz;
+    dbeta[c] = rank < 0 ? tdy : sdy;
   }
 }
 
@@ -360,7 +371,7 @@ __global__ __launch_bounds__(NTHR) void reduce_rows_kernel(const float* __restri
 __global__ __launch_bounds__(NTHR) void bn_bwd_dz_kernel(
     const float* __restrict__ g, const uint64_t* __restrict__ bits, const float* __restrict__ z,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ coef,
-    float kscale, int bn, int B, int H, float* __restrict__ dz, float* __restrict__ part_db) {
+    float kscale, int bn, int B, int H, float* __restrict__ dz, float* __restrict__ part_db, int Hc) {
   __shared__ float4 sm[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int strip = blockIdx.x;
@@ -370,8 +381,9 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_dz_kernel(
   float4 zero = make_float4(0, 0, 0, 0);
   float4 mu = zero, rs = zero, c0 = zero, c1 = zero, c2 = zero, sdb = zero;
   if (active && bn) {
-    mu = ld4(mean + c); rs = ld4(rstd + c);
-    c0 = ld4(coef + c); c1 = ld4(coef + H + c); c2 = ld4(coef + 2 * H + c);
+    const int cc = c % Hc;
+    mu = ld4(mean + cc); rs = ld4(rstd + cc);
+    c0 = ld4(coef + cc); c1 = ld4(coef + Hc + cc); c2 = ld4(coef + 2 * Hc + cc);
   }
   for (int r = blockIdx.y * 4 + wave; r < B; r += gridDim.y * 4) {
     if (!active) continue;
@@ -726,7 +738,7 @@ int launch_bn_apply(const float* z, const float* scale, const float* shift, cons
   const int strips = (H + 255) / 256;
   dim3 grid(strips, stream_rows_grid(B, strips));
   hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NTHR), 0, s, z, scale, shift, resid, act, bits, B, H,
-                     mode, thr, kscale, k0, k1, (uint32_t)step, (uint32_t)layer, inject_keep);
+                     mode, thr, kscale, k0, k1, (uint32_t)step, (uint32_t)layer, inject_keep, H);
   PL_CHECK_LAUNCH("bn_apply");
   return PL_OK;
 }
@@ -739,10 +751,10 @@ int bwd_row_chunks(int B) {
 
 int launch_bn_bwd_reduce(const float* g, const uint64_t* bits, const float* z, const float* mean,
                          const float* rstd, float keep_scale, int B, int H, float* part_dy,
-                         float* part_dyz, hipStream_t s) {
+                         float* part_dyz, hipStream_t s, int Hc) {
   dim3 grid((H + 255) / 256, bwd_row_chunks(B));
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(NTHR), 0, s, g, bits, z, mean, rstd, keep_scale, B,
-                     H, part_dy, part_dyz);
+                     H, part_dy, part_dyz, Hc > 0 ? Hc : H);
   PL_CHECK_LAUNCH("bn_bwd_reduce");
   return PL_OK;
 }
@@ -758,10 +770,10 @@ int launch_bn_bwd_finalize(const float* part, int RC, int world, int rank, int B
 
 int launch_bn_bwd_dz(const float* g, const uint64_t* bits, const float* z, const float* mean,
                      const float* rstd, const float* coef, float keep_scale, int bn, int B, int H,
-                     float* dz, float* part_db, hipStream_t s) {
+                     float* dz, float* part_db, hipStream_t s, int Hc) {
   dim3 grid((H + 255) / 256, bwd_row_chunks(B));
   hipLaunchKernelGGL(bn_bwd_dz_kernel, grid, dim3(NTHR), 0, s, g, bits, z, mean, rstd, coef, keep_scale,
-                     bn, B, H, dz, part_db);
+                     bn, B, H, dz, part_db, Hc > 0 ? Hc : H);
   PL_CHECK_LAUNCH("bn_bwd_dz");
   return PL_OK;
 }
@@ -998,12 +1010,20 @@ extern "C" int pl_l1_terms_fwd_bwd(const PLL1Term* terms, int nterms, float grad
 // otherwise hand the finalize kernel 2048 partials per column (38 us per layer)
 static int bn_group_rows(int64_t rows) { return rows > 16384 ? 256 : 64; }
 static int bn_groups(int64_t rows) { const int gs = bn_group_rows(rows); return (int)((rows + gs - 1) / gs); }
+// replicas of a narrow map: [rows][C] is worked on as [rows/R][R*C] (bn_colstats_kernel)
+static int bn_replicas(int64_t rows, int64_t C) {
+  int r = C <= 64 ? 4 : (C <= 128 ? 2 : 1);
+  while (r > 1 && (rows % r != 0 || rows / r < 2)) r >>= 1;
+  return r;
+}
 
 extern "C" size_t pl_bn_train_scratch_bytes(int64_t rows, int64_t C) {
   if (rows <= 0 || C <= 0) return 0;
-  const size_t fwd = ((size_t)2 * bn_groups(rows) * C + 2 * (size_t)C) * sizeof(float);
-  const int rc = bwd_row_chunks((int)rows);
-  const size_t bwd = ((size_t)2 * rc * C + 3 * (size_t)C + (size_t)rc * C) * sizeof(float);
+  const int R = bn_replicas(rows, C);
+  const int64_t rv = rows / R;                      // rows of the reshaped view
+  const size_t fwd = ((size_t)2 * R * bn_groups(rv) * C + 2 * (size_t)C) * sizeof(float);
+  const int rc = bwd_row_chunks((int)rv);
+  const size_t bwd = ((size_t)2 * R * rc * C + 3 * (size_t)C + (size_t)rc * R * C) * sizeof(float);
   return fwd > bwd ? fwd : bwd;
 }
 
@@ -1013,19 +1033,20 @@ extern "C" int pl_bn_train_fwd(const float* z, int64_t rows, int64_t C, const fl
   if (!z || !gamma || !beta || !y || !bits || !mean || !rstd || !scratch) PL_FAIL(PL_EINVAL, "pl_bn_train_fwd: null pointer");
   if (rows < 2 || rows > INT32_MAX || C <= 0 || (C & 3)) PL_FAIL(rows < 2 ? PL_EBATCH : PL_ESHAPE, "pl_bn_train_fwd: rows=%lld C=%lld (C %% 4 == 0, rows >= 2)", (long long)rows, (long long)C);
   hipStream_t s = (hipStream_t)stream;
-  const int G = bn_groups(rows), B = (int)rows, H = (int)C;
+  const int R = bn_replicas(rows, C);
+  const int B = (int)(rows / R), H = (int)C * R, Hc = (int)C;       // the view the streaming kernels work on
+  const int G = bn_groups(B), gs = bn_group_rows(B);
   float* stat = static_cast<float*>(scratch);
-  float* scale = stat + (size_t)2 * G * H;
-  float* shift = scale + H;
-  const int gs = bn_group_rows(rows);
-  hipLaunchKernelGGL(bn_colstats_kernel, dim3((H + 255) / 256, G), dim3(NTHR), 0, s, z, B, H, gs, stat, stat + (size_t)G * H);
+  float* scale = stat + (size_t)2 * R * G * Hc;
+  float* shift = scale + Hc;
+  hipLaunchKernelGGL(bn_colstats_kernel, dim3((H + 255) / 256, G), dim3(NTHR), 0, s, z, B, H, gs, Hc, stat);
   PL_CHECK_LAUNCH("bn_colstats");
-  PL_TRY(launch_bn_finalize(stat, G, 1, B, H, gamma, beta, eps, momentum, running_mean, running_var, batches, mean, rstd,
+  PL_TRY(launch_bn_finalize(stat, G, R, B, Hc, gamma, beta, eps, momentum, running_mean, running_var, batches, mean, rstd,
                             scale, shift, s, gs));
   const int strips = (H + 255) / 256;
   dim3 grid(strips, stream_rows_grid(B, strips));
   hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NTHR), 0, s, z, scale, shift, (const float*)nullptr, y, bits, B, H,
-                     relu ? 0 : 8, 0u, 1.0f, 0u, 0u, 0u, 0u, (const uint64_t*)nullptr);
+                     relu ? 0 : 8, 0u, 1.0f, 0u, 0u, 0u, 0u, (const uint64_t*)nullptr, Hc);
   PL_CHECK_LAUNCH("bn_apply");
   return PL_OK;
 }
@@ -1037,13 +1058,14 @@ extern "C" int pl_bn_train_bwd(const float* dy, const uint64_t* bits, const floa
     PL_FAIL(PL_EINVAL, "pl_bn_train_bwd: null pointer");
   if (rows < 2 || rows > INT32_MAX || C <= 0 || (C & 3)) PL_FAIL(PL_ESHAPE, "pl_bn_train_bwd: rows=%lld C=%lld", (long long)rows, (long long)C);
   hipStream_t s = (hipStream_t)stream;
-  const int B = (int)rows, H = (int)C, RC = bwd_row_chunks(B);
+  const int R = bn_replicas(rows, C);
+  const int B = (int)(rows / R), H = (int)C * R, Hc = (int)C, RC = bwd_row_chunks(B);
   float* part = static_cast<float*>(scratch);
-  float* coef = part + (size_t)2 * RC * H;
-  float* part_db = coef + 3 * (size_t)H;
-  PL_TRY(launch_bn_bwd_reduce(dy, bits, z, mean, rstd, 1.0f, B, H, part, part + (size_t)RC * H, s));
-  PL_TRY(launch_bn_bwd_finalize(part, RC, 1, 0, B, H, gamma, rstd, coef, dgamma, dbeta, s));
-  return launch_bn_bwd_dz(dy, bits, z, mean, rstd, coef, 1.0f, 1, B, H, dz, part_db, s);
+  float* coef = part + (size_t)2 * R * RC * Hc;
+  float* part_db = coef + 3 * (size_t)Hc;
+  PL_TRY(launch_bn_bwd_reduce(dy, bits, z, mean, rstd, 1.0f, B, H, part, part + (size_t)RC * Hc, s, Hc));
+  PL_TRY(launch_bn_bwd_finalize(part, RC, R, R > 1 ? -1 : 0, B, Hc, gamma, rstd, coef, dgamma, dbeta, s));
+  return launch_bn_bwd_dz(dy, bits, z, mean, rstd, coef, 1.0f, 1, B, H, dz, part_db, s, Hc);
 }
 
 extern "C" int pl_add_relu_fwd(const float* a, const float* b, int64_t rows, int64_t C, float* out, uint64_t* bits,

@@ -98,7 +98,7 @@ int bwd_row_chunks(int B);
 // pass 1: partial column sums of dy and dy*zhat, dy = g * bits * keep_scale
 int launch_bn_bwd_reduce(const float* g, const uint64_t* bits, const float* z, const float* mean,
                          const float* rstd, float keep_scale, int B, int H, float* part_dy,
-                         float* part_dyz, hipStream_t s);
+                         float* part_dyz, hipStream_t s, int Hc = 0);
 // finalize: c = {gamma*rstd, sum_dy/B, sum_dyz/B}; dgamma, dbeta
 // (part = [world][2][RC][H]; coef uses all ranks' partials, dgamma/dbeta this rank's only)
 int launch_bn_bwd_finalize(const float* part, int RC, int world, int rank, int B, int H,
@@ -107,7 +107,7 @@ int launch_bn_bwd_finalize(const float* part, int RC, int world, int rank, int B
 // pass 2: dz = c0*(dy - c1 - zhat*c2)  (bn) or dz = dy (no bn); partial column sums of dz
 int launch_bn_bwd_dz(const float* g, const uint64_t* bits, const float* z, const float* mean,
                      const float* rstd, const float* coef, float keep_scale, int bn, int B, int H,
-                     float* dz, float* part_db, hipStream_t s);
+                     float* dz, float* part_db, hipStream_t s, int Hc = 0);
 
 // out[i] = sum_s slabs[s*n + i]
 int launch_reduce_slabs(const float* slabs, int nslab, int64_t n, float* out, hipStream_t s);
