@@ -117,3 +117,54 @@ def broadcast_model(model, src=0, group=None):
     dist.broadcast(model.flat_params, src, group=group)
     dist.broadcast(model._bn_running, src, group=group)
     dist.broadcast(model._bn_batches, src, group=group)
+
+
+class FlatGrads:
+    """One flat gradient buffer for any module (the conv models keep ordinary torch parameters): every p.grad is a
+    view into it, autograd accumulates straight into the views, and the data-parallel step is ONE sum all-reduce of
+    the buffer (or a few contiguous buckets) instead of one collective per tensor -- the same arena idea as the
+    lifter's (BASELINE configs[4]: phase5 on 8 GPUs, data parallel).
+
+        flat = FlatGrads(model);  ...  flat.zero(); loss.backward(); flat.all_reduce_mean(); optimizer.step()
+    Optimizers must not replace .grad (use zero_grad(set_to_none=False) or flat.zero())."""
+
+    def __init__(self, module, group=None, bucket_bytes=None):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatGrads: the module has no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        if any(p.device != dev or p.dtype != dt for p in self.params):
+            raise ValueError("FlatGrads: parameters must share one device and dtype")
+        sizes = [(p.numel() + 63) // 64 * 64 for p in self.params]          # 64-element aligned slots
+        self.flat = torch.zeros(sum(sizes), dtype=dt, device=dev)
+        self.group, self.bucket_bytes = group, bucket_bytes
+        off = 0
+        for p, n in zip(self.params, sizes):
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += n
+
+    def zero(self):
+        self.flat.zero_()
+
+    def attached(self):
+        """True while every p.grad still is its view of the flat buffer."""
+        base = self.flat.data_ptr()
+        end = base + self.flat.numel() * self.flat.element_size()
+        return all(p.grad is not None and base <= p.grad.data_ptr() < end for p in self.params)
+
+    def all_reduce_mean(self):
+        """Sum over the ranks, divide by the world size; a no-op without an initialised process group."""
+        if not (dist.is_initialized() and dist.get_world_size(self.group) > 1):
+            return
+        if not self.attached():
+            raise RuntimeError("FlatGrads: a .grad was replaced (zero_grad(set_to_none=True)?): gradients are not in the buffer")
+        world = dist.get_world_size(self.group)
+        if self.bucket_bytes:
+            step = max(1, self.bucket_bytes // self.flat.element_size())
+            works = [dist.all_reduce(self.flat[i:i + step], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                     for i in range(0, self.flat.numel(), step)]
+            for w in works:
+                w.wait()
+        else:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        self.flat.div_(world)

@@ -84,3 +84,55 @@ def test_dp_allreduce_single_bucket():
 
 def test_dp_allreduce_bucketed():
     _run(4096)
+
+
+def _flat_worker(rank, world, port, bucket_bytes, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import importlib
+    pkg = importlib.import_module("3d_poseestimation_amd")
+    pkg.dp.init_from_env(backend="gloo")
+    torch.manual_seed(0)                                     # same weights on every rank
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.BatchNorm2d(8), torch.nn.ReLU(),
+                              torch.nn.Conv2d(8, 4, 1))
+    flat = pkg.dp.FlatGrads(net, bucket_bytes=bucket_bytes)
+    g = torch.Generator().manual_seed(5)
+    x, y = torch.randn(8, 3, 6, 6, generator=g), torch.randn(8, 4, 6, 6, generator=g)
+    lo, hi = pkg.dp.shard_rows(8, rank, world)
+    net[1].eval()                                            # running statistics: shards see the same normalisation
+    flat.zero()
+    torch.nn.functional.mse_loss(net(x[lo:hi]), y[lo:hi]).backward()
+    assert flat.attached()
+    flat.all_reduce_mean()
+    mine = flat.flat.clone()
+    ref = [p.grad.clone() for p in net.parameters()]
+    # one process on the whole batch
+    flat.zero()
+    torch.nn.functional.mse_loss(net(x), y).backward()
+    for a, p in zip(ref, net.parameters()):
+        assert torch.allclose(a, p.grad, rtol=1e-5, atol=1e-7)
+    torch.optim.SGD(net.parameters(), lr=0.1).zero_grad(set_to_none=True)     # detaches the views ...
+    try:
+        flat.all_reduce_mean()                                                # ... and that is reported, not ignored
+        out.put("no error")
+    except RuntimeError:
+        out.put(float(mine.abs().sum()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_grads_allreduce_world2():
+    """dp.FlatGrads: any module's gradients in one flat buffer, one (bucketed) all-reduce, mean over ranks ==
+    the whole-batch gradient; replacing a .grad is detected."""
+    ctx = mp.get_context("spawn")
+    for bucket in (None, 256):
+        port, out = _free_port(), ctx.Queue()
+        procs = [ctx.Process(target=_flat_worker, args=(r, 2, port, bucket, out)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = [out.get(timeout=120) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert all(isinstance(v, float) for v in res) and abs(res[0] - res[1]) < 1e-6 * max(1.0, res[0])
