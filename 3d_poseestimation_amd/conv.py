@@ -203,13 +203,7 @@ class _Conv2dFn(torch.autograd.Function):
         stride, padding = ctx.geom
         dy = dy.contiguous()
         dx = conv2d_nhwc_dgrad(dy, w, x.shape[1:3], stride, padding) if ctx.needs_input_grad[0] else None
-        dw = None
-        if ctx.needs_input_grad[1]:
-            if x.shape[3] % 2:       # the stem's 3 channels: pad to 4 so the implicit wgrad kernel (even Cin) takes it
-                xp = torch.nn.functional.pad(x, (0, 1))
-                dw = conv2d_nhwc_wgrad(xp, dy, w.shape[1], stride, padding)[..., :x.shape[3]].contiguous()
-            else:
-                dw = conv2d_nhwc_wgrad(x, dy, w.shape[1], stride, padding)
+        dw = conv2d_nhwc_wgrad(x, dy, w.shape[1], stride, padding) if ctx.needs_input_grad[1] else None
         return dx, dw, None, None
 
 

@@ -249,6 +249,88 @@ __global__ __launch_bounds__(NTHR) void stem7x7_c3_kernel(const float* __restric
   }
 }
 
+// Weight gradient of the stem: dw[co][k] = sum over pixels of dy[p][co] * x_gathered[p][k], k = (kh*7 + kw)*3 + ci
+// -- a 64 x 147 GEMM over B*Ho*Wo pixels whose B operand is a 7x7x3 window per pixel.  As a gathered-B launch of
+// the planes kernel it ran 1.65 ms at B = 32 (8-byte scattered loads); a first LDS-staged VALU kernel, 0.83 ms
+// (four waves queueing on broadcast LDS reads).  Here a workgroup walks whole output rows: the row's dy [Wo][64]
+// and the 7 zero-padded input rows under it are staged in LDS once, and each wave runs exact-fp32 MFMAs
+// (32x32x2: A = dy^T, 2 co-tiles; B = the windows, 5 k-tiles of which 147 columns are real) over its quarter of
+// the row's pixel pairs -- 7 LDS reads per 10 MFMAs.  Two workgroups per CU overlap staging with MFMA work.
+// Waves are combined through LDS at the end; one partial slab per workgroup, fixed-order reduce afterwards.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int STEM_NT = 5;               // ceil(147 / 32)
+constexpr int STEM_LDW = STEM_NT * 32;   // combine buffer row
+__global__ __launch_bounds__(NTHR, 2) void stem7x7_c3_wgrad_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ dy, int B, int H, int W,
+                                                                   int Ho, int Wo, float* __restrict__ part) {
+  extern __shared__ float smem[];
+  const int PW = 2 * Wo + 5;                       // padded input row: iw = -3 .. 2*Wo + 1
+  float* dys = smem;                               // [Wo][64]
+  float* xs = smem + (size_t)Wo * 64;              // [7][PW][3]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+  int boff[STEM_NT];
+#pragma unroll
+  for (int nt = 0; nt < STEM_NT; ++nt) {
+    const int k = min(nt * 32 + j, 146);           // columns >= 147 repeat the last one and are never stored
+    const int kh = k / 21;
+    boff[nt] = kh * PW * 3 + (k - kh * 21);        // (kw, ci) is contiguous in a padded row
+  }
+  f32x16 acc[2][STEM_NT];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < STEM_NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+  const int rows = B * Ho;
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int b = r / Ho, oh = r - b * Ho;
+    __syncthreads();
+    const float4* src = reinterpret_cast<const float4*>(dy + (size_t)r * Wo * 64);
+    for (int e = threadIdx.x; e < Wo * 16; e += NTHR) reinterpret_cast<float4*>(dys)[e] = src[e];
+    for (int e = threadIdx.x; e < 7 * PW * 3; e += NTHR) {
+      const int kh = e / (PW * 3), q = e - kh * PW * 3;
+      const int px = q / 3, iw = px - 3, ci = q - px * 3, ih = oh * 2 - 3 + kh;
+      xs[e] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? x[(((size_t)b * H + ih) * W + iw) * 3 + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int ow = wave * 2; ow < Wo; ow += 8) {    // lane half h takes pixel ow + h of the pair
+      const bool valid = ow + h < Wo;
+      const int p = min(ow + h, Wo - 1);
+      const float a0 = valid ? dys[p * 64 + j] : 0.f, a1 = valid ? dys[p * 64 + 32 + j] : 0.f;
+      float bv[STEM_NT];
+#pragma unroll
+      for (int nt = 0; nt < STEM_NT; ++nt) bv[nt] = xs[boff[nt] + p * 6];
+#pragma unroll
+      for (int nt = 0; nt < STEM_NT; ++nt) {
+        acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[nt], acc[0][nt], 0, 0, 0);
+        acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[nt], acc[1][nt], 0, 0, 0);
+      }
+    }
+  }
+  for (int w = 0; w < NTHR / 64; ++w) {            // fixed-order combine of the four waves: [64][STEM_LDW] in LDS
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < STEM_NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = mt * 32 + (r >> 2) * 8 + h * 4 + (r & 3);
+            float* d = smem + co * STEM_LDW + nt * 32 + j;
+            *d = w == 0 ? acc[mt][nt][r] : *d + acc[mt][nt][r];
+          }
+    }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 64 * 147; e += NTHR) {
+    const int co = e / 147, k = e - co * 147;
+    part[(size_t)blockIdx.x * 64 * 147 + e] = smem[co * STEM_LDW + k];
+  }
+}
+constexpr int STEM_WGRAD_WGS = 512;
+
 bool implicit_ok(int64_t M, int64_t Cin, int64_t Cout, int64_t K) {
   (void)Cout; (void)M;                   // any width, any pixel count: ragged last tiles are clamped and masked
   return Cin % 32 == 0 && K % 32 == 0;
@@ -402,11 +484,23 @@ extern "C" int pl_nhwc_to_nchw(const float* in, int64_t B, int64_t P, int64_t C,
 }
 
 // ---- weight gradient -----------------------------------------------------------------------
+// Split-K factor of a weight gradient: the pixel dimension is long (B*Ho*Wo) and the output small, so the slices
+// fill the chip.  Picks the s minimising rounds x slice length, rounds = ceil(tiles*s / 256 CUs) (one workgroup
+// per CU: 150 KB of LDS), slice length in 32-pixel tiles plus ~6 tiles' worth of prologue / epilogue -- any s,
+// not only powers of two (18 tiles x 16 slices = 288 workgroups ran two rounds, 14 slices run one).  Slices are
+// at least 8 tiles long and none is empty.  A fixed function of the shape, so results are reproducible.
 static int wgrad_splits(int64_t M, int64_t N, int64_t K) {
-  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
-  int s = 1;
-  while (tiles * s < 256 && s < 64 && K % (32 * (s * 2)) == 0 && K / (s * 2) >= 256) s *= 2;
-  return s;
+  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128), T = K / 32;
+  int best = 1;
+  int64_t best_cost = (tiles + 255) / 256 * (T + 6);
+  for (int s = 2; s <= 256; ++s) {
+    const int64_t per = (T + s - 1) / s;
+    if (per < 8) break;
+    if ((int64_t)(s - 1) * per >= T) continue;                 // would leave the last slice empty
+    const int64_t cost = (tiles * s + 255) / 256 * (per + 6);
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  return best;
 }
 
 static bool wgrad_implicit_ok(int64_t Cin, int64_t Cout, int64_t N, int64_t K, int64_t Wo) {
@@ -421,6 +515,8 @@ extern "C" size_t pl_conv2d_nhwc_wgrad_scratch_bytes(int64_t B, int64_t H, int64
   const int64_t Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return 0;
   const int64_t K = B * Ho * Wo, N = (int64_t)KH * KW * Cin;
+  if (Cin == 3 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && Cout == 64 && Wo <= 256)
+    return (size_t)STEM_WGRAD_WGS * 64 * 147 * sizeof(float);            // stem7x7_c3_wgrad_kernel partials
   const int s = wgrad_splits(Cout, N, K);
   size_t bytes = s > 1 ? (size_t)s * Cout * N * sizeof(float) : 0;
   if (!wgrad_implicit_ok(Cin, Cout, N, K, Wo)) bytes += (size_t)K * N * sizeof(float);
@@ -437,6 +533,16 @@ extern "C" int pl_conv2d_nhwc_wgrad(const float* x, int64_t B, int64_t H, int64_
   const int64_t Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   const int64_t K = B * Ho * Wo, N = (int64_t)KH * KW * Cin;
   if (Ho <= 0 || Wo <= 0 || K > INT32_MAX || N > INT32_MAX) PL_FAIL(PL_ESHAPE, "pl_conv2d_nhwc_wgrad: bad output size");
+  if (Cin == 3 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && Cout == 64 && Wo <= 256) {      // the stem
+    const int nwg = STEM_WGRAD_WGS;
+    const size_t need = (size_t)nwg * 64 * 147 * sizeof(float);
+    if (!scratch || scratch_bytes < need) PL_FAIL(PL_EWORKSPACE, "pl_conv2d_nhwc_wgrad: needs %zu scratch bytes (got %zu)", need, scratch_bytes);
+    const size_t lds = std::max(((size_t)Wo * 64 + 7 * (2 * (size_t)Wo + 5) * 3), (size_t)64 * STEM_LDW) * sizeof(float);
+    hipLaunchKernelGGL(stem7x7_c3_wgrad_kernel, dim3(nwg), dim3(NTHR), lds, (hipStream_t)stream, x, dy, (int)B, (int)H,
+                       (int)W, (int)Ho, (int)Wo, static_cast<float*>(scratch));
+    PL_CHECK_LAUNCH("stem7x7_c3_wgrad");
+    return launch_reduce_slabs(static_cast<const float*>(scratch), nwg, 64 * 147, dw, (hipStream_t)stream);
+  }
   const bool implicit = wgrad_implicit_ok(Cin, Cout, N, K, Wo);
   const int splits = wgrad_splits(Cout, N, K);
   const size_t slab_bytes = splits > 1 ? (size_t)splits * Cout * N * sizeof(float) : 0;

@@ -823,9 +823,9 @@ __device__ __forceinline__ void gemm_body_planes(const GemmArgs& p, const int bl
   int kbeg = 0, kend = p.K;
   float* C = p.C;
   if (p.split_k > 1) {
-    const int per = p.K / p.split_k;
-    kbeg = slice * per;
-    kend = kbeg + per;
+    const int per = ((p.K / BKX + p.split_k - 1) / p.split_k) * BKX;     // whole tiles; the last slice may be shorter
+    kbeg = min(slice * per, p.K);
+    kend = min(kbeg + per, p.K);
     C += (size_t)slice * p.M * p.ldc;
   }
   const int nk = (kend - kbeg) / BKX;
@@ -1172,14 +1172,14 @@ int launch_conv_nhwc(const GemmArgs& a, hipStream_t s) {
 }
 
 // dW = dy^T x_gathered: a.A = dy [pixels][Cout] (lda = Cout), a.B = x (NHWC), a.C = slabs when split_k > 1,
-// a.M = Cout, a.N = KH*KW*Cin, a.K = B*Ho*Wo; needs Cout % 128 == 0, N % 128 == 0, Cin even, Wo % 8 == 0 and
-// every K slice a multiple of 32 pixels.
+// a.M = Cout, a.N = KH*KW*Cin, a.K = B*Ho*Wo; needs Cout and Cin even, Wo % 8 == 0 and pixels % 32 == 0; the K slices
+// are whole 32-pixel tiles, the last one possibly shorter.
 int launch_conv_wgrad(const GemmArgs& a, hipStream_t s) {
   if (!a.A || !a.B || !a.C) PL_FAIL(PL_EINVAL, "conv wgrad: null operand");
   const int splits = a.split_k > 1 ? a.split_k : 1;
   if (a.conv_cin <= 0 || (a.conv_cin & 1) || a.M < 2 || (a.M & 1) || a.N < 2 || a.N % a.conv_cin || a.conv_wo % 8 ||
-      a.K % (BK * splits) || a.K != (a.K / (a.conv_ho * a.conv_wo)) * a.conv_ho * a.conv_wo || (a.lda & 1))
-    PL_FAIL(PL_ESHAPE, "conv wgrad: needs even Cout and Cin, Wo %% 8 == 0, pixels %% (32*splits) == 0 "
+      a.K % BK || a.K != (a.K / (a.conv_ho * a.conv_wo)) * a.conv_ho * a.conv_wo || (a.lda & 1))
+    PL_FAIL(PL_ESHAPE, "conv wgrad: needs even Cout and Cin, Wo %% 8 == 0, pixels %% 32 == 0 "
                        "(M=%d N=%d K=%d Cin=%d Wo=%d splits=%d)", a.M, a.N, a.K, a.conv_cin, a.conv_wo, splits);
   if ((reinterpret_cast<uintptr_t>(a.A) & 7) || (reinterpret_cast<uintptr_t>(a.B) & 7))
     PL_FAIL(PL_EINVAL, "conv wgrad: operands misaligned");
