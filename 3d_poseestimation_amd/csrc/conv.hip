@@ -336,6 +336,60 @@ bool implicit_ok(int64_t M, int64_t Cin, int64_t Cout, int64_t K) {
   return Cin % 32 == 0 && K % 32 == 0;
 }
 
+// y = epilogue(sum of split-K slabs): the epilogue of gemm_epilogue (bias, scale/shift, ReLU, residual, ReLU) applied
+// after the fixed-order slab sum; one float4 per thread, N % 4 == 0
+__global__ __launch_bounds__(NTHR) void reduce_slabs_epi_kernel(const float* __restrict__ slabs, int nslab, int64_t n4,
+                                                                int N, const float* __restrict__ bias,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int relu,
+                                                                const float* __restrict__ resid,
+                                                                float* __restrict__ y) {
+  const int64_t t = (int64_t)blockIdx.x * NTHR + threadIdx.x;
+  if (t >= n4) return;
+  float4 v = reinterpret_cast<const float4*>(slabs)[t];
+  for (int sl = 1; sl < nslab; ++sl) {
+    const float4 q = reinterpret_cast<const float4*>(slabs)[(size_t)sl * n4 + t];
+    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+  }
+  const int c = (int)((t * 4) % N);
+  float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (bias) o[j] += bias[c + j];
+    if (scale) o[j] = fmaf(o[j], scale[c + j], shift[c + j]);
+    if (relu == 1) o[j] = fmaxf(o[j], 0.f);
+  }
+  if (resid) {
+    const float4 q = reinterpret_cast<const float4*>(resid)[t];
+    o[0] += q.x; o[1] += q.y; o[2] += q.z; o[3] += q.w;
+  }
+  if (relu == 2) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+  }
+  reinterpret_cast<float4*>(y)[t] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// Split-K of a FORWARD / input-gradient convolution GEMM (M = pixels, N = Cout, K = taps x Cin): the deep layers
+// have few output tiles (layer4 at B = 32: 2048 x 512 = 64 tiles of 128 x 128 for 256 CUs, 144 K tiles each), so K
+// is cut into s slices whose plain sums land in slabs, and reduce_slabs_epi_kernel sums them and applies the
+// epilogue.  Cost model as wgrad_splits, plus the slab traffic ((s + 1) M N floats at ~4 TB/s) in units of one
+// K-tile step (~1.2 us); s divides the K tiles, slices >= 8 tiles, s <= 8.  1 = no split.
+int conv_fwd_splits(int64_t M, int64_t N, int64_t K, int arith) {
+  if (arith != PL_BF16X6 || (N & 3) || K % 32) return 1;
+  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128), T = K / 32;
+  if (tiles >= 192) return 1;
+  int best = 1;
+  double best_cost = (double)((tiles + 255) / 256) * (T + 6);
+  for (int s = 2; s <= 8; ++s) {
+    if (T % s || T / s < 8) continue;
+    const double traffic = (double)(s + 1) * M * N * 4.0 / 4.0e6 / 1.2;
+    const double cost = (double)((tiles * s + 255) / 256) * (T / s + 6) + traffic;
+    if (cost < best_cost * 0.9) { best_cost = cost; best = s; }
+  }
+  return best;
+}
+
 int conv_core(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* w, int64_t Cout, int KH,
               int KW, int stride, int pad_h, int pad_w, int64_t Ho, int64_t Wo, const float* scale,
               const float* shift, const float* bias, int relu, const float* resid, float* y, void* scratch,
@@ -355,15 +409,33 @@ int conv_core(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, cons
     return PL_OK;
   }
   const int gemm_arith = arith == PL_BF16 ? 7 : arith;     // PL_BF16 on the planes pipeline (gemm_f32.hip)
-  if (KH == 1 && KW == 1 && stride == 1 && pad_h == 0 && pad_w == 0) {
-    g.arith = gemm_arith;
-    return launch_gemm_f32(kNT, g, s);
+  const bool one = KH == 1 && KW == 1 && stride == 1 && pad_h == 0 && pad_w == 0;
+  const bool implicit = !one && implicit_ok(M, Cin, Cout, K);
+  // split-K (whole 128 x 128 tiles only: the split kernels' plain store is the tile store)
+  const int splits = (one || implicit) && M % 128 == 0 && Cout % 128 == 0 ? conv_fwd_splits(M, Cout, K, arith) : 1;
+  if (splits > 1) {
+    const size_t need = (size_t)splits * M * Cout * sizeof(float);
+    if (!scratch || scratch_bytes < need)
+      PL_FAIL(PL_EWORKSPACE, "conv: this shape is split %d ways over K and needs %zu scratch bytes (got %zu)", splits,
+              need, scratch_bytes);
+    g.C = static_cast<float*>(scratch); g.split_k = splits;
+    g.bias = nullptr; g.col_scale = nullptr; g.col_shift = nullptr; g.relu = 0; g.resid = nullptr;
   }
-  if (implicit_ok(M, Cin, Cout, K)) {
+  if (one) {
+    g.arith = gemm_arith;
+    PL_TRY(launch_gemm_f32(kNT, g, s));
+  } else if (implicit) {
     g.conv_cin = (int)Cin; g.conv_h = (int)H; g.conv_w = (int)W; g.conv_ho = (int)Ho; g.conv_wo = (int)Wo;
     g.conv_kw = KW; g.conv_stride = stride; g.conv_pad_h = pad_h; g.conv_pad_w = pad_w;
-    return launch_conv_nhwc(g, s);
+    PL_TRY(launch_conv_nhwc(g, s));
   }
+  if (splits > 1) {
+    const int64_t n4 = M * Cout / 4;
+    hipLaunchKernelGGL(reduce_slabs_epi_kernel, dim3((unsigned)((n4 + NTHR - 1) / NTHR)), dim3(NTHR), 0, s,
+                       static_cast<const float*>(scratch), splits, n4, (int)Cout, bias, scale, shift, relu, resid, y);
+    PL_CHECK_LAUNCH("reduce_slabs_epi");
+  }
+  if (one || implicit) return PL_OK;
   // fallback: explicit im2col (rows zero-padded to a multiple of 32 floats = whole K tiles) + the generic GEMM
   if (pad_h != pad_w) PL_FAIL(PL_ESHAPE, "conv: asymmetric padding only on the implicit path");
   const int64_t Kp = (K + 31) / 32 * 32;
@@ -397,8 +469,11 @@ extern "C" size_t pl_conv2d_nhwc_scratch_bytes(int64_t B, int64_t H, int64_t W, 
   const int64_t Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return 0;
   const int64_t M = B * Ho * Wo, K = (int64_t)KH * KW * Cin;
-  if ((KH == 1 && KW == 1 && stride == 1 && pad == 0) || implicit_ok(M, Cin, Cout, K)) return 0;
   if (Cin == 3 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && Cout == 64) return 0;      // stem7x7_c3_kernel
+  if ((KH == 1 && KW == 1 && stride == 1 && pad == 0) || implicit_ok(M, Cin, Cout, K)) {
+    const int splits = M % 128 == 0 && Cout % 128 == 0 ? conv_fwd_splits(M, Cout, K, PL_BF16X6) : 1;   // split-K slabs
+    return splits > 1 ? (size_t)splits * M * Cout * sizeof(float) : 0;
+  }
   const int64_t Kp = (K + 31) / 32 * 32;
   return ((size_t)M * Kp + (size_t)Cout * Kp) * sizeof(float);
 }

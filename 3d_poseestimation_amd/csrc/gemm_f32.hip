@@ -1154,12 +1154,15 @@ int launch_gemm_f32_pair(const GemmArgs& nn, const GemmArgs& tn, hipStream_t s) 
 
 int launch_conv_nhwc(const GemmArgs& a, hipStream_t s) {
   if (!a.A || !a.B || !a.C) PL_FAIL(PL_EINVAL, "conv: null operand");
-  if (a.conv_cin <= 0 || a.conv_cin % 32 || a.M < 1 || a.N < 1 || a.K % BK || a.K % a.conv_cin || a.split_k > 1)
-    PL_FAIL(PL_ESHAPE, "conv: needs Cin %% 32 == 0 (M=%d N=%d K=%d Cin=%d)", a.M, a.N, a.K, a.conv_cin);
+  const int splits = a.split_k > 1 ? a.split_k : 1;         // > 1: a.C = slabs [splits][M][ldc], plain sums
+  if (a.conv_cin <= 0 || a.conv_cin % 32 || a.M < 1 || a.N < 1 || a.K % BK || a.K % a.conv_cin ||
+      (splits > 1 && (a.arith == 1 || (a.K / BK) % splits)))
+    PL_FAIL(PL_ESHAPE, "conv: needs Cin %% 32 == 0 and whole K slices (M=%d N=%d K=%d Cin=%d splits=%d)", a.M, a.N,
+            a.K, a.conv_cin, splits);
   if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15)
     PL_FAIL(PL_EINVAL, "conv: operands not 16-byte aligned");
   ProfRec* prof = prof_begin(a, s);
-  const dim3 grid(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN));
+  const dim3 grid(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * splits);
   const bool edge = a.N % BN || a.M % BM;
   if (a.arith == 1) {
     if (edge) hipLaunchKernelGGL(conv_bf16_planes_kernel<true>, grid, dim3(NTHR), 0, s, a);
