@@ -121,7 +121,7 @@ Ws plan(const PLDesc* d, int64_t B) {
   w.L = 1 + 2 * d->num_stage;
   const int H = d->hidden;
   w.G = gemm_stat_groups((int)B);
-  w.RC = bwd_row_chunks((int)B);
+  w.RC = bwd_row_chunks((int)B, H);
   size_t o = 0;
   auto take = [&](size_t bytes) {
     const size_t at = o;

@@ -115,6 +115,10 @@ __device__ __forceinline__ float4 combine4(float4 v, float4 (*sm)[64], int wave,
 // Narrow maps (C = 64, 128): the caller views [rows][C] as [rows/R][R*C] so that every lane of a 256-column strip
 // works; virtual column vc is replica vc / Hc of real column vc % Hc, and the partials are written replica-major
 // ([R][2][G][Hc]) -- exactly the [world][2][G][H] layout bn_finalize merges, with the replicas in the role of ranks.
+// One pass over z: a workgroup's gs rows are taken 64 at a time, each wave holding its 16 rows of the sub-group in
+// registers (16 loads in flight per lane) for the sum AND the squares about the sub-group mean; the sub-groups are
+// merged pairwise in order (Chan et al.) into the one partial per gs rows.  (The first version re-read the group
+// from memory for the second moment: 2x the traffic on maps far larger than the L2.)
 __global__ __launch_bounds__(NTHR) void bn_colstats_kernel(const float* __restrict__ z, int B, int H, int gs, int Hc,
                                                            float* __restrict__ stat) {
   __shared__ float4 sm[4][64];
@@ -122,33 +126,49 @@ __global__ __launch_bounds__(NTHR) void bn_colstats_kernel(const float* __restri
   const int c = blockIdx.x * 256 + lane * 4;
   const bool active = c < H;
   const int r0 = blockIdx.y * gs, r1 = min(B, r0 + gs);
-  float4 s = make_float4(0, 0, 0, 0);
-  if (active)
-    for (int r = r0 + wave; r < r1; r += 4) {
-      const float4 v = ld4(z + (size_t)r * H + c);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  float4 tsum = make_float4(0, 0, 0, 0), tm2 = tsum;       // merged so far (wave 0)
+  float ndone = 0.f;
+  for (int q0 = r0; q0 < r1; q0 += 64) {
+    const int q1 = min(r1, q0 + 64);
+    float4 v[16];
+    float4 s = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = q0 + wave + 4 * i;
+      v[i] = (active && r < q1) ? ld4(z + (size_t)r * H + c) : make_float4(0, 0, 0, 0);
     }
-  float4 t = combine4(s, sm, wave, lane);
-  if (wave == 0) sm[0][lane] = t;
-  __syncthreads();
-  t = sm[0][lane];
-  __syncthreads();
-  const float inv = 1.0f / (float)(r1 - r0);
-  const float4 mu = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
-  float4 m2 = make_float4(0, 0, 0, 0);
-  if (active)
-    for (int r = r0 + wave; r < r1; r += 4) {
-      const float4 v = ld4(z + (size_t)r * H + c);
-      const float dx = v.x - mu.x, dy = v.y - mu.y, dz = v.z - mu.z, dw = v.w - mu.w;
-      m2.x = fmaf(dx, dx, m2.x); m2.y = fmaf(dy, dy, m2.y); m2.z = fmaf(dz, dz, m2.z); m2.w = fmaf(dw, dw, m2.w);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+    float4 t = combine4(s, sm, wave, lane);
+    if (wave == 0) sm[0][lane] = t;
+    __syncthreads();
+    t = sm[0][lane];
+    __syncthreads();
+    const float nb = (float)(q1 - q0), inv = 1.0f / nb;
+    const float4 mu = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
+    float4 m2 = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      if (q0 + wave + 4 * i < q1) {
+        const float dx = v[i].x - mu.x, dy = v[i].y - mu.y, dz = v[i].z - mu.z, dw = v[i].w - mu.w;
+        m2.x = fmaf(dx, dx, m2.x); m2.y = fmaf(dy, dy, m2.y); m2.z = fmaf(dz, dz, m2.z); m2.w = fmaf(dw, dw, m2.w);
+      }
+    const float4 q = combine4(m2, sm, wave, lane);
+    if (ndone == 0.f) { tsum = t; tm2 = q; }
+    else {
+      const float w = ndone * nb / (ndone + nb), ia = 1.0f / ndone;
+      const float dx = mu.x - tsum.x * ia, dy = mu.y - tsum.y * ia, dz = mu.z - tsum.z * ia, dw = mu.w - tsum.w * ia;
+      tm2.x += q.x + dx * dx * w; tm2.y += q.y + dy * dy * w; tm2.z += q.z + dz * dz * w; tm2.w += q.w + dw * dw * w;
+      tsum.x += t.x; tsum.y += t.y; tsum.z += t.z; tsum.w += t.w;
     }
-  const float4 q = combine4(m2, sm, wave, lane);
+    ndone += nb;
+  }
   if (wave == 0 && active) {
     const int rep = c / Hc, cc = c - rep * Hc;
     const size_t GH = (size_t)gridDim.y * Hc;
     float* base = stat + (size_t)rep * 2 * GH + (size_t)blockIdx.y * Hc + cc;
-    st4(base, t);
-    st4(base + GH, q);
+    st4(base, tsum);
+    st4(base + GH, tm2);
   }
 }
 
@@ -743,16 +763,22 @@ int launch_bn_apply(const float* z, const float* scale, const float* shift, cons
   return PL_OK;
 }
 
-int bwd_row_chunks(int B) {
+// Row chunks of the two backward streaming passes over a [B][H] matrix (grid.y; one partial row per chunk).
+// 32 rows per chunk, capped so that strips x chunks stays near 2048 workgroups (8 per CU) and never below 128:
+// a 256-column map of the conv path (one strip, 131072 rows) ran 128 workgroups on 256 CUs with the old flat cap.
+int bwd_row_chunks(int B, int H) {
+  const int strips = (H + 255) / 256;
+  int cap = 2048 / strips;
+  if (cap < 128) cap = 128;
   int rc = (B + 31) / 32;
-  if (rc > 128) rc = 128;
+  if (rc > cap) rc = cap;
   return rc < 1 ? 1 : rc;
 }
 
 int launch_bn_bwd_reduce(const float* g, const uint64_t* bits, const float* z, const float* mean,
                          const float* rstd, float keep_scale, int B, int H, float* part_dy,
                          float* part_dyz, hipStream_t s, int Hc) {
-  dim3 grid((H + 255) / 256, bwd_row_chunks(B));
+  dim3 grid((H + 255) / 256, bwd_row_chunks(B, H));
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(NTHR), 0, s, g, bits, z, mean, rstd, keep_scale, B,
                      H, part_dy, part_dyz, Hc > 0 ? Hc : H);
   PL_CHECK_LAUNCH("bn_bwd_reduce");
@@ -771,7 +797,7 @@ int launch_bn_bwd_finalize(const float* part, int RC, int world, int rank, int B
 int launch_bn_bwd_dz(const float* g, const uint64_t* bits, const float* z, const float* mean,
                      const float* rstd, const float* coef, float keep_scale, int bn, int B, int H,
                      float* dz, float* part_db, hipStream_t s, int Hc) {
-  dim3 grid((H + 255) / 256, bwd_row_chunks(B));
+  dim3 grid((H + 255) / 256, bwd_row_chunks(B, H));
   hipLaunchKernelGGL(bn_bwd_dz_kernel, grid, dim3(NTHR), 0, s, g, bits, z, mean, rstd, coef, keep_scale,
                      bn, B, H, dz, part_db, Hc > 0 ? Hc : H);
   PL_CHECK_LAUNCH("bn_bwd_dz");
@@ -1022,7 +1048,7 @@ extern "C" size_t pl_bn_train_scratch_bytes(int64_t rows, int64_t C) {
   const int R = bn_replicas(rows, C);
   const int64_t rv = rows / R;                      // rows of the reshaped view
   const size_t fwd = ((size_t)2 * R * bn_groups(rv) * C + 2 * (size_t)C) * sizeof(float);
-  const int rc = bwd_row_chunks((int)rv);
+  const int rc = bwd_row_chunks((int)rv, (int)C * R);
   const size_t bwd = ((size_t)2 * R * rc * C + 3 * (size_t)C + (size_t)rc * R * C) * sizeof(float);
   return fwd > bwd ? fwd : bwd;
 }
@@ -1059,7 +1085,7 @@ extern "C" int pl_bn_train_bwd(const float* dy, const uint64_t* bits, const floa
   if (rows < 2 || rows > INT32_MAX || C <= 0 || (C & 3)) PL_FAIL(PL_ESHAPE, "pl_bn_train_bwd: rows=%lld C=%lld", (long long)rows, (long long)C);
   hipStream_t s = (hipStream_t)stream;
   const int R = bn_replicas(rows, C);
-  const int B = (int)(rows / R), H = (int)C * R, Hc = (int)C, RC = bwd_row_chunks(B);
+  const int B = (int)(rows / R), H = (int)C * R, Hc = (int)C, RC = bwd_row_chunks(B, H);
   float* part = static_cast<float*>(scratch);
   float* coef = part + (size_t)2 * R * RC * Hc;
   float* part_db = coef + 3 * (size_t)Hc;

@@ -94,7 +94,7 @@ int launch_bn_apply(const float* z, const float* scale, const float* shift, cons
                     float* act, uint64_t* bits, int B, int H, float p, uint64_t seed,
                     uint64_t step, int layer, const uint64_t* inject_keep, hipStream_t s);
 
-int bwd_row_chunks(int B);
+int bwd_row_chunks(int B, int H);
 // pass 1: partial column sums of dy and dy*zhat, dy = g * bits * keep_scale
 int launch_bn_bwd_reduce(const float* g, const uint64_t* bits, const float* z, const float* mean,
                          const float* rstd, float keep_scale, int B, int H, float* part_dy,
