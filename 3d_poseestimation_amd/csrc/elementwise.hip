@@ -58,7 +58,10 @@ __global__ __launch_bounds__(NTHR) void bn_finalize_kernel(
   const float Bt = (float)Br * (float)world;
   const size_t GH = (size_t)G * H;
   float s = 0.f;
+  // (unroll: the partial loads are independent; left rolled each one waited out a memory round trip, 90 us for
+  //  the 4096 partials per column of a 64-channel map)
   if (ok)
+#pragma unroll 8
     for (int g = part; g < GT; g += RPARTS) {
       const int r = g / G, gl = g - r * G;
       s += stat[(size_t)r * 2 * GH + (size_t)gl * H + c];
@@ -66,6 +69,7 @@ __global__ __launch_bounds__(NTHR) void bn_finalize_kernel(
   const float mean = parts_sum(s, red, cl, part) / Bt;
   float m2 = 0.f;
   if (ok)
+#pragma unroll 8
     for (int g = part; g < GT; g += RPARTS) {
       const int r = g / G, gl = g - r * G;
       const int n = max(0, min(gs, Br - gl * gs));
@@ -343,7 +347,8 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_finalize_kernel(
   // rank < 0: the "ranks" are replicas of a narrow map (bn_colstats_kernel): every partial is this process's own
   const float* mine = part_all + (size_t)max(rank, 0) * 2 * RH;
   float a = 0.f, b = 0.f;
-  if (ok)
+  if (ok && rank >= 0)                    // a replica view only needs the totals below
+#pragma unroll 8
     for (int k = part; k < RC; k += RPARTS) {
       a += mine[(size_t)k * H + c];
       b += mine[RH + (size_t)k * H + c];
@@ -354,6 +359,7 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_finalize_kernel(
   if (world > 1) {                        // fixed rank-major order: every rank computes the same totals
     a = 0.f; b = 0.f;
     if (ok)
+#pragma unroll 8
       for (int k = part; k < RC * world; k += RPARTS) {
         const int r = k / RC, kl = k - r * RC;
         a += part_all[(size_t)r * 2 * RH + (size_t)kl * H + c];
@@ -380,6 +386,7 @@ __global__ __launch_bounds__(NTHR) void reduce_rows_kernel(const float* __restri
   const int c = blockIdx.x * RCOLS + cl;
   float a = 0.f;
   if (c < H)
+#pragma unroll 8
     for (int k = p; k < R; k += RPARTS) a += part[(size_t)k * H + c];
   const float t = parts_sum(a, red, cl, p);
   if (p == 0 && c < H) out[c] = t;
@@ -495,6 +502,7 @@ __global__ __launch_bounds__(NTHR) void reduce_rows_multi_kernel(RowJobs j) {
   const int c = blockIdx.x * RCOLS + cl;
   float a = 0.f;
   if (c < H)
+#pragma unroll 8
     for (int k = p; k < R; k += RPARTS) a += part[(size_t)k * H + c];
   const float t = parts_sum(a, red, cl, p);
   if (p == 0 && c < H) j.out[job][c] = t;
@@ -764,11 +772,12 @@ int launch_bn_apply(const float* z, const float* scale, const float* shift, cons
 }
 
 // Row chunks of the two backward streaming passes over a [B][H] matrix (grid.y; one partial row per chunk).
-// 32 rows per chunk, capped so that strips x chunks stays near 2048 workgroups (8 per CU) and never below 128:
-// a 256-column map of the conv path (one strip, 131072 rows) ran 128 workgroups on 256 CUs with the old flat cap.
+// 32 rows per chunk, capped so that strips x chunks stays near 1024 workgroups (4 per CU) and never below 128:
+// a 256-column map of the conv path (one strip, 131072 rows) ran 128 workgroups on 256 CUs with the old flat cap;
+// 2048 made the two streaming passes no faster and the finalize kernel (serial over the chunks) twice as slow.
 int bwd_row_chunks(int B, int H) {
   const int strips = (H + 255) / 256;
-  int cap = 2048 / strips;
+  int cap = 1024 / strips;
   if (cap < 128) cap = 128;
   int rc = (B + 31) / 32;
   if (rc > cap) rc = cap;

@@ -43,6 +43,7 @@ FLOP_PER_POSE = 25_618_432          # 2 x 12,809,216 MAC, GEMMs onl
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MATRIX_TFLOPS = 2516.0    # dense bf16 MFMA peak (the 2:1-sparsity figure is NOT used)
 BATCH = 4096
+PROF_EVERY = 7    # HIP events around every 7th GEMM launch (coprime with the launches per step; see poselift.h)
 
 
 def parse():
@@ -130,7 +131,8 @@ def read_rooflines(pkg, L, dtype, one, traffic):
         r = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
              "frac": round(ach / peak, 4), "traffic": traffic.get(tkey) if traffic else None,
              "kernel": kernel, "flop_per_launch": fl.value / n_l.value,
-             "avg_launch_us": round(avg_ms * 1e3, 2), "launches_timed": n_l.value}
+             "avg_launch_us": round(avg_ms * 1e3, 2), "launches_timed": n_l.value,
+             "sampling": f"HIP events around every {PROF_EVERY}th GEMM launch of the timed region"}
         if redundancy > 1:
             r["mfma_issue_frac"] = round(redundancy * ach / peak, 4)
         return r
@@ -172,7 +174,7 @@ def side_measurements(pkg, a, dev, x_eval, y_oracle):
         m = pkg.LinearModel(34, 51, compute_dtype=other).to(dev).train()
         opt = pkg.FlatAdamW(m, lr=1e-4)
         L = pkg.lib()
-        L.pl_prof_enable(1)
+        L.pl_prof_enable(PROF_EVERY)
         v = timed(lambda: pkg.train_step(m, opt, xb, yb))
         rl = read_rooflines(pkg, L, other, 2.0 * a.batch * 1024 * 1024, None)
         L.pl_prof_enable(0)
@@ -247,7 +249,7 @@ def main():
         model.flat_grads.zero_()
     run(a.warmup)
     if not a.no_prof:
-        L.pl_prof_enable(1)
+        L.pl_prof_enable(PROF_EVERY)
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(a.steps, a.warmup)

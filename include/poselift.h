@@ -327,8 +327,9 @@ int pl_softargmax_bwd(const float* logits, const float* stats, const float* gcoo
                       void* stream);
 
 /* ---- measurement hook (bench.py; not part of the reference interface) ------------------ */
-/* While enabled, every GEMM launch is bracketed by two HIP events recorded on the launch
- * stream.  pl_prof_read waits for them and sums the durations of the launches whose
+/* While enabled (on = n > 0), every n-th GEMM launch (n = 1: every one) is bracketed by two HIP events
+ * recorded on the launch stream -- a pair costs ~2.5 us of stream time, so bench.py samples every 7th launch
+ * of its timed region rather than all of them.  pl_prof_read waits for them and sums the durations of the launches whose
  * algorithmic work (2*M*N*K, summed over both problems of a dual launch) lies in
  * [min_flops, max_flops].  Enabling resets the record.  Not capturable. */
 int pl_prof_enable(int on);
