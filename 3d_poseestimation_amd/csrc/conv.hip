@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NTHR) void deconv_interleave_kernel(const float* __
   *reinterpret_cast<float4*>(y + ((b * 2 * Hi + oh) * 2 * Wi + ow) * C + c) = v;
 }
 
-// out[b][c][p] = in[b][p][c]   (p = pixel); 32x32 tiles through LDS, both sides coalesced
+// out[b][c][p] = in[b][p][c]   (p = pixel); 32x32 tiles through LDS, both sides coalesced (any P, C)
 __global__ __launch_bounds__(1024) void nhwc_to_nchw_kernel(const float* __restrict__ in, int P, int C,
                                                             float* __restrict__ out) {
   __shared__ float tile[32][33];
@@ -185,6 +185,34 @@ __global__ __launch_bounds__(1024) void nhwc_to_nchw_kernel(const float* __restr
   if (p0 + ty < P && c0 + tx < C) tile[ty][tx] = in[(b * P + p0 + ty) * C + c0 + tx];
   __syncthreads();
   if (c0 + ty < C && p0 + tx < P) out[(b * C + c0 + ty) * P + p0 + tx] = tile[tx][ty];
+}
+
+// the same for P % 4 == 0 and C % 4 == 0 (the head: P = 4096, C = 1088): 64x64 tiles, 16-byte loads along C and
+// 16-byte stores along P, 256 B per row on both sides (the 32x32 scalar version moved 0.77 TB/s, 3 ms per call at
+// B = 256); the 65-float row stride keeps both LDS phases conflict-free
+__global__ __launch_bounds__(NTHR) void nhwc_to_nchw_vec_kernel(const float* __restrict__ in, int P, int C,
+                                                                float* __restrict__ out) {
+  __shared__ float tile[64][65];                   // [p][c]
+  const int64_t b = blockIdx.z;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = p0 + ty + 16 * i, c = c0 + tx * 4;
+    if (p < P && c < C) {
+      const float4 v = *reinterpret_cast<const float4*>(in + (b * P + p) * C + c);
+      float* t = &tile[ty + 16 * i][tx * 4];
+      t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int cl = ty + 16 * i, c = c0 + cl, p = p0 + tx * 4;
+    if (c < C && p < P)
+      *reinterpret_cast<float4*>(out + (b * C + c) * P + p) =
+          make_float4(tile[tx * 4][cl], tile[tx * 4 + 1][cl], tile[tx * 4 + 2][cl], tile[tx * 4 + 3][cl]);
+  }
 }
 
 // The 7x7 / stride 2 / pad 3 stem on 3 input channels (Resnet.py:112-113): K = 147 is no multiple of anything the
@@ -552,6 +580,12 @@ extern "C" int pl_deconv4x4s2_nhwc_fwd(const float* x, int64_t B, int64_t Hi, in
 extern "C" int pl_nhwc_to_nchw(const float* in, int64_t B, int64_t P, int64_t C, float* out, void* stream) {
   if (!in || !out || in == out) PL_FAIL(PL_EINVAL, "pl_nhwc_to_nchw: null or aliased pointers");
   if (B <= 0 || P <= 0 || C <= 0 || B > 65535) PL_FAIL(PL_ESHAPE, "pl_nhwc_to_nchw: bad shape");
+  if ((P & 3) == 0 && (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+    dim3 grid((unsigned)((P + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B);
+    hipLaunchKernelGGL(nhwc_to_nchw_vec_kernel, grid, dim3(NTHR), 0, (hipStream_t)stream, in, (int)P, (int)C, out);
+    PL_CHECK_LAUNCH("nhwc_to_nchw_vec");
+    return PL_OK;
+  }
   dim3 grid((unsigned)((P + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(1024), 0, (hipStream_t)stream, in, (int)P, (int)C, out);
   PL_CHECK_LAUNCH("nhwc_to_nchw");

@@ -1043,7 +1043,9 @@ extern "C" int pl_l1_terms_fwd_bwd(const PLL1Term* terms, int nterms, float grad
 // =====================================================================================
 // rows per statistics group: 64 (the GEMM epilogue's unit) up to 16 K rows, then 256 -- a 131072-row map would
 // otherwise hand the finalize kernel 2048 partials per column (38 us per layer)
-static int bn_group_rows(int64_t rows) { return rows > 16384 ? 256 : 64; }
+// (1024 for maps so large that 256-row groups would leave > 1024 partials per column: the statistics kernel merges
+//  its 64-row sub-groups itself, so longer groups only cost workgroup count)
+static int bn_group_rows(int64_t rows) { return rows > 262144 ? 1024 : (rows > 16384 ? 256 : 64); }
 static int bn_groups(int64_t rows) { const int gs = bn_group_rows(rows); return (int)((rows + gs - 1) / gs); }
 // replicas of a narrow map: [rows][C] is worked on as [rows/R][R*C] (bn_colstats_kernel)
 static int bn_replicas(int64_t rows, int64_t C) {

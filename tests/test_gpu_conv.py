@@ -106,8 +106,11 @@ def test_deconv4x4s2_vs_torch(pkg, B, Hi, Cin, Cout, bn):
     assert bool((err <= bound).all()), float((err / bound).max())
 
 
-def test_nhwc_to_nchw(pkg):
-    x = torch.randn(3, 5, 7, 37)
+@pytest.mark.parametrize("shape", [(3, 5, 7, 37),          # scalar 32x32 tiles, ragged everywhere
+                                   (2, 8, 12, 68),          # 16-byte path, ragged 64x64 tiles (P = 96, C = 68)
+                                   (2, 16, 16, 192)])       # 16-byte path, whole tiles
+def test_nhwc_to_nchw(pkg, shape):
+    x = torch.randn(*shape)
     assert torch.equal(pkg.conv.nhwc_to_nchw(x.to(DEV)).cpu(), x.permute(0, 3, 1, 2).contiguous())
 
 
