@@ -49,6 +49,9 @@ def _ref(x_nhwc, w_oihw, stride, pad, scale, shift, bias, relu, resid):
     (2, 16, 64, 64, 3, 1, 1, True, 1, False, False),       # layer1 conv2, 64 -> 64: im2col fallback
     (2, 16, 256, 64, 1, 1, 0, True, 1, False, False),      # layer1 conv1 1x1, Cout = 64: edge GEMM
     (3, 10, 32, 40, 3, 2, 1, False, 2, True, True),        # nothing aligned
+    (4, 8, 512, 512, 3, 1, 1, True, 2, True, False),       # layer4 conv2: 8 output tiles -> split over K; the reduce
+    (4, 8, 512, 512, 3, 1, 1, False, 1, False, True),      #   kernel applies BN / ReLU / residual / bias
+    (4, 8, 2048, 512, 1, 1, 0, True, 1, False, False),     # layer4 conv1 (1x1 = plain GEMM), split over K
 ])
 def test_conv2d_nhwc_vs_torch(pkg, B, H, Cin, Cout, k, stride, pad, bn, relu, res, bias):
     g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cin + Cout + k + stride)
@@ -218,7 +221,10 @@ def test_model3d_any_batch_size(pkg, B):
     (2, 16, 512, 128, 1, 1, 0),      # 1x1
     (2, 16, 64, 128, 3, 1, 1),       # Cin = 64, 576 columns: not whole tiles -> im2col fallback
     (2, 16, 64, 64, 3, 1, 1),        # layer1 conv2
-    (2, 32, 3, 64, 7, 2, 3),         # the stem (dgrad not needed: x is the image)
+    (2, 32, 3, 64, 7, 2, 3),         # the stem (dgrad not needed: x is the image): stem7x7_c3_wgrad_kernel
+    (3, 38, 3, 64, 7, 2, 3),         # the stem on an odd map (Wo = 19: the last pixel pair is half empty)
+    (2, 64, 256, 1088, 1, 1, 0),     # the head's final 1x1: ragged Cout tiles, uneven K slices
+    (4, 8, 512, 512, 3, 1, 1),       # layer4 conv2: dgrad split over K
 ])
 def test_conv2d_backward_vs_torch_autograd(pkg, B, H, Cin, Cout, k, stride, pad):
     """dgrad and wgrad of the NHWC convolution against torch autograd on the CPU (fp64)."""
