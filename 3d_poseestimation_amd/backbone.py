@@ -174,20 +174,23 @@ class _HeatmapNet(nn.Module):
         """The same in the reference's layout [B, J*depth, 64, 64] (Model.py:91)."""
         return conv.nhwc_to_nchw(self.heatmap_logits_nhwc(x_nhwc))
 
-    def _heatmap_logits_train(self, x_nhwc):
-        """Training mode, differentiable: [B, H, W, 3] -> [B, J*depth, H/4, W/4] (NCHW for the soft-argmax)."""
+    def _heatmap_logits_train(self, x_nhwc, nhwc=False):
+        """Training mode, differentiable: [B, H, W, 3] -> [B, J*depth, H/4, W/4] (NCHW for the soft-argmax), or the
+        NHWC logits as the final convolution writes them (nhwc=True: the depth-64 head reads them in place)."""
         out = self.preact(x_nhwc)
         for i in (0, 3, 6):
             out = conv.batchnorm_relu_train(conv.deconv4x4s2_nhwc_autograd(out, self.deconv_layers[i].weight),
                                             self.deconv_layers[i + 1], True)
         out = conv.conv2d_bias_nhwc_autograd(out, conv.to_ohwi(self.final_layer.weight.float()), self.final_layer.bias)
-        return conv.nhwc_to_nchw_autograd(out)
+        return out if nhwc else conv.nhwc_to_nchw_autograd(out)
 
 
     def predict_nhwc(self, x_nhwc):
         """Coordinates from NHWC frames, in whichever mode the module is in (phase5's cycle step feeds BOTH networks
         the same frames; their reference forwards disagree about the input layout, this entry point does not)."""
         if self.training:
+            if self.depth_dim == 64:
+                return soft_argmax_3d_nhwc(self._heatmap_logits_train(x_nhwc, nhwc=True), self.num_joints)
             logits = self._heatmap_logits_train(x_nhwc)
             return (soft_argmax_3d(logits, self.num_joints, self.depth_dim) if self.depth_dim > 1
                     else soft_argmax_2d(logits, self.num_joints))
@@ -206,7 +209,7 @@ class Model_3D(_HeatmapNet):
     def forward(self, x):
         """x [B, 256, 256, 3] NHWC frames -> [B, 51] (x, y, z) per joint in (-1, 1)  (Model.py:83-137)."""
         if self.training:
-            return soft_argmax_3d(self._heatmap_logits_train(x), self.num_joints, self.depth_dim)
+            return soft_argmax_3d_nhwc(self._heatmap_logits_train(x, nhwc=True), self.num_joints)
         with torch.no_grad():
             return soft_argmax_3d_nhwc(self.heatmap_logits_nhwc(x), self.num_joints)
 

@@ -176,6 +176,36 @@ __global__ __launch_bounds__(NTHR) void softargmax_bwd_kernel(const float* __res
   }
 }
 
+// backward on the NHWC layout: one float4 = four consecutive depths of one (pixel, joint); pure streaming
+// (4 B read + 4 B written per voxel, every access a whole 16-byte vector of a contiguous row)
+__global__ __launch_bounds__(NTHR) void softargmax_nhwc_bwd_kernel(const float* __restrict__ logits,
+                                                                   const float* __restrict__ stats,
+                                                                   const float* __restrict__ gcoords, int J, int H,
+                                                                   int W, int64_t n4, float* __restrict__ dlogits) {
+  const int64_t t = (int64_t)blockIdx.x * NTHR + threadIdx.x;
+  if (t >= n4) return;
+  const int c4 = J * 16;                           // float4s per pixel
+  const int q = (int)(t % c4);
+  const int64_t bp = t / c4;
+  const int P = H * W;
+  const int p = (int)(bp % P);
+  const int64_t b = bp / P;
+  const int j = q >> 4, d0 = (q & 15) * 4;
+  const float* st = stats + ((size_t)b * J + j) * 5;
+  const float* g = gcoords + ((size_t)b * J + j) * 3;
+  const float m = st[0], inv = 1.0f / st[1];
+  const float gx = g[0] * 2.f / (float)W, gy = g[1] * 2.f / (float)H, gz = g[2] * 2.f / 64.f;
+  const float base = gx * ((float)(p % W) - st[2]) + gy * ((float)(p / W) - st[3]);
+  const float z0 = (float)d0 - st[4];
+  const float4 v = reinterpret_cast<const float4*>(logits)[t];
+  float4 o;
+  o.x = __expf(v.x - m) * inv * fmaf(gz, z0, base);
+  o.y = __expf(v.y - m) * inv * fmaf(gz, z0 + 1.f, base);
+  o.z = __expf(v.z - m) * inv * fmaf(gz, z0 + 2.f, base);
+  o.w = __expf(v.w - m) * inv * fmaf(gz, z0 + 3.f, base);
+  reinterpret_cast<float4*>(dlogits)[t] = o;
+}
+
 int check_dims(int64_t BJ, int64_t D, int64_t H, int64_t W, int ncoord, const char* who) {
   if (BJ <= 0 || D <= 0 || H <= 0 || W <= 0 || (W & 3) || D * H * W > (int64_t)1 << 30 || BJ > 65535 * 64)
     PL_FAIL(PL_ESHAPE, "%s: bad dims BJ=%lld D=%lld H=%lld W=%lld (W %% 4 == 0)", who, (long long)BJ, (long long)D,
@@ -227,5 +257,20 @@ extern "C" int pl_softargmax3d_nhwc_fwd(const float* logits, int64_t B, int64_t 
   hipLaunchKernelGGL(softargmax_nhwc_fwd_kernel, dim3((unsigned)(B * J)), dim3(NTHR), 0, (hipStream_t)stream, logits,
                      (int)J, (int)H, (int)W, coords, stats);
   PL_CHECK_LAUNCH("softargmax_nhwc_fwd");
+  return PL_OK;
+}
+
+extern "C" int pl_softargmax3d_nhwc_bwd(const float* logits, const float* stats, const float* gcoords, int64_t B,
+                                        int64_t J, int64_t H, int64_t W, float* dlogits, void* stream) {
+  if (!logits || !stats || !gcoords || !dlogits) PL_FAIL(PL_EINVAL, "pl_softargmax3d_nhwc_bwd: null pointer");
+  if ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15)
+    PL_FAIL(PL_EINVAL, "pl_softargmax3d_nhwc_bwd: tensors not 16-byte aligned");
+  if (B <= 0 || J <= 0 || H <= 0 || W <= 0 || B * J > 0x7fffffff || H * W > (1 << 24))
+    PL_FAIL(PL_ESHAPE, "pl_softargmax3d_nhwc_bwd: bad dims");
+  const int64_t n4 = B * H * W * J * 16;
+  if (n4 > (int64_t)INT32_MAX * NTHR) PL_FAIL(PL_ESHAPE, "pl_softargmax3d_nhwc_bwd: too large");
+  hipLaunchKernelGGL(softargmax_nhwc_bwd_kernel, dim3((unsigned)((n4 + NTHR - 1) / NTHR)), dim3(NTHR), 0,
+                     (hipStream_t)stream, logits, stats, gcoords, (int)J, (int)H, (int)W, n4, dlogits);
+  PL_CHECK_LAUNCH("softargmax_nhwc_bwd");
   return PL_OK;
 }

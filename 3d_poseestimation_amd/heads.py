@@ -55,19 +55,39 @@ def soft_argmax_2d(out, num_joints=17):
     return _SoftArgmaxFn.apply(x, B * num_joints, 1, H, W, 2, 0).reshape(B, num_joints * 2)
 
 
-@torch.no_grad()
+class _SoftArgmax3dNHWCFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, num_joints):
+        B, H, W, _ = x.shape
+        coords = torch.empty(B * num_joints, 3, dtype=torch.float32, device=x.device)
+        stats = torch.empty(B * num_joints, 5, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().pl_softargmax3d_nhwc_fwd(x.data_ptr(), B, num_joints, H, W, coords.data_ptr(),
+                                                     stats.data_ptr(), _lib.current_stream_ptr())
+        _lib.check(rc, "pl_softargmax3d_nhwc_fwd")
+        ctx.save_for_backward(x, stats)
+        ctx.num_joints = num_joints
+        return coords
+
+    @staticmethod
+    def backward(ctx, g):
+        x, stats = ctx.saved_tensors
+        B, H, W, _ = x.shape
+        g = g.contiguous()
+        dl = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().pl_softargmax3d_nhwc_bwd(x.data_ptr(), stats.data_ptr(), g.data_ptr(), B, ctx.num_joints,
+                                                     H, W, dl.data_ptr(), _lib.current_stream_ptr())
+        _lib.check(rc, "pl_softargmax3d_nhwc_bwd")
+        return dl, None
+
+
 def soft_argmax_3d_nhwc(out, num_joints=17):
-    """(B, H, W, num_joints*64) NHWC logits (depth_dim 64) -> (B, num_joints*3); inference only (no backward
-    on this layout yet): what Model_3D's final 1x1 convolution writes, read in place."""
+    """(B, H, W, num_joints*64) NHWC logits (depth_dim 64) -> (B, num_joints*3), differentiable: what Model_3D's
+    final 1x1 convolution writes, read in place -- no NHWC <-> NCHW pass in either direction."""
     x = out.contiguous()
     _lib.require_device_tensor(x, "heat-map logits")
     B, H, W, C = x.shape
     if C != num_joints * 64:
         raise ValueError(f"expected {num_joints * 64} channels (depth 64), got {C}")
-    coords = torch.empty(B * num_joints, 3, dtype=torch.float32, device=x.device)
-    stats = torch.empty(B * num_joints, 5, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
-        rc = _lib.lib().pl_softargmax3d_nhwc_fwd(x.data_ptr(), B, num_joints, H, W, coords.data_ptr(), stats.data_ptr(),
-                                                 _lib.current_stream_ptr())
-    _lib.check(rc, "pl_softargmax3d_nhwc_fwd")
-    return coords.reshape(B, num_joints * 3)
+    return _SoftArgmax3dNHWCFn.apply(x, num_joints).reshape(B, num_joints * 3)

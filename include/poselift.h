@@ -159,6 +159,11 @@ int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const float* target
  * coords [B*J][3] and stats [B*J][5] as pl_softargmax_fwd(ncoord 3, centred 1).  Model.py:94-133. */
 int pl_softargmax3d_nhwc_fwd(const float* logits, int64_t B, int64_t J, int64_t H, int64_t W,
                              float* coords, float* stats, void* stream);
+/* Backward of pl_softargmax3d_nhwc_fwd: dlogits [B][H*W][J*64] from the saved logits, the forward's stats [B*J][5]
+ * and the coordinate gradients gcoords [B*J][3]; one streaming pass (4 B read + 4 B written per voxel), so a
+ * training step needs no NHWC <-> NCHW pass around the head (phase4_joined/Model.py:94-133 under autograd). */
+int pl_softargmax3d_nhwc_bwd(const float* logits, const float* stats, const float* gcoords, int64_t B, int64_t J,
+                             int64_t H, int64_t W, float* dlogits, void* stream);
 
 /* ---- convolution path (first slice: forward) ------------------------ */
 /* nn.Conv2d forward in NHWC with the Bottleneck's eval-mode epilogue folded in: phase4_joined/Resnet.py:51-95

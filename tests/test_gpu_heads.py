@@ -93,3 +93,29 @@ def test_soft_argmax_3d_nhwc_matches_the_nchw_kernel_and_oracle(pkg):
     got = pkg.soft_argmax_3d_nhwc(x.permute(0, 2, 3, 1).contiguous().to(DEV)).cpu().numpy()
     ref = pkg.soft_argmax_3d(x.to(DEV)).cpu().numpy()
     assert np.abs(got - want).max() < 2e-5 and np.abs(got - ref).max() < 2e-5
+
+
+def test_soft_argmax_3d_nhwc_backward_vs_torch_autograd(pkg):
+    """dlogits of the NHWC head against torch autograd (fp64) of the stated softmax + expectation, and against the
+    NCHW kernel's backward on the same logits."""
+    torch.manual_seed(6)
+    B, J, D, H, W = 2, 17, 64, 12, 8
+    x = torch.randn(B, J * D, H, W) * 2
+    g = torch.randn(B, J * 3)
+    xr = x.double().requires_grad_(True)
+    hm = torch.softmax(xr.reshape(B, J, -1), 2).reshape(B, J, D, H, W)
+    cx = (hm.sum((2, 3)) * torch.arange(W, dtype=torch.float64)).sum(2, keepdim=True)
+    cy = (hm.sum((2, 4)) * torch.arange(H, dtype=torch.float64)).sum(2, keepdim=True)
+    cz = (hm.sum((3, 4)) * torch.arange(D, dtype=torch.float64)).sum(2, keepdim=True)
+    pred = torch.cat(((cx / W - .5) * 2, (cy / H - .5) * 2, (cz / D - .5) * 2), 2).reshape(B, J * 3)
+    (pred * g.double()).sum().backward()
+    xn = x.permute(0, 2, 3, 1).contiguous().to(DEV).requires_grad_(True)
+    out = pkg.soft_argmax_3d_nhwc(xn)
+    assert float((out.detach().cpu().double() - pred.detach()).abs().max()) < 2e-5
+    (out * g.to(DEV)).sum().backward()
+    want = xr.grad.permute(0, 2, 3, 1)
+    scale = float(want.abs().max())
+    assert float((xn.grad.cpu().double() - want).abs().max()) < 2e-5 * scale
+    xc = x.to(DEV).requires_grad_(True)
+    (pkg.soft_argmax_3d(xc) * g.to(DEV)).sum().backward()
+    assert float((xn.grad.permute(0, 3, 1, 2) - xc.grad).abs().max()) < 2e-6 * scale
