@@ -93,6 +93,8 @@ SIGNATURES = {
     "pl_mask_by_bits": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P]),
     "pl_maxpool3x3s2_nhwc": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P]),
     "pl_maxpool3x3s2_nhwc_bwd": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P]),
+    "pl_maxpool3x3s2_nhwc_idx": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _P]),
+    "pl_maxpool3x3s2_nhwc_bwd_idx": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P]),
     "pl_upsample2x_zero_nhwc": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P]),
     "pl_colsum_scratch_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64]),
     "pl_colsum": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _P]),

@@ -303,21 +303,33 @@ def add_relu(a, b):
 
 
 class _MaxPoolFn(torch.autograd.Function):
+    """Forward records the winning tap per output element (one byte); backward reads those and dy only."""
+
     @staticmethod
     def forward(ctx, x):
-        ctx.save_for_backward(x)
-        return maxpool3x3s2_nhwc(x)
+        _lib.require_device_tensor(x, "x")
+        B, H, W, C = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty(B, Ho, Wo, C, dtype=torch.float32, device=x.device)
+        idx = torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().pl_maxpool3x3s2_nhwc_idx(x.data_ptr(), B, H, W, C, y.data_ptr(), idx.data_ptr(),
+                                                     _lib.current_stream_ptr())
+        _lib.check(rc, "pl_maxpool3x3s2_nhwc_idx")
+        ctx.save_for_backward(idx)
+        ctx.in_shape = tuple(x.shape)
+        return y
 
     @staticmethod
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
+        (idx,) = ctx.saved_tensors
         dy = dy.contiguous()
-        B, H, W, C = x.shape
-        dx = torch.empty_like(x)
-        with torch.cuda.device(x.device):
-            rc = _lib.lib().pl_maxpool3x3s2_nhwc_bwd(x.data_ptr(), dy.data_ptr(), B, H, W, C, dx.data_ptr(),
-                                                     _lib.current_stream_ptr())
-        _lib.check(rc, "pl_maxpool3x3s2_nhwc_bwd")
+        B, H, W, C = ctx.in_shape
+        dx = torch.empty(B, H, W, C, dtype=torch.float32, device=dy.device)
+        with torch.cuda.device(dy.device):
+            rc = _lib.lib().pl_maxpool3x3s2_nhwc_bwd_idx(idx.data_ptr(), dy.data_ptr(), B, H, W, C, dx.data_ptr(),
+                                                         _lib.current_stream_ptr())
+        _lib.check(rc, "pl_maxpool3x3s2_nhwc_bwd_idx")
         return dx
 
 

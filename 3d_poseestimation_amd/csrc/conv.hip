@@ -118,6 +118,71 @@ __global__ __launch_bounds__(NTHR) void maxpool3x3s2_nhwc_bwd_kernel(const float
   *reinterpret_cast<float4*>(dx + t * 4) = make_float4(g[0], g[1], g[2], g[3]);
 }
 
+// Training-mode pair: the forward also records WHICH tap (kh*3 + kw, first maximum in that order = torch's tie
+// rule) produced every output element, one byte each; the backward then needs neither x nor the nine-tap
+// recomputation: an input pixel looks at the <= 4 windows that contain it and takes dy where the recorded tap is
+// its own (2.9 -> 0.5 ms for the stem's map at B = 256: 1 GB of dx written, 0.34 GB of dy + indices read).
+__global__ __launch_bounds__(NTHR) void maxpool3x3s2_nhwc_idx_kernel(const float* __restrict__ x, int H, int W, int C,
+                                                                     int Ho, int Wo, int64_t n4, float* __restrict__ y,
+                                                                     uchar4* __restrict__ idx) {
+  const int64_t t = (int64_t)blockIdx.x * NTHR + threadIdx.x;
+  if (t >= n4) return;
+  const int c4 = C >> 2;
+  const int c = (int)(t % c4) * 4;
+  int64_t r = t / c4;
+  const int ow = (int)(r % Wo); r /= Wo;
+  const int oh = (int)(r % Ho);
+  const int64_t b = r / Ho;
+  float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  unsigned char k[4] = {0, 0, 0, 0};
+  bool any = false;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int ih = oh * 2 - 1 + kh, iw = ow * 2 - 1 + kw;
+      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+        const float4 v = *reinterpret_cast<const float4*>(x + ((b * H + ih) * W + iw) * C + c);
+        const float vs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (!any || vs[j] > m[j]) { m[j] = vs[j]; k[j] = (unsigned char)(kh * 3 + kw); }
+        any = true;
+      }
+    }
+  *reinterpret_cast<float4*>(y + t * 4) = make_float4(m[0], m[1], m[2], m[3]);
+  idx[t] = make_uchar4(k[0], k[1], k[2], k[3]);
+}
+
+__global__ __launch_bounds__(NTHR) void maxpool3x3s2_nhwc_bwd_idx_kernel(const uchar4* __restrict__ idx,
+                                                                         const float* __restrict__ dy, int H, int W,
+                                                                         int C, int Ho, int Wo, int64_t n4,
+                                                                         float* __restrict__ dx) {
+  const int64_t t = (int64_t)blockIdx.x * NTHR + threadIdx.x;
+  if (t >= n4) return;
+  const int c4 = C >> 2;
+  const int cq = (int)(t % c4);
+  int64_t r = t / c4;
+  const int iw = (int)(r % W); r /= W;
+  const int ih = (int)(r % H);
+  const int64_t b = r / H;
+  float g[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int oh = max(0, ih / 2); oh <= min(Ho - 1, (ih + 1) / 2); ++oh)
+    for (int ow = max(0, iw / 2); ow <= min(Wo - 1, (iw + 1) / 2); ++ow) {
+      const int kh0 = ih - (oh * 2 - 1), kw0 = iw - (ow * 2 - 1);            // this pixel's tap in that window
+      if (kh0 < 0 || kh0 > 2 || kw0 < 0 || kw0 > 2) continue;
+      const int64_t o = ((b * Ho + oh) * Wo + ow) * c4 + cq;
+      const uchar4 k = idx[o];
+      const float4 gv = *reinterpret_cast<const float4*>(dy + o * 4);
+      const unsigned char mine = (unsigned char)(kh0 * 3 + kw0);
+      if (k.x == mine) g[0] += gv.x;
+      if (k.y == mine) g[1] += gv.y;
+      if (k.z == mine) g[2] += gv.z;
+      if (k.w == mine) g[3] += gv.w;
+    }
+  *reinterpret_cast<float4*>(dx + t * 4) = make_float4(g[0], g[1], g[2], g[3]);
+}
+
 // part[chunk][c] = sum over the chunk's rows of X[r][c]; grid = (ceil(cols/256), chunks), rows interleaved by 4*chunks
 __global__ __launch_bounds__(NTHR) void colsum_wide_kernel(const float* __restrict__ X, int rows, int cols,
                                                            float* __restrict__ part) {
@@ -736,5 +801,35 @@ extern "C" int pl_upsample2x_zero_nhwc(const float* x, int64_t B, int64_t Hi, in
   hipLaunchKernelGGL(upsample2x_zero_kernel, dim3((unsigned)((n4 + NTHR - 1) / NTHR)), dim3(NTHR), 0,
                      (hipStream_t)stream, x, (int)Hi, (int)Wi, (int)C, n4, y);
   PL_CHECK_LAUNCH("upsample2x_zero");
+  return PL_OK;
+}
+
+extern "C" int pl_maxpool3x3s2_nhwc_idx(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y,
+                                        unsigned char* idx, void* stream) {
+  if (!x || !y || !idx) PL_FAIL(PL_EINVAL, "pl_maxpool3x3s2_nhwc_idx: null pointer");
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) PL_FAIL(PL_ESHAPE, "pl_maxpool3x3s2_nhwc_idx: C %% 4 == 0 needed");
+  if (reinterpret_cast<uintptr_t>(idx) & 3) PL_FAIL(PL_EINVAL, "pl_maxpool3x3s2_nhwc_idx: idx not 4-byte aligned");
+  const int64_t Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int64_t n4 = B * Ho * Wo * (C >> 2);
+  if (n4 > (int64_t)INT32_MAX * NTHR) PL_FAIL(PL_ESHAPE, "pl_maxpool3x3s2_nhwc_idx: too large");
+  hipLaunchKernelGGL(maxpool3x3s2_nhwc_idx_kernel, dim3((unsigned)((n4 + NTHR - 1) / NTHR)), dim3(NTHR), 0,
+                     (hipStream_t)stream, x, (int)H, (int)W, (int)C, (int)Ho, (int)Wo, n4, y,
+                     reinterpret_cast<uchar4*>(idx));
+  PL_CHECK_LAUNCH("maxpool3x3s2_nhwc_idx");
+  return PL_OK;
+}
+
+extern "C" int pl_maxpool3x3s2_nhwc_bwd_idx(const unsigned char* idx, const float* dy, int64_t B, int64_t H, int64_t W,
+                                            int64_t C, float* dx, void* stream) {
+  if (!idx || !dy || !dx) PL_FAIL(PL_EINVAL, "pl_maxpool3x3s2_nhwc_bwd_idx: null pointer");
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) PL_FAIL(PL_ESHAPE, "pl_maxpool3x3s2_nhwc_bwd_idx: C %% 4 == 0 needed");
+  if (reinterpret_cast<uintptr_t>(idx) & 3) PL_FAIL(PL_EINVAL, "pl_maxpool3x3s2_nhwc_bwd_idx: idx not 4-byte aligned");
+  const int64_t Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int64_t n4 = B * H * W * (C >> 2);
+  if (n4 > (int64_t)INT32_MAX * NTHR) PL_FAIL(PL_ESHAPE, "pl_maxpool3x3s2_nhwc_bwd_idx: too large");
+  hipLaunchKernelGGL(maxpool3x3s2_nhwc_bwd_idx_kernel, dim3((unsigned)((n4 + NTHR - 1) / NTHR)), dim3(NTHR), 0,
+                     (hipStream_t)stream, reinterpret_cast<const uchar4*>(idx), dy, (int)H, (int)W, (int)C, (int)Ho,
+                     (int)Wo, n4, dx);
+  PL_CHECK_LAUNCH("maxpool3x3s2_nhwc_bwd_idx");
   return PL_OK;
 }

@@ -223,6 +223,12 @@ int pl_maxpool3x3s2_nhwc(const float* x, int64_t B, int64_t H, int64_t W, int64_
  * maximum in (kh, kw) order, recomputed from x (no index tensor, no atomics). */
 int pl_maxpool3x3s2_nhwc_bwd(const float* x, const float* dy, int64_t B, int64_t H, int64_t W, int64_t C,
                              float* dx, void* stream);
+/* The training-mode pair (what autograd's MaxPool2d keeps is an index tensor too): the forward also writes, one
+ * byte per output element, the tap kh*3 + kw of the first maximum; the backward reads those bytes and dy only. */
+int pl_maxpool3x3s2_nhwc_idx(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y,
+                             unsigned char* idx, void* stream);
+int pl_maxpool3x3s2_nhwc_bwd_idx(const unsigned char* idx, const float* dy, int64_t B, int64_t H, int64_t W,
+                                 int64_t C, float* dx, void* stream);
 /* y [B][2Hi][2Wi][C]: x on the even pixels, zero elsewhere -- the input gradient of a 1x1 stride-2 convolution
  * (the downsample branches, Resnet.py:151-158) is dy W (a GEMM) placed this way. */
 int pl_upsample2x_zero_nhwc(const float* x, int64_t B, int64_t Hi, int64_t Wi, int64_t C, float* y, void* stream);

@@ -318,17 +318,30 @@ def test_bottleneck_train_step_from_the_building_blocks_vs_torch(pkg):
         assert close(getattr(b, n).running_var, getattr(ref, n).running_var, 1e-5), n
 
 
-def test_maxpool_backward_vs_torch(pkg):
-    x = torch.randn(2, 12, 10, 8)
+@pytest.mark.parametrize("shape", [(2, 12, 10, 8), (1, 11, 9, 4)])
+def test_maxpool_backward_vs_torch(pkg, shape):
+    """Both backward entry points (from the recorded tap index = the autograd path, and recomputed from x) against
+    torch, bit for bit, ties included."""
+    torch.manual_seed(sum(shape))
+    x = torch.randn(*shape)
     x[0, 2:4, 2:4] = 1.5                                       # ties inside windows: first maximum wins, as in torch
     xr = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
     y = F.max_pool2d(xr, 3, 2, 1)
     dy = torch.randn(y.shape)
     y.backward(dy)
+    want = xr.grad.permute(0, 2, 3, 1)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
     xd = x.to(DEV).requires_grad_(True)
     yd = pkg.conv.maxpool3x3s2_nhwc_autograd(xd)
-    yd.backward(dy.permute(0, 2, 3, 1).contiguous().to(DEV))
-    assert torch.equal(xd.grad.cpu(), xr.grad.permute(0, 2, 3, 1))
+    assert torch.equal(yd.detach().cpu(), y.detach().permute(0, 2, 3, 1))
+    yd.backward(dyd)
+    assert torch.equal(xd.grad.cpu(), want)
+    B, H, W, C = shape
+    dx = torch.empty(B, H, W, C, device=DEV)
+    L = pkg.lib()
+    rc = L.pl_maxpool3x3s2_nhwc_bwd(xd.data_ptr(), dyd.data_ptr(), B, H, W, C, dx.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(dx.cpu(), want)
 
 
 def test_model3d_train_step_vs_torch_autograd(pkg):
