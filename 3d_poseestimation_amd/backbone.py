@@ -10,7 +10,7 @@ nn.ConvTranspose2d in the reference's construction order, so `state_dict()` has 
 shapes (a reference checkpoint loads with load_state_dict) -- pinned by tests/golden/g9: the reference's
 ResNet("resnet50") imported and run as-is.  The arithmetic is conv.py's: every convolution with its
 BatchNorm (running statistics), ReLU and residual add folded into one launch.  In TRAINING mode the same
-containers run a first, unfused cut of the path (conv.py's differentiable pieces: implicit-GEMM convolution
+containers run the differentiable form of the path (conv.py's differentiable pieces: implicit-GEMM convolution
 with dgrad / wgrad on the library, BatchNorm2d on batch statistics with its backward, max-pool, transposed
 convolution and residual join with theirs): correct against torch autograd, not yet tuned -- the next slice of
 row N2 fuses the statistics into the GEMM epilogue and the BatchNorm backward into dgrad's producer.

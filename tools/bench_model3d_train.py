@@ -47,7 +47,7 @@ def main():
         opt_e.step()
 
     t = timed(step_ours, a.iters)
-    print(f"B={a.B} this library (unfused first cut, fp32-grade) : {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
+    print(f"B={a.B} this library (fp32-grade arithmetic)        : {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
     t = timed(step_eager, a.iters)
     print(f"B={a.B} PyTorch-ROCm eager fp32                      : {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
 
