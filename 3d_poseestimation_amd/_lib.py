@@ -84,7 +84,7 @@ SIGNATURES = {
     "pl_conv2d_nhwc_wgrad_scratch_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64,
                                                         _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "pl_conv2d_nhwc_wgrad": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int,
-                                        _c.c_int, _c.c_int, _c.c_int, _P, _P, _c.c_size_t, _P]),
+                                        _c.c_int, _c.c_int, _c.c_int, _P, _c.c_int, _P, _c.c_size_t, _P]),
     "pl_bn_train_scratch_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64]),
     "pl_bn_train_fwd": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _c.c_float, _c.c_float, _P, _P, _P, _c.c_int,
                                    _P, _P, _P, _P, _P, _P]),

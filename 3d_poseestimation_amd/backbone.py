@@ -89,17 +89,20 @@ class ResNet(nn.Module):
         def w(m):
             return conv.to_ohwi(m.weight.float())
         bnr = conv.batchnorm_relu_train
-        x = bnr(conv.conv2d_nhwc_autograd(x.float(), w(self.conv1), 2, 3), self.bn1, True)
+        ar = self.compute_dtype
+
+        def cv(inp, m, stride, padding):
+            return conv.conv2d_nhwc_autograd(inp, w(m), stride, padding, ar)
+        x = bnr(cv(x.float(), self.conv1, 2, 3), self.bn1, True)
         x = conv.maxpool3x3s2_nhwc_autograd(x)
         for li in (1, 2, 3, 4):
             for blk in getattr(self, f"layer{li}"):
                 identity = x
                 if blk.downsample is not None:
-                    identity = bnr(conv.conv2d_nhwc_autograd(x, w(blk.downsample[0]), blk.stride, 0),
-                                   blk.downsample[1], False)
-                out = bnr(conv.conv2d_nhwc_autograd(x, w(blk.conv1), 1, 0), blk.bn1, True)
-                out = bnr(conv.conv2d_nhwc_autograd(out, w(blk.conv2), blk.stride, 1), blk.bn2, True)
-                out = bnr(conv.conv2d_nhwc_autograd(out, w(blk.conv3), 1, 0), blk.bn3, False)
+                    identity = bnr(cv(x, blk.downsample[0], blk.stride, 0), blk.downsample[1], False)
+                out = bnr(cv(x, blk.conv1, 1, 0), blk.bn1, True)
+                out = bnr(cv(out, blk.conv2, blk.stride, 1), blk.bn2, True)
+                out = bnr(cv(out, blk.conv3, 1, 0), blk.bn3, False)
                 x = conv.add_relu(out, identity)
         return x
 
@@ -179,9 +182,11 @@ class _HeatmapNet(nn.Module):
         NHWC logits as the final convolution writes them (nhwc=True: the depth-64 head reads them in place)."""
         out = self.preact(x_nhwc)
         for i in (0, 3, 6):
-            out = conv.batchnorm_relu_train(conv.deconv4x4s2_nhwc_autograd(out, self.deconv_layers[i].weight),
-                                            self.deconv_layers[i + 1], True)
-        out = conv.conv2d_bias_nhwc_autograd(out, conv.to_ohwi(self.final_layer.weight.float()), self.final_layer.bias)
+            out = conv.batchnorm_relu_train(
+                conv.deconv4x4s2_nhwc_autograd(out, self.deconv_layers[i].weight, self.compute_dtype),
+                self.deconv_layers[i + 1], True)
+        out = conv.conv2d_bias_nhwc_autograd(out, conv.to_ohwi(self.final_layer.weight.float()), self.final_layer.bias,
+                                             arith=self.compute_dtype)
         return out if nhwc else conv.nhwc_to_nchw_autograd(out)
 
 

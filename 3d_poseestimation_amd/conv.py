@@ -84,7 +84,7 @@ def conv2d_nhwc(x, w_ohwi, stride=1, padding=0, scale=None, shift=None, bias=Non
     return y
 
 
-def conv2d_nhwc_wgrad(x, dy, kernel_size, stride=1, padding=0):
+def conv2d_nhwc_wgrad(x, dy, kernel_size, stride=1, padding=0, arith="bf16x6"):
     """Weight gradient of conv2d_nhwc: x [B,H,W,Cin], dy [B,Ho,Wo,Cout] -> dw [Cout,KH,KW,Cin] (OHWI)."""
     x, dy = x.contiguous(), dy.contiguous()
     _lib.require_device_tensor(x, "x")
@@ -101,13 +101,13 @@ def conv2d_nhwc_wgrad(x, dy, kernel_size, stride=1, padding=0):
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     with torch.cuda.device(x.device):
         rc = L.pl_conv2d_nhwc_wgrad(x.data_ptr(), B, H, W, Cin, dy.data_ptr(), Cout, KH, KW, stride, padding,
-                                    dw.data_ptr(), scratch.data_ptr() if nbytes else None, nbytes,
+                                    dw.data_ptr(), ARITH[arith], scratch.data_ptr() if nbytes else None, nbytes,
                                     _lib.current_stream_ptr())
     _lib.check(rc, "pl_conv2d_nhwc_wgrad")
     return dw
 
 
-def conv2d_nhwc_dgrad(dy, w_ohwi, in_hw, stride=1, padding=0):
+def conv2d_nhwc_dgrad(dy, w_ohwi, in_hw, stride=1, padding=0, arith="bf16x6"):
     """Input gradient of conv2d_nhwc: dy [B,Ho,Wo,Cout], w [Cout,KH,KW,Cin] -> dx [B,H,W,Cin].  No kernel of its
     own: stride 1 is the forward convolution of dy with the flipped filter, channels swapped; stride 2 (3x3 pad 1
     and 1x1 pad 0, the backbone's two cases, even H and W) is the transposed convolution
@@ -116,14 +116,14 @@ def conv2d_nhwc_dgrad(dy, w_ohwi, in_hw, stride=1, padding=0):
     H, W = in_hw
     if stride == 1:
         wf = w_ohwi.flip(1, 2).permute(3, 1, 2, 0).contiguous()            # [Cin][KH][KW][Cout]
-        dx = conv2d_nhwc(dy, wf, 1, KH - 1 - padding)
+        dx = conv2d_nhwc(dy, wf, 1, KH - 1 - padding, arith=arith)
         if dx.shape[1:3] != (H, W):
             raise ValueError("conv2d_nhwc_dgrad: input size does not match")
         return dx
     if stride == 2 and H % 2 == 0 and W % 2 == 0 and KH == 1 and KW == 1 and padding == 0:
         # dy W on the even pixels: one GEMM ([M][Cout] x [Cout][Cin], the OHWI filter read as [Cin][1][1][Cout]^T)
         B, Ho, Wo, _ = dy.shape
-        t = conv2d_nhwc(dy, w_ohwi.reshape(Cout, Cin).t().contiguous().reshape(Cin, 1, 1, Cout), 1, 0)
+        t = conv2d_nhwc(dy, w_ohwi.reshape(Cout, Cin).t().contiguous().reshape(Cin, 1, 1, Cout), 1, 0, arith=arith)
         dx = torch.empty(B, H, W, Cin, dtype=torch.float32, device=dy.device)
         with torch.cuda.device(dy.device):
             rc = _lib.lib().pl_upsample2x_zero_nhwc(t.data_ptr(), B, Ho, Wo, Cin, dx.data_ptr(), _lib.current_stream_ptr())
@@ -134,7 +134,7 @@ def conv2d_nhwc_dgrad(dy, w_ohwi, in_hw, stride=1, padding=0):
         w4 = torch.zeros(Cout, Cin, 4, 4, dtype=torch.float32, device=w_ohwi.device)
         o = 1 - padding
         w4[:, :, o:o + KH, o:o + KW] = w_ohwi.permute(0, 3, 1, 2)
-        return deconv4x4s2_nhwc(dy, deconv_subkernels(w4))
+        return deconv4x4s2_nhwc(dy, deconv_subkernels(w4), arith=arith)
     raise NotImplementedError(f"conv2d_nhwc_dgrad: stride {stride}, kernel {KH}, padding {padding}, input {H}x{W}")
 
 
@@ -192,24 +192,25 @@ class _Conv2dFn(torch.autograd.Function):
     """conv2d_nhwc with autograd: dgrad and wgrad run on the library too (conv2d_nhwc_dgrad / _wgrad)."""
 
     @staticmethod
-    def forward(ctx, x, w_ohwi, stride, padding):
+    def forward(ctx, x, w_ohwi, stride, padding, arith):
         ctx.save_for_backward(x, w_ohwi)
-        ctx.geom = (stride, padding)
-        return conv2d_nhwc(x, w_ohwi, stride, padding)
+        ctx.geom = (stride, padding, arith)
+        return conv2d_nhwc(x, w_ohwi, stride, padding, arith=arith)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        stride, padding = ctx.geom
+        stride, padding, arith = ctx.geom
         dy = dy.contiguous()
-        dx = conv2d_nhwc_dgrad(dy, w, x.shape[1:3], stride, padding) if ctx.needs_input_grad[0] else None
-        dw = conv2d_nhwc_wgrad(x, dy, w.shape[1], stride, padding) if ctx.needs_input_grad[1] else None
-        return dx, dw, None, None
+        dx = conv2d_nhwc_dgrad(dy, w, x.shape[1:3], stride, padding, arith) if ctx.needs_input_grad[0] else None
+        dw = conv2d_nhwc_wgrad(x, dy, w.shape[1], stride, padding, arith) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None, None
 
 
-def conv2d_nhwc_autograd(x, w_ohwi, stride=1, padding=0):
-    """Differentiable conv2d_nhwc (no folded epilogue: in training mode BatchNorm needs batch statistics)."""
-    return _Conv2dFn.apply(x, w_ohwi, stride, padding)
+def conv2d_nhwc_autograd(x, w_ohwi, stride=1, padding=0, arith="bf16x6"):
+    """Differentiable conv2d_nhwc (no folded epilogue: in training mode BatchNorm needs batch statistics).
+    arith "bf16": forward, dgrad and wgrad round their operands to bf16 while staging (fp32 accumulate/storage)."""
+    return _Conv2dFn.apply(x, w_ohwi, stride, padding, arith)
 
 
 class _BNReLUFn(torch.autograd.Function):
@@ -343,40 +344,41 @@ class _DeconvFn(torch.autograd.Function):
     forward convolution kernel, stride 2) and dW = wgrad of C with input dy and output gradient x."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, arith):
         ctx.save_for_backward(x, weight)
-        return deconv4x4s2_nhwc(x, deconv_subkernels(weight.detach().float()))
+        ctx.arith = arith
+        return deconv4x4s2_nhwc(x, deconv_subkernels(weight.detach().float()), arith=arith)
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         dx = dw = None
-        if ctx.needs_input_grad[0]:
-            dx = conv2d_nhwc(dy, weight.detach().permute(0, 2, 3, 1).contiguous(), 2, 1)   # [Cin][4][4][Cout] as OHWI
-        if ctx.needs_input_grad[1]:
-            dw = conv2d_nhwc_wgrad(dy, x, 4, 2, 1).permute(0, 3, 1, 2).contiguous()        # [Cin][4][4][Cout] -> [Cin][Cout][4][4]
-        return dx, dw
+        if ctx.needs_input_grad[0]:       # [Cin][4][4][Cout] as OHWI
+            dx = conv2d_nhwc(dy, weight.detach().permute(0, 2, 3, 1).contiguous(), 2, 1, arith=ctx.arith)
+        if ctx.needs_input_grad[1]:       # [Cin][4][4][Cout] -> [Cin][Cout][4][4]
+            dw = conv2d_nhwc_wgrad(dy, x, 4, 2, 1, ctx.arith).permute(0, 3, 1, 2).contiguous()
+        return dx, dw, None
 
 
-def deconv4x4s2_nhwc_autograd(x, weight_iohw):
-    return _DeconvFn.apply(x.contiguous(), weight_iohw)
+def deconv4x4s2_nhwc_autograd(x, weight_iohw, arith="bf16x6"):
+    return _DeconvFn.apply(x.contiguous(), weight_iohw, arith)
 
 
 class _ConvBiasFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w_ohwi, bias, stride, padding):
+    def forward(ctx, x, w_ohwi, bias, stride, padding, arith):
         ctx.save_for_backward(x, w_ohwi)
-        ctx.geom = (stride, padding)
-        return conv2d_nhwc(x, w_ohwi, stride, padding, bias=bias)
+        ctx.geom = (stride, padding, arith)
+        return conv2d_nhwc(x, w_ohwi, stride, padding, bias=bias, arith=arith)
 
     @staticmethod
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
-        stride, padding = ctx.geom
+        stride, padding, arith = ctx.geom
         dy = dy.contiguous()
-        dx = conv2d_nhwc_dgrad(dy, w, x.shape[1:3], stride, padding) if ctx.needs_input_grad[0] else None
-        dw = conv2d_nhwc_wgrad(x, dy, w.shape[1], stride, padding) if ctx.needs_input_grad[1] else None
+        dx = conv2d_nhwc_dgrad(dy, w, x.shape[1:3], stride, padding, arith) if ctx.needs_input_grad[0] else None
+        dw = conv2d_nhwc_wgrad(x, dy, w.shape[1], stride, padding, arith) if ctx.needs_input_grad[1] else None
         db = None
         if ctx.needs_input_grad[2]:
             C = dy.shape[-1]
@@ -387,11 +389,11 @@ class _ConvBiasFn(torch.autograd.Function):
             with torch.cuda.device(dy.device):
                 rc = L.pl_colsum(dy.data_ptr(), rows, C, db.data_ptr(), scratch.data_ptr(), _lib.current_stream_ptr())
             _lib.check(rc, "pl_colsum")
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
-def conv2d_bias_nhwc_autograd(x, w_ohwi, bias, stride=1, padding=0):
-    return _ConvBiasFn.apply(x, w_ohwi, bias, stride, padding)
+def conv2d_bias_nhwc_autograd(x, w_ohwi, bias, stride=1, padding=0, arith="bf16x6"):
+    return _ConvBiasFn.apply(x, w_ohwi, bias, stride, padding, arith)
 
 
 class _ToNCHWFn(torch.autograd.Function):

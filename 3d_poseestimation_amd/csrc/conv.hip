@@ -699,8 +699,9 @@ extern "C" size_t pl_conv2d_nhwc_wgrad_scratch_bytes(int64_t B, int64_t H, int64
 
 // dw [Cout][KH][KW][Cin] = sum_{b,oh,ow} dy[b][oh][ow][co] * x[b][oh*s - p + kh][ow*s - p + kw][ci]
 extern "C" int pl_conv2d_nhwc_wgrad(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* dy,
-                                    int64_t Cout, int KH, int KW, int stride, int pad, float* dw, void* scratch,
-                                    size_t scratch_bytes, void* stream) {
+                                    int64_t Cout, int KH, int KW, int stride, int pad, float* dw, int arith,
+                                    void* scratch, size_t scratch_bytes, void* stream) {
+  if (arith != PL_BF16X6 && arith != PL_BF16) PL_FAIL(PL_EDTYPE, "pl_conv2d_nhwc_wgrad: arith %d (PL_BF16X6 or PL_BF16)", arith);
   if (!x || !dy || !dw) PL_FAIL(PL_EINVAL, "pl_conv2d_nhwc_wgrad: null pointer");
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
     PL_FAIL(PL_ESHAPE, "pl_conv2d_nhwc_wgrad: bad geometry");
@@ -728,7 +729,7 @@ extern "C" int pl_conv2d_nhwc_wgrad(const float* x, int64_t B, int64_t H, int64_
   GemmArgs g = {};
   g.A = dy; g.C = splits > 1 ? slabs : dw;
   g.M = (int)Cout; g.N = (int)N; g.K = (int)K; g.lda = (int)Cout; g.ldb = (int)N; g.ldc = (int)N;
-  g.split_k = splits; g.arith = PL_BF16X6;
+  g.split_k = splits; g.arith = implicit ? arith : PL_BF16X6;   // the im2col fallback (odd shapes) stays fp32-grade
   if (implicit) {
     g.B = x;
     g.conv_cin = (int)Cin; g.conv_h = (int)H; g.conv_w = (int)W; g.conv_ho = (int)Ho; g.conv_wo = (int)Wo;

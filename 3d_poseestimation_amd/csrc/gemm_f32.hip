@@ -995,10 +995,10 @@ __global__ __launch_bounds__(256) void conv_x6_planes_kernel(GemmArgs p) {
   gemm_body_planes<false, false, 32, true, N_EDGE>(p, blockIdx.x, gridDim.x, lds);
 }
 
-template <bool MN_EDGE>
+template <bool MN_EDGE, int NPL = 3>      // NPL = 1: PL_BF16 (operands rounded to bf16 while staged, one product)
 __global__ __launch_bounds__(256) void conv_wgrad_x6_planes_kernel(GemmArgs p) {
   __shared__ __attribute__((aligned(16))) char lds[PCfg<32>::LDS];
-  gemm_body_planes<true, true, 32, false, MN_EDGE, true>(p, blockIdx.x, gridDim.x, lds);
+  gemm_body_planes<true, true, 32, false, MN_EDGE, true, NPL>(p, blockIdx.x, gridDim.x, lds);
 }
 
 // PL_BF16 on the planes pipeline (conv path throughput mode): the same bodies with NPL = 1
@@ -1192,8 +1192,11 @@ int launch_conv_wgrad(const GemmArgs& a, hipStream_t s) {
     PL_FAIL(PL_EINVAL, "conv wgrad: operands misaligned");
   ProfRec* prof = prof_begin(a, s);
   const dim3 grid(((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * splits);
-  if (a.M % BM || a.N % BN) hipLaunchKernelGGL(conv_wgrad_x6_planes_kernel<true>, grid, dim3(NTHR), 0, s, a);
-  else hipLaunchKernelGGL(conv_wgrad_x6_planes_kernel<false>, grid, dim3(NTHR), 0, s, a);
+  const bool edge = a.M % BM || a.N % BN, bf = a.arith == 1;
+  if (edge && bf) hipLaunchKernelGGL((conv_wgrad_x6_planes_kernel<true, 1>), grid, dim3(NTHR), 0, s, a);
+  else if (edge) hipLaunchKernelGGL((conv_wgrad_x6_planes_kernel<true, 3>), grid, dim3(NTHR), 0, s, a);
+  else if (bf) hipLaunchKernelGGL((conv_wgrad_x6_planes_kernel<false, 1>), grid, dim3(NTHR), 0, s, a);
+  else hipLaunchKernelGGL((conv_wgrad_x6_planes_kernel<false, 3>), grid, dim3(NTHR), 0, s, a);
   if (prof) (void)hipEventRecord(prof->e1, s);
   PL_CHECK_LAUNCH("conv_wgrad_x6_planes");
   return PL_OK;

@@ -188,13 +188,15 @@ int pl_conv2d_nhwc_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t 
 /* Weight gradient of the same convolution (autograd of nn.Conv2d, phase4_joined/train.py:80 loss.backward()):
  * dw [Cout][KH][KW][Cin] = sum_{b,oh,ow} dy[b][oh][ow][co] * x[b][oh*stride - pad + kh][ow*stride - pad + kw][ci],
  * the TN GEMM over pixels with x gathered on the fly, split over the pixels so that it fills the chip (fixed-order
- * slab combine, no float atomics).  Cout % 128 == 0, KH*KW*Cin % 128 == 0, Cin even, Wo % 8 == 0, B*Ho*Wo % 32 == 0
- * (PL_ESHAPE otherwise).  The input gradient needs no kernel of its own: stride 1 = pl_conv2d_nhwc_fwd on dy with
+ * slab combine, no float atomics).  Cout and Cin even, Wo % 8 == 0 and B*Ho*Wo % 32 == 0 take the gathered kernel
+ * (ragged tiles clamped and masked); other shapes an explicit im2col + the generic GEMM in scratch; the 7x7 / Cin = 3
+ * stem its own exact-fp32 kernel.  arith: PL_BF16X6 (fp32-grade) or PL_BF16 (operands rounded to bf16 while staged,
+ * fp32 accumulate and output).  The input gradient needs no kernel of its own: stride 1 = pl_conv2d_nhwc_fwd on dy with
  * the flipped, transposed filter; stride 2 = pl_deconv4x4s2_nhwc_fwd (conv.py conv2d_nhwc_dgrad). */
 size_t pl_conv2d_nhwc_wgrad_scratch_bytes(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout,
                                           int KH, int KW, int stride, int pad);
 int pl_conv2d_nhwc_wgrad(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* dy,
-                         int64_t Cout, int KH, int KW, int stride, int pad, float* dw, void* scratch,
+                         int64_t Cout, int KH, int KW, int stride, int pad, float* dw, int arith, void* scratch,
                          size_t scratch_bytes, void* stream);
 
 /* Training-mode BatchNorm (+ ReLU) over the rows of a [rows][C] fp32 matrix: nn.BatchNorm2d on an NHWC feature map

@@ -467,3 +467,37 @@ def test_bf16_arithmetic_mode_of_the_conv_path(pkg):
     assert float((fast - ref).abs().max()) < 2e-2                # coordinates in (-1, 1): 0.6 voxel of 64
     with pytest.raises(KeyError):
         pkg.conv.conv2d_nhwc(x.to(DEV), pkg.conv.to_ohwi(w).to(DEV), 1, 1, arith="fp16")
+
+
+def test_bf16_arithmetic_mode_trains(pkg):
+    """compute_dtype="bf16" in TRAINING mode: forward, dgrad and wgrad of every convolution round their operands to
+    bf16 while staging (fp32 accumulate and storage; the stem and BatchNorm stay fp32).  A single weight gradient is
+    really bf16 and only bf16; the model's loss and gradients stay close to the fp32-grade mode's."""
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(2, 16, 16, 128, generator=g)
+    dy = torch.randn(2, 16, 16, 256, generator=g)
+    ref = pkg.conv.conv2d_nhwc_wgrad(x.to(DEV), dy.to(DEV), 3, 1, 1)
+    fast = pkg.conv.conv2d_nhwc_wgrad(x.to(DEV), dy.to(DEV), 3, 1, 1, arith="bf16")
+    rel = float((fast - ref).abs().max() / ref.abs().max())
+    assert 1e-5 < rel < 2e-2, rel
+    torch.manual_seed(3)
+    m = pkg.Model_3D().train()
+    m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 61))
+    with torch.no_grad():
+        m.final_layer.weight.mul_(1e-3)
+    m = m.to(DEV)
+    frames = pkg.synth.seeded_frames(4, 62, size=64).to(DEV)
+    target = torch.randn(4, 51, device=DEV)
+
+    def grads(mode):
+        m.compute_dtype = m.preact.compute_dtype = mode
+        m.zero_grad(set_to_none=True)
+        loss = ((m(frames) - target) ** 2).mean()
+        loss.backward()
+        return float(loss), torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
+    l0, g0 = grads("bf16x6")
+    l1, g1 = grads("bf16")
+    assert abs(l1 - l0) < 2e-2 * abs(l0)
+    cos = float(torch.dot(g0, g1) / (g0.norm() * g1.norm()))
+    assert cos > 0.98, cos                                     # same descent direction; not bit-close by design
+    assert float((g0 - g1).norm()) > 0                          # and really a different arithmetic

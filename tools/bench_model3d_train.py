@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """phase4 train step (BASELINE configs[3] shape: 256x256 frames; phase4_joined/train.py:69-89: forward, MSE, backward,
-Adam lr 1e-3) -- this library's first, unfused cut of the conv path beside PyTorch-ROCm eager of the same stock modules.
+Adam lr 1e-3) -- this library's conv path (fp32-grade and bf16 arithmetic) beside PyTorch-ROCm eager of the same stock
+modules (fp32 and bf16 autocast).
     python tools/bench_model3d_train.py [--B 32] [--iters 5]"""
 import argparse, copy, importlib, os, sys, time, torch
 import torch.nn.functional as F
@@ -46,10 +47,22 @@ def main():
         F.mse_loss(torch_forward(eager, xn), target).backward()
         opt_e.step()
 
+    def step_eager_bf16():
+        opt_e.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = torch_forward(eager, xn)
+        F.mse_loss(pred.float(), target).backward()
+        opt_e.step()
+
     t = timed(step_ours, a.iters)
     print(f"B={a.B} this library (fp32-grade arithmetic)        : {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
+    ours.compute_dtype = ours.preact.compute_dtype = "bf16"
+    t = timed(step_ours, a.iters)
+    print(f"B={a.B} this library (bf16 arithmetic, fp32 storage) : {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
     t = timed(step_eager, a.iters)
     print(f"B={a.B} PyTorch-ROCm eager fp32                      : {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
+    t = timed(step_eager_bf16, a.iters)
+    print(f"B={a.B} PyTorch-ROCm eager bf16 autocast             : {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
 
 
 if __name__ == "__main__":
