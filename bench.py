@@ -38,6 +38,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the pool's host driver only supports dmabuf IPC; RCCL across processes fails without this (set before torch loads)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 FLOP_PER_POSE = 25_618_432          # 2 x 12,809,216 MAC, GEMMs only, fwd+bwd
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
