@@ -1,10 +1,11 @@
-"""Convolution-path forward ops on the HIP library (first slice), NHWC throughout.
+"""Convolution-path ops on the HIP library, NHWC throughout: forward ops and their autograd forms.
 
     conv2d_nhwc          nn.Conv2d forward with the Bottleneck's eval-mode epilogue folded in
                          (/root/reference/phase4_joined/Resnet.py:51-95, :112-118, :151-158; Model.py:66-69)
     maxpool3x3s2_nhwc    nn.MaxPool2d(3, 2, 1)                               (Resnet.py:119)
     deconv4x4s2_nhwc     nn.ConvTranspose2d(4, 2, 1, bias=False) + BN + ReLU (Model.py:47-63)
-    nhwc_to_nchw         layout change in front of the soft-argmax
+    nhwc_to_nchw         layout change for heads that want NCHW (Model_2D)
+    *_autograd, batchnorm_relu_train, add_relu   the differentiable forms used in training mode
     to_ohwi / deconv_subkernels / fold_bn   weight-layout helpers (host side, once per model)
 
 The phase4 model permutes its NHWC input to NCHW for cuDNN/MIOpen (Model.py:88); here activations stay NHWC

@@ -1,14 +1,20 @@
-// Convolution-path forward pieces of the phase4 model (first slice), NHWC throughout.
+// Convolution path of the phase4 / phase5 models, NHWC throughout: forward, input- and
+// weight-gradient pieces.  The GEMM bodies are gemm_f32.hip's planes pipeline; this file holds the geometry, the
+// split-K policy and the non-GEMM kernels.
 //
-//   pl_conv2d_nhwc_fwd       nn.Conv2d (+ folded eval BatchNorm2d, ReLU, residual): implicit GEMM on the
-//                            PL_BF16X6 planes pipeline where the shape allows whole tiles (gemm_f32.hip),
-//                            else explicit im2col into caller scratch + the generic GEMM (7x7 stem with
-//                            Cin = 3, the 64-wide layer1 convolutions)
-//   pl_maxpool3x3s2_nhwc     nn.MaxPool2d(3, 2, 1)                     phase4_joined/Resnet.py:119
+//   pl_conv2d_nhwc_fwd       nn.Conv2d (+ folded eval BatchNorm2d, ReLU, residual, bias): a 1x1 is the plain GEMM, a
+//                            KxK with Cin % 32 == 0 the same GEMM with a gathering A loader (ragged tiles clamped
+//                            and masked); few-tile problems are split over K (slabs + reduce_slabs_epi_kernel);
+//                            the 7x7 Cin = 3 stem is a direct fp32 kernel; anything else: im2col + generic GEMM
+//   pl_conv2d_nhwc_wgrad     dW = dy^T x_gathered over the pixels, split-K by a cost model; the stem has its own
+//                            LDS-staged fp32-MFMA kernel.  (dgrad is composed from the forward kernels, conv.py)
+//   pl_maxpool3x3s2_nhwc*    nn.MaxPool2d(3, 2, 1), its backward from x, and the training pair with a tap index
+//                            phase4_joined/Resnet.py:119
 //   pl_deconv4x4s2_nhwc_fwd  nn.ConvTranspose2d(k=4, s=2, p=1, bias=False) (+ folded BN, ReLU)
-//                            phase4_joined/Model.py:47-69: four 2x2-tap convolutions, one per output parity,
-//                            each an implicit GEMM over the INPUT resolution, then one interleave pass
-//   pl_nhwc_to_nchw          the head's output for the soft-argmax, which wants [B][J*D][H][W]
+//                            phase4_joined/Model.py:47-69: four 2x2-tap convolutions, one per output parity, in one
+//                            grouped launch over the INPUT resolution, then one interleave pass
+//   pl_nhwc_to_nchw          layout pass for callers that want [B][J*D][H][W] (Model_2D's head)
+//   pl_colsum, pl_upsample2x_zero_nhwc   bias gradient; placement of a 1x1 stride-2 convolution's input gradient
 #include "pl_internal.h"
 
 namespace pl {
@@ -423,6 +429,8 @@ __global__ __launch_bounds__(NTHR, 2) void stem7x7_c3_wgrad_kernel(const float* 
   }
 }
 constexpr int STEM_WGRAD_WGS = 512;
+// the staged row pair (dy [Wo][64] + 7 padded input rows) must fit 64 KB of dynamic LDS: 424 Wo + 420 bytes
+constexpr int STEM_WGRAD_MAX_WO = 152;     // wider maps take the generic (im2col) path
 
 bool implicit_ok(int64_t M, int64_t Cin, int64_t Cout, int64_t K) {
   (void)Cout; (void)M;                   // any width, any pixel count: ragged last tiles are clamped and masked
@@ -689,7 +697,7 @@ extern "C" size_t pl_conv2d_nhwc_wgrad_scratch_bytes(int64_t B, int64_t H, int64
   const int64_t Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return 0;
   const int64_t K = B * Ho * Wo, N = (int64_t)KH * KW * Cin;
-  if (Cin == 3 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && Cout == 64 && Wo <= 256)
+  if (Cin == 3 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && Cout == 64 && Wo <= STEM_WGRAD_MAX_WO)
     return (size_t)STEM_WGRAD_WGS * 64 * 147 * sizeof(float);            // stem7x7_c3_wgrad_kernel partials
   const int s = wgrad_splits(Cout, N, K);
   size_t bytes = s > 1 ? (size_t)s * Cout * N * sizeof(float) : 0;
@@ -708,7 +716,7 @@ extern "C" int pl_conv2d_nhwc_wgrad(const float* x, int64_t B, int64_t H, int64_
   const int64_t Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   const int64_t K = B * Ho * Wo, N = (int64_t)KH * KW * Cin;
   if (Ho <= 0 || Wo <= 0 || K > INT32_MAX || N > INT32_MAX) PL_FAIL(PL_ESHAPE, "pl_conv2d_nhwc_wgrad: bad output size");
-  if (Cin == 3 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && Cout == 64 && Wo <= 256) {      // the stem
+  if (Cin == 3 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && Cout == 64 && Wo <= STEM_WGRAD_MAX_WO) {      // the stem
     const int nwg = STEM_WGRAD_WGS;
     const size_t need = (size_t)nwg * 64 * 147 * sizeof(float);
     if (!scratch || scratch_bytes < need) PL_FAIL(PL_EWORKSPACE, "pl_conv2d_nhwc_wgrad: needs %zu scratch bytes (got %zu)", need, scratch_bytes);
