@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""phase5 cycle step (/root/reference/phase5_loop/train_5 copy.py:147-236, Triangle on, Flip off)
+on 256x256 frames: this library's `cycle_step` (Model_2D + Model_3D + lifter x2 + projector + TriangleLoss, one
+backward, four optimizers) beside the same step written with stock PyTorch-ROCm modules (eager fp32).
+    python tools/bench_cycle.py [--B 32] [--iters 3]"""
+import argparse, copy, importlib, os, sys, time, torch
+import torch.nn.functional as F
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("3d_poseestimation_amd")
+from oracle.torch_twin import TwinLifter  # noqa: E402  (the stock-module lifter: comparison baseline only)
+
+
+def backbone(m, x):
+    r = m.preact
+    x = F.max_pool2d(F.relu(r.bn1(r.conv1(x))), 3, 2, 1)
+    for li in (1, 2, 3, 4):
+        for blk in getattr(r, f"layer{li}"):
+            idn = x if blk.downsample is None else blk.downsample(x)
+            o = F.relu(blk.bn1(blk.conv1(x)))
+            o = F.relu(blk.bn2(blk.conv2(o)))
+            x = F.relu(blk.bn3(blk.conv3(o)) + idn)
+    return m.final_layer(m.deconv_layers(x))
+
+
+def eager_3d(m, x):
+    out = backbone(m, x)
+    B = out.shape[0]
+    hm = torch.softmax(out.reshape(B, 17, -1), 2).reshape(B, 17, 64, 64, 64)
+    ar = torch.arange(64, device=out.device, dtype=torch.float32)
+    cx = (hm.sum((2, 3)) * ar).sum(2, keepdim=True); cy = (hm.sum((2, 4)) * ar).sum(2, keepdim=True)
+    cz = (hm.sum((3, 4)) * ar).sum(2, keepdim=True)
+    return torch.cat(((cx / 64 - .5) * 2, (cy / 64 - .5) * 2, (cz / 64 - .5) * 2), 2)
+
+
+def eager_2d(m, x):
+    out = backbone(m, x)
+    B = out.shape[0]
+    hm = torch.softmax(out.reshape(B, 17, -1), 2).reshape(B, 17, 64, 64)
+    ar = torch.arange(64, device=out.device, dtype=torch.float32)
+    cx = (hm.sum(2) * ar).sum(2, keepdim=True); cy = (hm.sum(3) * ar).sum(2, keepdim=True)
+    return torch.cat((cx / 64, cy / 64), 2)
+
+
+def centre(t):
+    return t - t[:, :1]
+
+
+def timed(step, iters):
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(iters):
+        step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=32); ap.add_argument("--iters", type=int, default=3)
+    a = ap.parse_args()
+    B, dev = a.B, "cuda"
+    torch.manual_seed(0)
+    m2, m3 = pkg.Model_2D().train(), pkg.Model_3D().train()
+    for m, seed in ((m2, 61), (m3, 62)):
+        m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), seed))
+        with torch.no_grad():
+            m.final_layer.weight.mul_(1e-3)
+    e2, e3 = copy.deepcopy(m2).to(dev), copy.deepcopy(m3).to(dev)
+    m2, m3 = m2.to(dev), m3.to(dev)
+    lift = pkg.LinearModel(34, 51, linear_size=1024, p_dropout=0.5).to(dev).train()
+    proj = pkg.LinearModel(51, 34, linear_size=64, p_dropout=0.5).to(dev).train()
+    opts = [torch.optim.Adam(m2.parameters(), lr=1e-4), torch.optim.Adam(m3.parameters(), lr=1e-4),
+            pkg.FlatAdamW(lift, lr=1e-4), pkg.FlatAdamW(proj, lr=1e-4)]
+    frames = pkg.synth.seeded_frames(B, 63).to(dev)
+    y1, y2 = pkg.synth.synthetic_batch(B, 64, dev)
+    crit = pkg.TriangleLoss(Project=True, era="lifter")
+
+    def ours():
+        pkg.cycle_step(m2, m3, lift, opts, frames, y1, y2, crit, model_proj=proj)
+
+    elift, eproj = TwinLifter(34, 51).to(dev).train(), TwinLifter(51, 34, linear_size=64).to(dev).train()
+    eopts = [torch.optim.Adam(e2.parameters(), lr=1e-4), torch.optim.Adam(e3.parameters(), lr=1e-4),
+             torch.optim.AdamW(elift.parameters(), lr=1e-4), torch.optim.AdamW(eproj.parameters(), lr=1e-4)]
+    xn = frames.permute(0, 3, 1, 2).contiguous()
+
+    def eager():
+        for o in eopts:
+            o.zero_grad()
+        p2, p3 = eager_2d(e2, xn), eager_3d(e3, xn)
+        lp, lg = elift(p2).reshape(B, 17, 3), elift(y1).reshape(B, 17, 3)
+        pp, pg = centre(eproj(p3).reshape(B, 17, 2)), centre(eproj(y2).reshape(B, 17, 2))
+        loss = (F.l1_loss(p2, y1) + F.l1_loss(p3, y2) + F.l1_loss(lg, y2) + F.l1_loss(lp, lg)
+                + F.l1_loss(pg, centre(y1)) + F.l1_loss(pp, pg))
+        loss.backward()
+        for o in eopts:
+            o.step()
+
+    t = timed(ours, a.iters)
+    print(f"B={B} cycle step, this library (fp32-grade) : {t * 1e3:8.1f} ms/step = {B / t:7.1f} frames/s")
+    t = timed(eager, a.iters)
+    print(f"B={B} cycle step, PyTorch-ROCm eager fp32   : {t * 1e3:8.1f} ms/step = {B / t:7.1f} frames/s")
+
+
+if __name__ == "__main__":
+    main()
