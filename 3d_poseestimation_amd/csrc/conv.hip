@@ -727,9 +727,15 @@ extern "C" int pl_conv2d_nhwc_wgrad(const float* x, int64_t B, int64_t H, int64_
     return launch_reduce_slabs(static_cast<const float*>(scratch), nwg, 64 * 147, dw, (hipStream_t)stream);
   }
   const bool implicit = wgrad_implicit_ok(Cin, Cout, N, K, Wo);
-  const int splits = wgrad_splits(Cout, N, K);
+  int splits = wgrad_splits(Cout, N, K);
+  // a 1x1 stride-1 convolution with whole tiles gathers nothing: dW = dy^T x is the plain TN GEMM (16-byte loads,
+  // no pixel decode) -- the lifter's dW kernel.  It wants equal K slices: the largest divisor of the K tiles <= splits.
+  const bool plain_tn = KH == 1 && KW == 1 && stride == 1 && pad == 0 && Cout % 128 == 0 && Cin % 128 == 0 &&
+                        K % 32 == 0 && arith == PL_BF16X6 && !getenv("POSELIFT_WGRAD_GATHER");
+  if (plain_tn)
+    while (splits > 1 && (K / 32) % splits) --splits;
   const size_t slab_bytes = splits > 1 ? (size_t)splits * Cout * N * sizeof(float) : 0;
-  const size_t need = slab_bytes + (implicit ? 0 : (size_t)K * N * sizeof(float));
+  const size_t need = slab_bytes + ((implicit || plain_tn) ? 0 : (size_t)K * N * sizeof(float));
   if (need && (!scratch || scratch_bytes < need))
     PL_FAIL(PL_EWORKSPACE, "pl_conv2d_nhwc_wgrad: needs %zu scratch bytes (got %zu)", need, scratch_bytes);
   hipStream_t s = (hipStream_t)stream;
@@ -738,7 +744,10 @@ extern "C" int pl_conv2d_nhwc_wgrad(const float* x, int64_t B, int64_t H, int64_
   g.A = dy; g.C = splits > 1 ? slabs : dw;
   g.M = (int)Cout; g.N = (int)N; g.K = (int)K; g.lda = (int)Cout; g.ldb = (int)N; g.ldc = (int)N;
   g.split_k = splits; g.arith = implicit ? arith : PL_BF16X6;   // the im2col fallback (odd shapes) stays fp32-grade
-  if (implicit) {
+  if (plain_tn) {
+    g.B = x;
+    PL_TRY(launch_gemm_f32(kTN, g, s));
+  } else if (implicit) {
     g.B = x;
     g.conv_cin = (int)Cin; g.conv_h = (int)H; g.conv_w = (int)W; g.conv_ho = (int)Ho; g.conv_wo = (int)Wo;
     g.conv_kw = KW; g.conv_stride = stride; g.conv_pad_h = pad; g.conv_pad_w = pad;
