@@ -14,4 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o b -- python3 $R/bench.py --steps 60 --warmup 10 --no-extras --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -o t -- python3 $R/tools/run_model3d_train.py 32 3 > $O/train.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_infer -o i -- python3 $R/tools/run_model3d.py 64 5 > $O/infer.log 2>&1
+cd $R
+python tools/bench_model3d_train.py --B 32 --iters 3 > $O/train_b32.txt 2>/dev/null
+python tools/bench_model3d_train.py --B 256 --iters 2 > $O/train_b256.txt 2>/dev/null
 echo final-profiles-done
