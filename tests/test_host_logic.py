@@ -29,6 +29,32 @@ def test_library_exports_every_declared_symbol(pkg):
     assert pkg.lib().pl_version() == 100
 
 
+def test_entry_points_reject_bad_arguments_before_touching_a_device(pkg):
+    """Argument validation of the conv-path / head entry points returns an error code and a message before any HIP
+    call -- checkable here without a GPU (null pointers, bad geometry, bad arithmetic codes), and the scratch-size
+    helpers are pure host functions."""
+    L = pkg.lib()
+    one = ctypes.c_void_p(16)            # a non-null, 16-byte aligned dummy: never dereferenced on these paths
+    assert L.pl_conv2d_nhwc_fwd(None, 1, 8, 8, 32, one, 64, 3, 3, 1, 1, None, None, None, 0, None, one, 2, None, 0, None) != 0
+    assert b"null" in L.pl_last_error()
+    assert L.pl_conv2d_nhwc_fwd(one, 1, 8, 8, 32, one, 64, 3, 3, 1, 1, None, None, None, 0, None, one, 9, None, 0, None) != 0
+    assert b"arith" in L.pl_last_error()
+    assert L.pl_conv2d_nhwc_wgrad(one, 1, 8, 8, 32, one, 64, 3, 3, 1, 1, one, 9, None, 0, None) != 0
+    assert b"arith" in L.pl_last_error()
+    assert L.pl_maxpool3x3s2_nhwc_idx(one, 1, 8, 8, 6, one, one, None) != 0          # C % 4
+    assert L.pl_maxpool3x3s2_nhwc_bwd_idx(None, one, 1, 8, 8, 8, one, None) != 0
+    assert L.pl_softargmax3d_nhwc_bwd(one, one, one, 0, 17, 64, 64, one, None) != 0  # B = 0
+    assert L.pl_softargmax3d_nhwc_bwd(one, one, one, 1, 17, 64, 64, ctypes.c_void_p(20), None) != 0
+    assert b"aligned" in L.pl_last_error()
+    assert L.pl_nhwc_to_nchw(one, 1, 16, 8, one, None) != 0                          # in == out
+    # scratch sizes: the stem's weight gradient needs its per-workgroup partials, a 1x1 nothing unless it is split
+    assert L.pl_conv2d_nhwc_wgrad_scratch_bytes(2, 64, 64, 3, 64, 7, 7, 2, 3) == 512 * 64 * 147 * 4
+    assert L.pl_conv2d_nhwc_scratch_bytes(64, 64, 64, 256, 1024, 1, 1, 1, 0) == 0       # 2048 x 8 tiles: no split
+    split = L.pl_conv2d_nhwc_scratch_bytes(4, 8, 8, 512, 512, 3, 3, 1, 1)              # layer4 conv2: 8 tiles
+    assert split > 0 and split % (256 * 512 * 4) == 0
+    assert L.pl_bn_train_scratch_bytes(0, 64) == 0 and L.pl_bn_train_scratch_bytes(4096, 64) > 0
+
+
 def test_python_layout_matches_c_layout(pkg):
     for (i, h, o, s) in [(34, 1024, 51, 2), (34, 64, 51, 2), (51, 64, 34, 2), (34, 32, 51, 3), (10, 4, 3, 0)]:
         d = pkg._lib.PLDesc(in_dim=i, hidden=h, out_dim=o, num_stage=s, bn=1, dtype=0, p_dropout=0.5,
