@@ -728,8 +728,8 @@ extern "C" int pl_conv2d_nhwc_wgrad(const float* x, int64_t B, int64_t H, int64_
   }
   const bool implicit = wgrad_implicit_ok(Cin, Cout, N, K, Wo);
   int splits = wgrad_splits(Cout, N, K);
-  // a 1x1 stride-1 convolution with whole tiles gathers nothing: dW = dy^T x is the plain TN GEMM (16-byte loads,
-  // no pixel decode) -- the lifter's dW kernel.  It wants equal K slices: the largest divisor of the K tiles <= splits.
+  // a 1x1 stride-1 convolution with whole tiles gathers nothing: dW = dy^T x is the plain TN GEMM (same thread
+  // mapping, but no pixel decode and no border selects in the staging path) -- the lifter's dW kernel.  It wants equal K slices: the largest divisor of the K tiles <= splits.
   const bool plain_tn = KH == 1 && KW == 1 && stride == 1 && pad == 0 && Cout % 128 == 0 && Cin % 128 == 0 &&
                         K % 32 == 0 && arith == PL_BF16X6 && !getenv("POSELIFT_WGRAD_GATHER");
   if (plain_tn)
