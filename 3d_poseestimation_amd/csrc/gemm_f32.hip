@@ -711,13 +711,24 @@ __device__ __forceinline__ void load_tile_wgrad(Stage& s, const GemmArgs& p, con
   const int ih = oh * p.conv_stride - p.conv_pad_h + c.kh;
   const bool rok = (unsigned)ih < (unsigned)p.conv_h;
   const float* row = p.B + ((size_t)b * p.conv_h + (rok ? ih : 0)) * p.conv_w * p.conv_cin + c.ci;
+  const int iw0 = ow0 * p.conv_stride - p.conv_pad_w + c.kw, iw7 = iw0 + 7 * p.conv_stride;
   float2 v[8];
+  // interior octets (the wave's eight pixels and its lanes' taps all inside the image -- most of them): no
+  // per-pixel compare / select pairs in the staging path, which competes with the operand split for VALU slots
+  const bool inside = rok && iw0 >= 0 && iw7 < p.conv_w;
+  if (__builtin_amdgcn_ballot_w64(!inside) == 0) {
+    const float* t = row + (size_t)iw0 * p.conv_cin;
+    const size_t step = (size_t)p.conv_stride * p.conv_cin;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int iw = (ow0 + j) * p.conv_stride - p.conv_pad_w + c.kw;
-    const bool ok = rok && (unsigned)iw < (unsigned)p.conv_w;
-    const float2 t = *reinterpret_cast<const float2*>(row + (size_t)(ok ? iw : 0) * p.conv_cin);
-    v[j] = ok ? t : make_float2(0.f, 0.f);
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float2*>(t + j * step);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int iw = iw0 + j * p.conv_stride;
+      const bool ok = rok && (unsigned)iw < (unsigned)p.conv_w;
+      const float2 t = *reinterpret_cast<const float2*>(row + (size_t)(ok ? iw : 0) * p.conv_cin);
+      v[j] = ok ? t : make_float2(0.f, 0.f);
+    }
   }
   s.v0 = make_float4(v[0].x, v[0].y, v[1].x, v[1].y);
   s.v1 = make_float4(v[2].x, v[2].y, v[3].x, v[3].y);
