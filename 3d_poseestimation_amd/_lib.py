@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # POSELIFT_LIB: another build of the same library (same-box A/B of two builds, tools/ab_env.py)
 LIB_PATH = os.environ.get("POSELIFT_LIB") or os.path.join(_HERE, "csrc", "libposelift.so")
 
-PL_F32, PL_BF16, PL_BF16X6 = 0, 1, 2
+PL_F32, PL_BF16, PL_BF16X6, PL_F16X3 = 0, 1, 2, 3
 
 
 # int gather(void* user, float* buf, int64_t floats_per_rank, void* stream)   (poselift.h: PLGatherFn)
@@ -112,6 +112,9 @@ SIGNATURES = {
                                _c.c_int, _P, _P]),
     "pl_gemm_arith": (_c.c_int, [_c.c_int, _c.c_int, _P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P,
                                  _c.c_int, _P, _P]),
+    "pl_gemm_planes_scratch_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64]),
+    "pl_gemm_planes": (_c.c_int, [_c.c_int, _c.c_int, _P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P,
+                                  _c.c_float, _c.c_float, _P, _P]),
     "pl_prof_enable": (_c.c_int, [_c.c_int]),
     "pl_prof_read": (_c.c_int, [_c.c_double, _c.c_double, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64),
                                 _c.POINTER(_c.c_double)]),

@@ -32,7 +32,7 @@ int check_desc(const PLDesc* d, bool need_arenas) {
   if (d->in_dim <= 0 || d->out_dim <= 0 || d->hidden <= 0 || d->num_stage < 0)
     PL_FAIL(PL_ESHAPE, "bad dims in=%d hidden=%d out=%d stages=%d", d->in_dim, d->hidden, d->out_dim, d->num_stage);
   if (d->hidden % 4 != 0) PL_FAIL(PL_ESHAPE, "hidden=%d must be a multiple of 4", d->hidden);
-  if (d->dtype != PL_F32 && d->dtype != PL_BF16 && d->dtype != PL_BF16X6)
+  if (d->dtype != PL_F32 && d->dtype != PL_BF16 && d->dtype != PL_BF16X6 && d->dtype != PL_F16X3)
     PL_FAIL(PL_EDTYPE, "dtype %d is not a PLDtype", d->dtype);
   if (!(d->p_dropout >= 0.f && d->p_dropout <= 1.f)) PL_FAIL(PL_EINVAL, "p_dropout=%f outside [0,1]", d->p_dropout);
   if (need_arenas) {
@@ -61,6 +61,16 @@ int sync_gather(const PLDesc* d, float* base, int64_t floats_per_rank, hipStream
   if (rc != 0) PL_FAIL(PL_ESYNC, "PLSync gather callback failed (%d)", rc);
   return PL_OK;
 }
+
+// PL_F16X3: the 1024-wide GEMMs run on fp16 operand planes written by the kernels that produce the tensors
+// (gemm_planes.hip).  That path wants whole 128x128 tiles, BatchNorm (its backward pass 1 supplies the range bound
+// of dz) and local statistics; anything else runs the same fp32-grade arithmetic class on the round-1 kernels
+// (PL_BF16X6: fp32 operands split inside the GEMM) -- never a lower precision, never the CPU.
+inline bool planes_path(const PLDesc* d, int64_t B) {
+  return d->dtype == PL_F16X3 && d->bn && sync_world(d) == 1 && d->hidden % 128 == 0 && B % 128 == 0 &&
+         d->num_stage >= 1 && B * (int64_t)d->hidden * 4 < (1ll << 30);
+}
+inline int arith_of(const PLDesc* d) { return d->dtype == PL_F16X3 ? (int)PL_BF16X6 : d->dtype; }
 
 struct ParamLayout {
   int L;                       // hidden layers
@@ -114,6 +124,11 @@ struct Ws {
   std::vector<size_t> z, act, bits, mean, rstd, dbpart;
   size_t stat, scale, shift, coef, ga, gb, dz, slabs, outpart, dyout, mse, total;
   size_t act_bytes, bits_bytes;
+  // PL_F16X3 planes path
+  bool planes;
+  std::vector<size_t> actp, wp;       // activation planes of layers 0..L-2, weight planes of layers 1..L-1
+  std::vector<char> act_f32;          // is the fp32 activation of layer l materialised?
+  size_t dzp, amax, dzscale;
 };
 
 Ws plan(const PLDesc* d, int64_t B) {
@@ -130,9 +145,14 @@ Ws plan(const PLDesc* d, int64_t B) {
   };
   w.act_bytes = (size_t)B * H * sizeof(float);
   w.bits_bytes = (size_t)B * bitmap_words_per_row(H) * sizeof(uint64_t);
+  w.planes = planes_path(d, B);
   for (int l = 0; l < w.L; ++l) {
+    // planes path: a layer's output is kept in fp32 only where something reads it as fp32 -- the skip connection
+    // (even layers) and the output Linear (last layer); the odd layers feed GEMMs only and exist as planes
+    const bool f32 = !w.planes || (l % 2 == 0) || l == w.L - 1;
+    w.act_f32.push_back(f32 ? 1 : 0);
     w.z.push_back(take(w.act_bytes));
-    w.act.push_back(take(w.act_bytes));
+    w.act.push_back(f32 ? take(w.act_bytes) : 0);
     w.bits.push_back(take(w.bits_bytes));
     w.mean.push_back(take((size_t)H * 4));
     w.rstd.push_back(take((size_t)H * 4));
@@ -165,6 +185,15 @@ Ws plan(const PLDesc* d, int64_t B) {
   w.outpart = take((size_t)colsum_chunks((int)B) * d->out_dim * 4);
   w.dyout = take((size_t)B * d->out_dim * 4);                 // d loss / d y of the fused train step
   w.mse = take(pl_mse_scratch_bytes(B * d->out_dim));
+  w.dzp = w.amax = w.dzscale = 0;
+  if (w.planes) {
+    for (int l = 0; l + 1 < w.L; ++l) w.actp.push_back(take(w.act_bytes));           // two fp16 planes = 4 B per element
+    w.wp.push_back(0);
+    for (int l = 1; l < w.L; ++l) w.wp.push_back(take((size_t)H * H * 4));
+    w.dzp = take(w.act_bytes);
+    w.amax = take((size_t)((H + 255) / 256) * w.RC * 2 * 4);
+    w.dzscale = take((size_t)w.L * 2 * 4);
+  }
   w.total = o;
   return w;
 }
@@ -203,6 +232,27 @@ int check_ws(const Ws& w, void* ws, size_t bytes) {
   if (reinterpret_cast<uintptr_t>(ws) & 255) PL_FAIL(PL_EWORKSPACE, "workspace not 256-byte aligned");
   if (bytes < w.total) PL_FAIL(PL_EWORKSPACE, "workspace too small: %zu < %zu bytes", bytes, w.total);
   return PL_OK;
+}
+
+inline unsigned short* u16(void* ws, size_t off) { return reinterpret_cast<unsigned short*>(static_cast<char*>(ws) + off); }
+
+// fp16 operand planes of every 1024-wide weight matrix (layers 1..L-1), from the fp32 parameter arena
+int split_weight_planes(const PLDesc* d, const ParamLayout& P, const Ws& w, void* ws, hipStream_t s) {
+  const int64_t n = (int64_t)d->hidden * d->hidden;
+  for (int l = 1; l < w.L; ++l) {
+    PlaneOut po = {u16(ws, w.wp[l]), u16(ws, w.wp[l]) + n, kWeightPlaneScale, nullptr, 2};
+    PL_TRY(launch_split_planes(d->params + P.off[4 * l], n, po, s));
+  }
+  return PL_OK;
+}
+
+PlanesGemmArgs planes_args(const unsigned short* A, int64_t a_plane, int lda, const unsigned short* Bm, int64_t b_plane,
+                           int ldb, float* C, int M, int N, int K, float out_scale, const float* dyn_inv) {
+  PlanesGemmArgs g = {};
+  g.A = A; g.B = Bm; g.a_plane = a_plane; g.b_plane = b_plane; g.lda = lda; g.ldb = ldb;
+  g.mode = 2; g.out_scale = out_scale; g.dyn_inv = dyn_inv;
+  g.e.C = C; g.e.M = M; g.e.N = N; g.e.K = K; g.e.ldc = N; g.e.split_k = 1;
+  return g;
 }
 
 int gemm_out_layer(const float* h, const float* W, const float* bias, float* y, int M, int N, int K,
@@ -276,7 +326,10 @@ extern "C" int pl_workspace_view(const PLDesc* d, int64_t B, int which, int64_t 
   const size_t hb = (size_t)d->hidden * 4;
   switch (which) {
     case 0: *off = w.z[layer]; *size = w.act_bytes; break;
-    case 1: *off = w.act[layer]; *size = w.act_bytes; break;
+    case 1:
+      if (!w.act_f32[layer])
+        PL_FAIL(PL_EINVAL, "pl_workspace_view: PL_F16X3 keeps the output of hidden layer %lld as fp16 planes only", (long long)layer);
+      *off = w.act[layer]; *size = w.act_bytes; break;
     case 2: *off = w.bits[layer]; *size = w.bits_bytes; break;
     case 3: *off = w.mean[layer]; *size = hb; break;
     case 4: *off = w.rstd[layer]; *size = hb; break;
@@ -304,18 +357,33 @@ extern "C" int pl_lifter_fwd_eval(const PLDesc* d, const float* x, float* y, int
                                f32(ws, w.scale) + (size_t)l * H, f32(ws, w.shift) + (size_t)l * H, s));
   }
   const float* a_in = x;
+  if (w.planes) PL_TRY(split_weight_planes(d, P, w, ws, s));
+  const int64_t BH = B * H;
   for (int l = 0; l < w.L; ++l) {
     const Layer ly = layer_of(d, P, nullptr, l);
+    // (planes path: the eval-mode output of an odd layer goes through its z buffer -- its fp32 activation is not kept)
+    float* out = w.act_f32[l] ? f32(ws, w.act[l]) : f32(ws, w.z[l]);
     GemmArgs g = {};
-    g.A = a_in; g.B = ly.W; g.C = f32(ws, w.act[l]);
+    g.A = a_in; g.B = ly.W; g.C = out;
     g.M = (int)B; g.N = H; g.K = ly.K; g.lda = ly.K; g.ldb = ly.K; g.ldc = H; g.split_k = 1;
-    g.arith = d->dtype;
+    g.arith = arith_of(d);
     g.col_scale = f32(ws, w.scale) + (size_t)l * H;
     g.col_shift = f32(ws, w.shift) + (size_t)l * H;
     g.relu = 1;
     if (l >= 2 && (l % 2) == 0) g.resid = f32(ws, w.act[l - 2]);
-    PL_TRY(launch_gemm_f32(kNT, g, s));
-    a_in = g.C;
+    if (w.planes && l > 0) {
+      PlanesGemmArgs pg = planes_args(u16(ws, w.actp[l - 1]), BH, H, u16(ws, w.wp[l]), (int64_t)H * H, H, out, (int)B, H, H,
+                                      1.0f / (kActPlaneScale * kWeightPlaneScale), nullptr);
+      pg.e.col_scale = g.col_scale; pg.e.col_shift = g.col_shift; pg.e.relu = 1; pg.e.resid = g.resid;
+      PL_TRY(launch_gemm_planes(kNT, pg, s));
+    } else {
+      PL_TRY(launch_gemm_f32(kNT, g, s));
+    }
+    if (w.planes && l + 1 < w.L) {
+      PlaneOut po = {u16(ws, w.actp[l]), u16(ws, w.actp[l]) + BH, kActPlaneScale, nullptr, 2};
+      PL_TRY(launch_split_planes(out, BH, po, s));
+    }
+    a_in = out;
   }
   return gemm_out_layer(a_in, d->params + P.off[4 * w.L], d->params + P.off[4 * w.L + 1], y, (int)B,
                         d->out_dim, H, f32(ws, w.slabs), s);
@@ -339,12 +407,14 @@ extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, in
   const int H = d->hidden;
   const size_t inj_stride = (size_t)B * bitmap_words_per_row(H);
   const float* a_in = x;
+  const int64_t BH = B * H;
+  if (w.planes) PL_TRY(split_weight_planes(d, P, w, ws, s));
   for (int l = 0; l < w.L; ++l) {
     const Layer ly = layer_of(d, P, nullptr, l);
     GemmArgs g = {};
     g.A = a_in; g.B = ly.W; g.C = f32(ws, w.z[l]); g.bias = ly.b;
     g.M = (int)B; g.N = H; g.K = ly.K; g.lda = ly.K; g.ldb = ly.K; g.ldc = H; g.split_k = 1;
-    g.arith = d->dtype;
+    g.arith = arith_of(d);
     const bool skinny = l == 0 && skinny_supported(ly.K, H);
     const int groups = skinny ? skinny_stat_groups((int)B) : w.G;
     float* stat = f32(ws, w.stat);
@@ -354,6 +424,11 @@ extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, in
     }
     if (skinny) {
       PL_TRY(launch_skinny_wide_out(a_in, ly.W, ly.b, g.C, (int)B, ly.K, H, false, g.stat_sum, g.stat_m2, s));
+    } else if (w.planes && l > 0) {
+      PlanesGemmArgs pg = planes_args(u16(ws, w.actp[l - 1]), BH, H, u16(ws, w.wp[l]), (int64_t)H * H, H, g.C, (int)B, H, H,
+                                      1.0f / (kActPlaneScale * kWeightPlaneScale), nullptr);
+      pg.e.bias = ly.b; pg.e.stat_sum = g.stat_sum; pg.e.stat_m2 = g.stat_m2;
+      PL_TRY(launch_gemm_planes(kNT, pg, s));
     } else {
       PL_TRY(launch_gemm_f32(kNT, g, s));
     }
@@ -368,10 +443,13 @@ extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, in
       scale = sc; shift = sh;
     }
     const float* resid = (l >= 2 && (l % 2) == 0) ? f32(ws, w.act[l - 2]) : nullptr;
-    PL_TRY(launch_bn_apply(g.C, scale, shift, resid, f32(ws, w.act[l]), u64(ws, w.bits[l]), (int)B, H,
+    PlaneOut po = {nullptr, nullptr, kActPlaneScale, nullptr, 0};
+    if (w.planes && l + 1 < w.L) { po.h = u16(ws, w.actp[l]); po.l = po.h + BH; po.kind = 2; }
+    float* act = w.act_f32[l] ? f32(ws, w.act[l]) : nullptr;
+    PL_TRY(launch_bn_apply(g.C, scale, shift, resid, act, u64(ws, w.bits[l]), (int)B, H,
                            d->p_dropout, seed, step, l,
-                           inject_keep ? inject_keep + (size_t)l * inj_stride : nullptr, s));
-    a_in = f32(ws, w.act[l]);
+                           inject_keep ? inject_keep + (size_t)l * inj_stride : nullptr, s, &po));
+    a_in = act;
   }
   return gemm_out_layer(a_in, d->params + P.off[4 * w.L], d->params + P.off[4 * w.L + 1], y, (int)B,
                         d->out_dim, H, f32(ws, w.slabs), s);
@@ -399,6 +477,8 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
   float* GA = f32(ws, w.ga);
   float* GB = f32(ws, w.gb);
   float* DZ = f32(ws, w.dz);
+  const int64_t BH = B * H;
+  const int n_amax = ((H + 255) / 256) * w.RC;
   // bias gradients = column sums of partials; all of them are reduced by ONE launch at the end
   std::vector<const float*> jpart; std::vector<float*> jout; std::vector<int> jR, jH;
 
@@ -431,25 +511,41 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
     const float* gin = (l % 2 == 1) ? GB : GA;
     const uint64_t* bits = u64(ws, w.bits[l]);
     const float* z = f32(ws, w.z[l]);
+    const bool pl_layer = w.planes && l > 0;       // this layer's dz feeds the planes GEMM pair
+    float* dzs = pl_layer ? f32(ws, w.dzscale) + 2 * l : nullptr;
     if (d->bn) {
       // (pass 1 was tried inside the producing GEMM's epilogue: +17 us per GEMM for the 7.5 us
       //  kernel it removed -- every tile finishes at once, so epilogue work is pure tail)
       float* stat = f32(ws, w.stat);
       float* mine = stat + (size_t)sync_rank(d) * 2 * w.RC * H;
       PL_TRY(launch_bn_bwd_reduce(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), kscale, Bi, H,
-                                  mine, mine + (size_t)w.RC * H, s));
+                                  mine, mine + (size_t)w.RC * H, s, 0, pl_layer ? f32(ws, w.amax) : nullptr));
       PL_TRY(sync_gather(d, stat, (int64_t)2 * w.RC * H, s));
       PL_TRY(launch_bn_bwd_finalize(stat, w.RC, sync_world(d), sync_rank(d), Bi, H, ly.gamma,
-                                    f32(ws, w.rstd[l]), f32(ws, w.coef), ly.ggamma, ly.gbeta, s));
+                                    f32(ws, w.rstd[l]), f32(ws, w.coef), ly.ggamma, ly.gbeta, s,
+                                    pl_layer ? f32(ws, w.amax) : nullptr, n_amax, dzs));
     } else {
       PL_TRY(launch_fill(ly.ggamma, H, 0.f, s));
       PL_TRY(launch_fill(ly.gbeta, H, 0.f, s));
     }
+    PlaneOut dzo = {nullptr, nullptr, 1.0f, dzs, 0};
+    if (pl_layer) { dzo.h = u16(ws, w.dzp); dzo.l = dzo.h + BH; dzo.kind = 2; }
     PL_TRY(launch_bn_bwd_dz(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), f32(ws, w.coef), kscale,
-                            d->bn, Bi, H, DZ, f32(ws, w.dbpart[l]), s));
+                            d->bn, Bi, H, pl_layer ? nullptr : DZ, f32(ws, w.dbpart[l]), s, 0, &dzo));
     jpart.push_back(f32(ws, w.dbpart[l])); jout.push_back(ly.gb); jR.push_back(w.RC); jH.push_back(H);
-    const float* a_in = l == 0 ? x : f32(ws, w.act[l - 1]);
-    if (l > 0) {
+    const float* a_in = l == 0 ? x : (w.planes ? nullptr : f32(ws, w.act[l - 1]));
+    if (pl_layer) {
+      // dX = dz W (NN) and dW = dz^T a (TN, split-K slabs) on the planes: one launch
+      const int splits = tn_splits(H, H, Bi);
+      PlanesGemmArgs nn = planes_args(u16(ws, w.dzp), BH, H, u16(ws, w.wp[l]), (int64_t)H * H, H,
+                                      (l % 2 == 1) ? GA : GB, Bi, H, H, 1.0f / kWeightPlaneScale, dzs + 1);
+      if (l % 2 == 1) nn.e.addend = GA;
+      PlanesGemmArgs tn = planes_args(u16(ws, w.dzp), BH, H, u16(ws, w.actp[l - 1]), BH, H,
+                                      splits > 1 ? slabs : ly.gW, H, H, Bi, 1.0f / kActPlaneScale, dzs + 1);
+      tn.e.split_k = splits;
+      PL_TRY(launch_gemm_planes_pair(nn, tn, s));
+      if (splits > 1) PL_TRY(launch_reduce_slabs(slabs, splits, (int64_t)H * H, ly.gW, s));
+    } else if (l > 0) {
       // da_in = dz W and dW = dz^T a_in share dz and are independent: ONE launch.  A residual
       // block's first Linear also receives the skip gradient (in GA, added in the epilogue).
       // (Tried: dW on a side stream so that the next layer's BatchNorm-backward kernels overlap it --
@@ -458,7 +554,7 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
       GemmArgs g = {};
       g.A = DZ; g.B = ly.W; g.M = Bi; g.N = H; g.K = H; g.lda = H; g.ldb = H; g.ldc = H; g.split_k = 1;
       if (l % 2 == 1) { g.C = GA; g.addend = GA; } else { g.C = GB; }
-      g.arith = d->dtype;
+      g.arith = arith_of(d);
       GemmArgs t = {};
       t.arith = g.arith;
       t.A = DZ; t.B = a_in; t.M = H; t.N = H; t.K = Bi; t.lda = H; t.ldb = H; t.ldc = H;
@@ -536,6 +632,37 @@ extern "C" int pl_gemm_arith(int layout, int arith, const float* A, const float*
     return launch_reduce_slabs(slabs, split_k, M * N, C, s);
   }
   return launch_gemm_f32((GemmLayout)layout, g, s);
+}
+
+// C = op(A) op(B) on 16-bit operand planes: the fp32 operands are split into planes in `scratch` first (the lifter's
+// own producers write planes directly), then the planes GEMM of gemm_planes.hip runs.  mode: PL_F16X3 or PL_BF16.
+extern "C" size_t pl_gemm_planes_scratch_bytes(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  return (size_t)(align_up(M * K * 4, 256) + align_up(N * K * 4, 256));
+}
+
+extern "C" int pl_gemm_planes(int layout, int mode, const float* A, const float* Bm, float* C, int64_t M, int64_t N,
+                              int64_t K, const float* bias, float scale_a, float scale_b, void* scratch, void* stream) {
+  if (layout < 0 || layout > 2) PL_FAIL(PL_EINVAL, "pl_gemm_planes: layout %d", layout);
+  if (mode != PL_F16X3 && mode != PL_BF16) PL_FAIL(PL_EDTYPE, "pl_gemm_planes: mode %d", mode);
+  if (!A || !Bm || !C || !scratch) PL_FAIL(PL_EINVAL, "pl_gemm_planes: null pointer");
+  if (M <= 0 || N <= 0 || K <= 0 || M * K >= (1ll << 29) || N * K >= (1ll << 29)) PL_FAIL(PL_ESHAPE, "pl_gemm_planes: bad shape");
+  if (!(scale_a > 0.f) || !(scale_b > 0.f)) PL_FAIL(PL_EINVAL, "pl_gemm_planes: scales must be positive powers of two");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned short* pa = static_cast<unsigned short*>(scratch);
+  unsigned short* pb = reinterpret_cast<unsigned short*>(static_cast<char*>(scratch) + align_up(M * K * 4, 256));
+  const int kind = mode == PL_F16X3 ? 2 : 1;
+  PlaneOut oa = {pa, pa + M * K, scale_a, nullptr, kind}, ob = {pb, pb + N * K, scale_b, nullptr, kind};
+  PL_TRY(launch_split_planes(A, M * K, oa, s));
+  PL_TRY(launch_split_planes(Bm, N * K, ob, s));
+  PlanesGemmArgs g = {};
+  g.A = pa; g.B = pb; g.a_plane = M * K; g.b_plane = N * K;
+  g.lda = layout == kTN ? (int)M : (int)K;
+  g.ldb = layout == kNT ? (int)K : (int)N;
+  g.mode = mode == PL_F16X3 ? 2 : 0;
+  g.out_scale = mode == PL_F16X3 ? 1.0f / (scale_a * scale_b) : 1.0f;
+  g.e.C = C; g.e.M = (int)M; g.e.N = (int)N; g.e.K = (int)K; g.e.ldc = (int)N; g.e.split_k = 1; g.e.bias = bias;
+  return launch_gemm_planes((GemmLayout)layout, g, s);
 }
 
 // ---------------------------------------------------------------------------------------

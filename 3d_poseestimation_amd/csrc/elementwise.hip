@@ -21,6 +21,43 @@ constexpr int NTHR = 256;
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// ---- GEMM operand planes written by the kernel that produces the tensor (pl_internal.h PlaneOut) ----------
+// Four consecutive elements per lane: one 8-byte store per plane (512 B per wave instruction).
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+struct PlaneDst { unsigned short* h; unsigned short* l; float scale; int kind; };
+
+__device__ __forceinline__ PlaneDst plane_dst(const PlaneOut& o) {
+  PlaneDst d = {o.h, o.l, o.scale, o.kind};
+  if (o.kind == 2 && o.dyn) d.scale = o.dyn[0];
+  return d;
+}
+
+__device__ __forceinline__ void store_planes4(const PlaneDst& d, size_t off, float4 v) {
+  if (d.kind == 2) {
+    const float a[4] = {v.x * d.scale, v.y * d.scale, v.z * d.scale, v.w * d.scale};
+    f16x4 hh, ll;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      hh[j] = (_Float16)a[j];
+      ll[j] = (_Float16)((a[j] - (float)hh[j]) * 2048.0f);
+    }
+    *reinterpret_cast<f16x4*>(d.h + off) = hh;
+    *reinterpret_cast<f16x4*>(d.l + off) = ll;
+  } else if (d.kind == 1) {
+    bf16x4 q;
+    q[0] = (__bf16)v.x; q[1] = (__bf16)v.y; q[2] = (__bf16)v.z; q[3] = (__bf16)v.w;
+    *reinterpret_cast<bf16x4*>(d.h + off) = q;
+  }
+}
+
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, int64_t n4, PlaneOut o) {
+  const PlaneDst d = plane_dst(o);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride)
+    store_planes4(d, (size_t)i * 4, ld4(x + 4 * i));
+}
+
 // -------------------------------------------------------------------------------------
 // Small fixed-order column reductions.  Shape of all three: block = 256 threads = 16 columns
 // x 16 row-parts, grid = ceil(H/16): every thread sums a strided 1/16 of the partial rows
@@ -233,7 +270,8 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(
     const float* __restrict__ z, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* resid, float* act, uint64_t* __restrict__ bits, int B, int H, int mode,
     uint32_t thr, float kscale, uint32_t k0, uint32_t k1, uint32_t c3, uint32_t layer,
-    const uint64_t* __restrict__ inject, int Hc) {
+    const uint64_t* __restrict__ inject, int Hc, PlaneOut po) {
+  const PlaneDst pd = plane_dst(po);
   // Hc: real columns behind the H virtual ones (bn_colstats_kernel); Hc == H for the lifter
   // mode: 0 keep all, 1 philox, 2 injected bitmap, 3 drop all; + 8: no ReLU (BatchNorm alone; bitmap all ones)
   const bool norelu = (mode & 8) != 0;
@@ -286,7 +324,8 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(
         const float4 rv = ld4(resid + off);
         out.x += rv.x; out.y += rv.y; out.z += rv.z; out.w += rv.w;
       }
-      st4(act + off, out);
+      if (act) st4(act + off, out);
+      if (pd.kind) store_planes4(pd, off, out);
     }
   }
 }
@@ -297,7 +336,7 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(
 __global__ __launch_bounds__(NTHR) void bn_bwd_reduce_kernel(
     const float* __restrict__ g, const uint64_t* __restrict__ bits, const float* __restrict__ z,
     const float* __restrict__ mean, const float* __restrict__ rstd, float kscale, int B, int H,
-    float* __restrict__ part_dy, float* __restrict__ part_dyz, int Hc) {
+    float* __restrict__ part_dy, float* __restrict__ part_dyz, int Hc, float* __restrict__ part_amax) {
   __shared__ float4 sm[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int strip = blockIdx.x;
@@ -305,6 +344,7 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_reduce_kernel(
   const bool active = c < H;
   const int wpr = ((H + 255) >> 8) * 4;
   float4 mu = make_float4(0, 0, 0, 0), rs = mu, s1 = mu, s2 = mu;
+  float mxd = 0.f, mxz = 0.f;                     // max |dy|, max |zhat| seen by this lane (part_amax)
   if (active) { mu = ld4(mean + c % Hc); rs = ld4(rstd + c % Hc); }
   for (int r = blockIdx.y * 4 + wave; r < B; r += gridDim.y * 4) {
     if (!active) continue;
@@ -316,13 +356,34 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_reduce_kernel(
     const float d2 = ((bw[2] >> lane) & 1ull) ? gv.z * kscale : 0.f;
     const float d3 = ((bw[3] >> lane) & 1ull) ? gv.w * kscale : 0.f;
     s1.x += d0; s1.y += d1; s1.z += d2; s1.w += d3;
-    s2.x = fmaf(d0, (zv.x - mu.x) * rs.x, s2.x);
-    s2.y = fmaf(d1, (zv.y - mu.y) * rs.y, s2.y);
-    s2.z = fmaf(d2, (zv.z - mu.z) * rs.z, s2.z);
-    s2.w = fmaf(d3, (zv.w - mu.w) * rs.w, s2.w);
+    const float z0 = (zv.x - mu.x) * rs.x, z1 = (zv.y - mu.y) * rs.y, z2 = (zv.z - mu.z) * rs.z, z3 = (zv.w - mu.w) * rs.w;
+    s2.x = fmaf(d0, z0, s2.x);
+    s2.y = fmaf(d1, z1, s2.y);
+    s2.z = fmaf(d2, z2, s2.z);
+    s2.w = fmaf(d3, z3, s2.w);
+    if (part_amax) {
+      mxd = fmaxf(fmaxf(mxd, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
+      mxz = fmaxf(fmaxf(mxz, fmaxf(fabsf(z0), fabsf(z1))), fmaxf(fabsf(z2), fabsf(z3)));
+    }
   }
   const float4 t1 = combine4(s1, sm, wave, lane);
   const float4 t2 = combine4(s2, sm, wave, lane);
+  if (part_amax) {                                 // wave-uniform; one pair per workgroup, no atomics
+    sm[wave][lane] = make_float4(mxd, mxz, 0.f, 0.f);
+    __syncthreads();
+    if (wave == 0) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { a = fmaxf(a, sm[w][lane].x); b = fmaxf(b, sm[w][lane].y); }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { a = fmaxf(a, __shfl_xor(a, o)); b = fmaxf(b, __shfl_xor(b, o)); }
+      if (lane == 0) {
+        float* q = part_amax + ((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 2;
+        q[0] = a; q[1] = b;
+      }
+    }
+    __syncthreads();
+  }
   if (wave == 0 && active) {
     // replica-major when Hc < H: [R][2][RC][Hc] (part_dyz = part_dy + RC*Hc); plain [2][RC][H] otherwise
     const int rep = c / Hc, cc = c - rep * Hc;
@@ -338,8 +399,37 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_reduce_kernel(
 __global__ __launch_bounds__(NTHR) void bn_bwd_finalize_kernel(
     const float* __restrict__ part_all, int RC, int world, int rank, int Br, int H,
     const float* __restrict__ gamma, const float* __restrict__ rstd, float* __restrict__ coef,
-    float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ part_amax, int n_amax,
+    float* __restrict__ dz_scale) {
   __shared__ float red[RPARTS][RCOLS];
+  if (dz_scale && blockIdx.x == gridDim.x - 1) {
+    // the extra workgroup: range bound of dz = c0 (dy - c1 - zhat c2), |c1| <= max|dy|, |c2| <= max|dy| (mean |zhat| <= 1):
+    //   |dz| <= max|c0| max|dy| (2 + max|zhat|)  ->  S = the power of two that maps the bound into (2^13, 2^14]
+    float a = 0.f, b = 0.f, c0 = 0.f;
+    for (int k = threadIdx.x; k < n_amax; k += NTHR) { a = fmaxf(a, part_amax[2 * k]); b = fmaxf(b, part_amax[2 * k + 1]); }
+    for (int k = threadIdx.x; k < H; k += NTHR) c0 = fmaxf(c0, fabsf(gamma[k] * rstd[k]));
+    float* sm = &red[0][0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      a = fmaxf(a, __shfl_xor(a, o)); b = fmaxf(b, __shfl_xor(b, o)); c0 = fmaxf(c0, __shfl_xor(c0, o));
+    }
+    if (lane == 0) { sm[wave * 3] = a; sm[wave * 3 + 1] = b; sm[wave * 3 + 2] = c0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int w = 1; w < 4; ++w) { a = fmaxf(a, sm[w * 3]); b = fmaxf(b, sm[w * 3 + 1]); c0 = fmaxf(c0, sm[w * 3 + 2]); }
+      const float bound = c0 * a * (2.0f + b);
+      int e = 0;
+      float S = 1.0f, Si = 1.0f;
+      if (bound > 0.f && bound < 3.0e38f) {          // zero / inf / nan gradients: scale 1 (they stay what they are)
+        (void)frexpf(bound, &e);                     // bound = m 2^e, 0.5 <= m < 1
+        e = min(max(14 - e, -100), 100);
+        S = ldexpf(1.0f, e); Si = ldexpf(1.0f, -e);
+      }
+      dz_scale[0] = S; dz_scale[1] = Si;
+    }
+    return;
+  }
   const int cl = threadIdx.x & (RCOLS - 1), part = threadIdx.x / RCOLS;
   const int c = blockIdx.x * RCOLS + cl;
   const bool ok = c < H;
@@ -398,8 +488,9 @@ __global__ __launch_bounds__(NTHR) void reduce_rows_kernel(const float* __restri
 __global__ __launch_bounds__(NTHR) void bn_bwd_dz_kernel(
     const float* __restrict__ g, const uint64_t* __restrict__ bits, const float* __restrict__ z,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ coef,
-    float kscale, int bn, int B, int H, float* __restrict__ dz, float* __restrict__ part_db, int Hc) {
+    float kscale, int bn, int B, int H, float* __restrict__ dz, float* __restrict__ part_db, int Hc, PlaneOut po) {
   __shared__ float4 sm[4][64];
+  const PlaneDst pd = plane_dst(po);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int strip = blockIdx.x;
   const int c = strip * 256 + lane * 4;
@@ -429,7 +520,8 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_dz_kernel(
       d.z = c0.z * (d.z - c1.z - (zv.z - mu.z) * rs.z * c2.z);
       d.w = c0.w * (d.w - c1.w - (zv.w - mu.w) * rs.w * c2.w);
     }
-    st4(dz + off, d);
+    if (dz) st4(dz + off, d);
+    if (pd.kind) store_planes4(pd, off, d);
     sdb.x += d.x; sdb.y += d.y; sdb.z += d.z; sdb.w += d.w;
   }
   const float4 t = combine4(sdb, sm, wave, lane);
@@ -753,8 +845,10 @@ int launch_bn_finalize(const float* stat, int G, int world, int B, int H,
 
 int launch_bn_apply(const float* z, const float* scale, const float* shift, const float* resid,
                     float* act, uint64_t* bits, int B, int H, float p, uint64_t seed, uint64_t step,
-                    int layer, const uint64_t* inject_keep, hipStream_t s) {
+                    int layer, const uint64_t* inject_keep, hipStream_t s, const PlaneOut* planes) {
   int mode = 0;
+  const PlaneOut po = planes ? *planes : PlaneOut{nullptr, nullptr, 1.f, nullptr, 0};
+  if (!act && !po.kind) PL_FAIL(PL_EINVAL, "bn_apply: nothing to write");
   float kscale = 1.f;
   if (p >= 1.f) mode = 3;
   else if (p > 0.f) {
@@ -766,7 +860,7 @@ int launch_bn_apply(const float* z, const float* scale, const float* shift, cons
   const int strips = (H + 255) / 256;
   dim3 grid(strips, stream_rows_grid(B, strips));
   hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NTHR), 0, s, z, scale, shift, resid, act, bits, B, H,
-                     mode, thr, kscale, k0, k1, (uint32_t)step, (uint32_t)layer, inject_keep, H);
+                     mode, thr, kscale, k0, k1, (uint32_t)step, (uint32_t)layer, inject_keep, H, po);
   PL_CHECK_LAUNCH("bn_apply");
   return PL_OK;
 }
@@ -786,30 +880,44 @@ int bwd_row_chunks(int B, int H) {
 
 int launch_bn_bwd_reduce(const float* g, const uint64_t* bits, const float* z, const float* mean,
                          const float* rstd, float keep_scale, int B, int H, float* part_dy,
-                         float* part_dyz, hipStream_t s, int Hc) {
+                         float* part_dyz, hipStream_t s, int Hc, float* part_amax) {
   dim3 grid((H + 255) / 256, bwd_row_chunks(B, H));
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(NTHR), 0, s, g, bits, z, mean, rstd, keep_scale, B,
-                     H, part_dy, part_dyz, Hc > 0 ? Hc : H);
+                     H, part_dy, part_dyz, Hc > 0 ? Hc : H, part_amax);
   PL_CHECK_LAUNCH("bn_bwd_reduce");
   return PL_OK;
 }
 
 int launch_bn_bwd_finalize(const float* part, int RC, int world, int rank, int B, int H,
                            const float* gamma, const float* rstd, float* coef, float* dgamma,
-                           float* dbeta, hipStream_t s) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((H + RCOLS - 1) / RCOLS), dim3(NTHR), 0, s, part, RC, world, rank,
-                     B, H, gamma, rstd, coef, dgamma, dbeta);
+                           float* dbeta, hipStream_t s, const float* part_amax, int n_amax, float* dz_scale) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((H + RCOLS - 1) / RCOLS + (dz_scale ? 1 : 0)), dim3(NTHR), 0, s, part,
+                     RC, world, rank, B, H, gamma, rstd, coef, dgamma, dbeta, part_amax, n_amax, dz_scale);
   PL_CHECK_LAUNCH("bn_bwd_finalize");
   return PL_OK;
 }
 
 int launch_bn_bwd_dz(const float* g, const uint64_t* bits, const float* z, const float* mean,
                      const float* rstd, const float* coef, float keep_scale, int bn, int B, int H,
-                     float* dz, float* part_db, hipStream_t s, int Hc) {
+                     float* dz, float* part_db, hipStream_t s, int Hc, const PlaneOut* planes) {
   dim3 grid((H + 255) / 256, bwd_row_chunks(B, H));
+  const PlaneOut po = planes ? *planes : PlaneOut{nullptr, nullptr, 1.f, nullptr, 0};
+  if (!dz && !po.kind) PL_FAIL(PL_EINVAL, "bn_bwd_dz: nothing to write");
   hipLaunchKernelGGL(bn_bwd_dz_kernel, grid, dim3(NTHR), 0, s, g, bits, z, mean, rstd, coef, keep_scale,
-                     bn, B, H, dz, part_db, Hc > 0 ? Hc : H);
+                     bn, B, H, dz, part_db, Hc > 0 ? Hc : H, po);
   PL_CHECK_LAUNCH("bn_bwd_dz");
+  return PL_OK;
+}
+
+int launch_split_planes(const float* x, int64_t n, const PlaneOut& out, hipStream_t s) {
+  if (!x || !out.h || (out.kind == 2 && !out.l) || out.kind < 1 || out.kind > 2) PL_FAIL(PL_EINVAL, "split_planes: bad arguments");
+  if ((n & 3) || !aligned16(x) || (reinterpret_cast<uintptr_t>(out.h) & 7) || (reinterpret_cast<uintptr_t>(out.l) & 7))
+    PL_FAIL(PL_EINVAL, "split_planes: n %% 4 and alignment");
+  const int64_t n4 = n >> 2;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(split_planes_kernel, dim3(blocks), dim3(256), 0, s, x, n4, out);
+  PL_CHECK_LAUNCH("split_planes");
   return PL_OK;
 }
 
@@ -1083,7 +1191,8 @@ extern "C" int pl_bn_train_fwd(const float* z, int64_t rows, int64_t C, const fl
   const int strips = (H + 255) / 256;
   dim3 grid(strips, stream_rows_grid(B, strips));
   hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NTHR), 0, s, z, scale, shift, (const float*)nullptr, y, bits, B, H,
-                     relu ? 0 : 8, 0u, 1.0f, 0u, 0u, 0u, 0u, (const uint64_t*)nullptr, Hc);
+                     relu ? 0 : 8, 0u, 1.0f, 0u, 0u, 0u, 0u, (const uint64_t*)nullptr, Hc,
+                     PlaneOut{nullptr, nullptr, 1.f, nullptr, 0});
   PL_CHECK_LAUNCH("bn_apply");
   return PL_OK;
 }

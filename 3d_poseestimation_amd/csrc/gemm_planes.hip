@@ -1,0 +1,136 @@
+// GEMMs on pre-split 16-bit operand planes (gemm_planes.h): the 1024-wide Linears of the lifter in the
+// PL_F16X3 (fp32-grade, three fp16 MFMAs per product term) and PL_BF16 (bf16 storage) modes.
+//
+// Replaces the ATen addmm calls behind nn.Linear forward / backward (reference phase1_lifting/baselineModel.py:33,39
+// and their autograd), like gemm_f32.hip; same 128x128 tile per workgroup, same register epilogue (gemm_epilogue.h:
+// bias, training-mode BatchNorm partial statistics, eval-mode BN fold + ReLU + skip, residual-gradient addend, split-K
+// slabs).  512 threads: wavefronts 0-3 compute, wavefronts 4-7 drive the LDS-DMA.
+#include "gemm_epilogue.h"
+#include "gemm_planes.h"
+#include "pl_internal.h"
+
+namespace pl {
+namespace {
+
+struct PlanesKern {
+  plp::PlanesArgs p;
+  GemmArgs e;
+  float out_scale;
+  const float* dyn_inv;
+};
+
+template <bool A_KS, bool B_KS, int MODE>
+__device__ __forceinline__ void planes_body(const PlanesKern& k, const int block_id, const int nwork, char* lds) {
+  f32x16 acc[plp::ModeCfg<MODE>::NACC][2][2];
+  int m0, n0, slice;
+  if (!plp::planes_mainloop<A_KS, B_KS, 32, MODE, 4, 0, 3>(k.p, block_id, nwork, lds, acc, m0, n0, slice)) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;       // waves 0-3 only
+  const int i = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  if constexpr (MODE == plp::kF16x3) {
+    // main + low / 2048, then back from the operands' power-of-two scales (exact unless the result under/overflows)
+    const float os = k.dyn_inv ? k.out_scale * k.dyn_inv[0] : k.out_scale;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          acc[0][a][b][r] = fmaf(acc[1][a][b][r], 1.0f / plp::kF16LoScale, acc[0][a][b][r]) * os;
+  }
+  float* C = k.e.C + (k.e.split_k > 1 ? (size_t)slice * k.e.M * k.e.ldc : 0);
+  gemm_epilogue<false, 2>(k.e, C, acc[0], m0, n0, wm, wn, i, h);
+}
+
+template <bool A_KS, bool B_KS, int MODE>
+__global__ __launch_bounds__(512) void planes_gemm_kernel(PlanesKern k) {
+  __shared__ __attribute__((aligned(16))) char lds[plp::PlanesCfg<32, plp::ModeCfg<MODE>::NPL, 3>::LDS];
+  planes_body<A_KS, B_KS, MODE>(k, blockIdx.x, gridDim.x, lds);
+}
+
+// backward pair of one layer in one launch: workgroups [0, n0) run dX = dz W (NN), the rest dW = dz^T a (TN, split-K
+// slabs).  One workgroup per CU at a time (96 KB of LDS each): what the single launch saves is the launch boundary
+// and the tail of the first problem, which the second one's workgroups fill.
+template <int MODE>
+__global__ __launch_bounds__(512) void planes_gemm_dual_kernel(PlanesKern k0, PlanesKern k1, int n0) {
+  __shared__ __attribute__((aligned(16))) char lds[plp::PlanesCfg<32, plp::ModeCfg<MODE>::NPL, 3>::LDS];
+  if ((int)blockIdx.x < n0)
+    planes_body<false, true, MODE>(k0, blockIdx.x, n0, lds);
+  else
+    planes_body<true, true, MODE>(k1, blockIdx.x - n0, gridDim.x - n0, lds);
+}
+
+int npl_of(int mode) { return mode == plp::kF16x3 ? 2 : (mode == plp::kBf16x6 ? 3 : 1); }
+
+PlanesKern kern_of(GemmLayout layout, const PlanesGemmArgs& a) {
+  PlanesKern k = {};
+  k.p.A = reinterpret_cast<const __bf16*>(a.A);
+  k.p.B = reinterpret_cast<const __bf16*>(a.B);
+  k.p.C = a.e.C;
+  k.p.M = a.e.M; k.p.N = a.e.N; k.p.K = a.e.K;
+  k.p.lda = a.lda; k.p.ldb = a.ldb; k.p.ldc = a.e.ldc;
+  k.p.split_k = a.e.split_k;
+  k.p.a_plane = (size_t)a.a_plane; k.p.b_plane = (size_t)a.b_plane;
+  k.e = a.e;
+  k.out_scale = a.out_scale;
+  k.dyn_inv = a.dyn_inv;
+  (void)layout;
+  return k;
+}
+
+int grid_of(const PlanesGemmArgs& a) {
+  return (a.e.M / 128) * (a.e.N / 128) * (a.e.split_k > 1 ? a.e.split_k : 1);
+}
+
+}  // namespace
+
+// whole 128x128 tiles, every K slice a whole number of 32-k tiles, 16-byte aligned plane rows, and every byte
+// offset the DMA's 32-bit scalar offset has to hold below 2^31
+bool planes_gemm_ok(GemmLayout layout, const PlanesGemmArgs& a) {
+  const GemmArgs& e = a.e;
+  if (a.mode != plp::kBf16 && a.mode != plp::kF16x3) return false;
+  if (!a.A || !a.B || !e.C || e.M <= 0 || e.N <= 0 || e.K <= 0) return false;
+  const int splits = e.split_k > 1 ? e.split_k : 1;
+  if (e.M % 128 || e.N % 128 || e.K % (32 * splits)) return false;
+  if ((a.lda & 7) || (a.ldb & 7)) return false;
+  if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) return false;
+  if (((a.a_plane | a.b_plane) & 7) != 0) return false;
+  const int npl = npl_of(a.mode);
+  const bool a_ks = layout == kTN, b_ks = layout != kNT;
+  const int64_t a_ext = (int64_t)(npl - 1) * a.a_plane * 2 + (a_ks ? (int64_t)e.K * a.lda * 2 : (int64_t)128 * a.lda * 2 + (int64_t)e.K * 2);
+  const int64_t b_ext = (int64_t)(npl - 1) * a.b_plane * 2 + (b_ks ? (int64_t)e.K * a.ldb * 2 : (int64_t)128 * a.ldb * 2 + (int64_t)e.K * 2);
+  if (a_ext >= (1ll << 31) || b_ext >= (1ll << 31)) return false;
+  if ((e.stat_sum != nullptr) != (e.stat_m2 != nullptr)) return false;
+  return true;
+}
+
+int launch_gemm_planes(GemmLayout layout, const PlanesGemmArgs& a, hipStream_t s) {
+  if (!planes_gemm_ok(layout, a)) PL_FAIL(PL_ESHAPE, "gemm_planes: unsupported problem %dx%dx%d (layout %d, mode %d)", a.e.M, a.e.N, a.e.K, (int)layout, a.mode);
+  const PlanesKern k = kern_of(layout, a);
+  const dim3 grid(grid_of(a)), block(512);
+#define PL_PLANES_LAUNCH(MODE)                                                                                   \
+  switch (layout) {                                                                                              \
+    case kNT: hipLaunchKernelGGL((planes_gemm_kernel<false, false, MODE>), grid, block, 0, s, k); break;         \
+    case kNN: hipLaunchKernelGGL((planes_gemm_kernel<false, true, MODE>), grid, block, 0, s, k); break;          \
+    case kTN: hipLaunchKernelGGL((planes_gemm_kernel<true, true, MODE>), grid, block, 0, s, k); break;           \
+    default: PL_FAIL(PL_EINVAL, "gemm_planes: bad layout %d", (int)layout);                                     \
+  }
+  if (a.mode == plp::kF16x3) { PL_PLANES_LAUNCH(plp::kF16x3) } else { PL_PLANES_LAUNCH(plp::kBf16) }
+#undef PL_PLANES_LAUNCH
+  PL_CHECK_LAUNCH("gemm_planes");
+  return PL_OK;
+}
+
+int launch_gemm_planes_pair(const PlanesGemmArgs& nn, const PlanesGemmArgs& tn, hipStream_t s) {
+  if (!planes_gemm_ok(kNN, nn) || !planes_gemm_ok(kTN, tn) || nn.mode != tn.mode)
+    PL_FAIL(PL_ESHAPE, "gemm_planes_pair: unsupported problems");
+  const PlanesKern k0 = kern_of(kNN, nn), k1 = kern_of(kTN, tn);
+  const int g0 = grid_of(nn), g1 = grid_of(tn);
+  if (nn.mode == plp::kF16x3)
+    hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kF16x3>), dim3(g0 + g1), dim3(512), 0, s, k0, k1, g0);
+  else
+    hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kBf16>), dim3(g0 + g1), dim3(512), 0, s, k0, k1, g0);
+  PL_CHECK_LAUNCH("gemm_planes_dual");
+  return PL_OK;
+}
+
+}  // namespace pl

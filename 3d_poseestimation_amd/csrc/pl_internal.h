@@ -71,6 +71,39 @@ int launch_conv_nhwc_group4(const GemmArgs* a, hipStream_t s);
 // weight gradient of a convolution: the TN planes GEMM over pixels with the B operand gathered from x
 int launch_conv_wgrad(const GemmArgs& a, hipStream_t s);
 
+// ---------------------------------------------------------------------------------
+// planes GEMM (gemm_planes.hip / gemm_planes.h): operands pre-split into 16-bit planes by their producers
+// ---------------------------------------------------------------------------------
+// Where a streaming kernel writes the planes of the tensor it produces ([rows][cols] row-major, like the tensor):
+//   kind 0 none; 1 one bf16 plane (PL_BF16 storage); 2 fp16 pair (PL_F16X3): h = fp16(S x), l = fp16((S x - h) * 2048)
+// S = scale, or -- dyn != NULL -- the device value dyn[0] (a power of two written by an earlier kernel).
+struct PlaneOut {
+  unsigned short* h;
+  unsigned short* l;
+  float scale;
+  const float* dyn;
+  int kind;
+};
+constexpr float kActPlaneScale = 1.0f;      // activations: fp16 covers 6e-5 .. 65504 in h, the remainder in l
+constexpr float kWeightPlaneScale = 16.0f;  // weights (|w| ~ 0.03 at init): 3.8e-6 .. 4094
+
+struct PlanesGemmArgs {
+  GemmArgs e;                 // M, N, K, C, ldc, split_k and the epilogue fields (A, B, lda, ldb, arith unused)
+  const unsigned short* A;    // planes of A: k-contiguous [M][K] (NT, NN) or k-strided [K][M] (TN)
+  const unsigned short* B;    // planes of B: k-contiguous [N][K] (NT) or k-strided [K][N] (NN, TN)
+  int64_t a_plane, b_plane;   // elements between two planes of one tensor
+  int lda, ldb;               // row strides (elements) of the plane matrices
+  int mode;                   // plp::PlanesMode: 0 bf16 (one plane), 2 f16x3 (two planes)
+  float out_scale;            // acc * out_scale [* dyn_inv[0]] before the epilogue: 1 / (S_A S_B)
+  const float* dyn_inv;       // device scalar or NULL
+};
+bool planes_gemm_ok(GemmLayout layout, const PlanesGemmArgs& a);
+int launch_gemm_planes(GemmLayout layout, const PlanesGemmArgs& a, hipStream_t s);
+// dX = dz W (NN) and dW = dz^T a (TN, split-K slabs) of one layer in ONE launch
+int launch_gemm_planes_pair(const PlanesGemmArgs& nn, const PlanesGemmArgs& tn, hipStream_t s);
+// x [n] fp32 -> planes (static scale); n % 4 == 0, 16-byte aligned
+int launch_split_planes(const float* x, int64_t n, const PlaneOut& out, hipStream_t s);
+
 int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s);
 int launch_gemm_f32_pair(const GemmArgs& nn, const GemmArgs& tn, hipStream_t s);
 int gemm_stat_groups(int M);  // number of 64-row groups the stats epilogue emits
@@ -90,24 +123,31 @@ int launch_bn_finalize(const float* stat, int G, int world, int B, int H,
                        float* mean, float* rstd, float* scale, float* shift, hipStream_t s, int group_rows = 64);
 
 // act = [resid +] dropout(relu(z*scale + shift)); bits = keep&positive bitmap
+// planes: also (act == NULL: only) write the activation as GEMM operand planes
 int launch_bn_apply(const float* z, const float* scale, const float* shift, const float* resid,
                     float* act, uint64_t* bits, int B, int H, float p, uint64_t seed,
-                    uint64_t step, int layer, const uint64_t* inject_keep, hipStream_t s);
+                    uint64_t step, int layer, const uint64_t* inject_keep, hipStream_t s,
+                    const PlaneOut* planes = nullptr);
 
 int bwd_row_chunks(int B, int H);
 // pass 1: partial column sums of dy and dy*zhat, dy = g * bits * keep_scale
+// part_amax (optional): [strips * RC][2] per-workgroup maxima of |dy| and |zhat| (the dz range bound, below)
 int launch_bn_bwd_reduce(const float* g, const uint64_t* bits, const float* z, const float* mean,
                          const float* rstd, float keep_scale, int B, int H, float* part_dy,
-                         float* part_dyz, hipStream_t s, int Hc = 0);
+                         float* part_dyz, hipStream_t s, int Hc = 0, float* part_amax = nullptr);
 // finalize: c = {gamma*rstd, sum_dy/B, sum_dyz/B}; dgamma, dbeta
 // (part = [world][2][RC][H]; coef uses all ranks' partials, dgamma/dbeta this rank's only)
+// dz_scale (optional, with part_amax of n_amax workgroups): {S, 1/S}, S the power of two that maps the bound
+// max|c0| max|dy| (2 + max|zhat|) >= max|dz| to at most 2^14 (fp16 planes of dz, PL_F16X3)
 int launch_bn_bwd_finalize(const float* part, int RC, int world, int rank, int B, int H,
                            const float* gamma, const float* rstd, float* coef, float* dgamma,
-                           float* dbeta, hipStream_t s);
+                           float* dbeta, hipStream_t s, const float* part_amax = nullptr, int n_amax = 0,
+                           float* dz_scale = nullptr);
 // pass 2: dz = c0*(dy - c1 - zhat*c2)  (bn) or dz = dy (no bn); partial column sums of dz
+// planes: also (dz == NULL: only) write dz as GEMM operand planes
 int launch_bn_bwd_dz(const float* g, const uint64_t* bits, const float* z, const float* mean,
                      const float* rstd, const float* coef, float keep_scale, int bn, int B, int H,
-                     float* dz, float* part_db, hipStream_t s, int Hc = 0);
+                     float* dz, float* part_db, hipStream_t s, int Hc = 0, const PlaneOut* planes = nullptr);
 
 // out[i] = sum_s slabs[s*n + i]
 int launch_reduce_slabs(const float* slabs, int nslab, int64_t n, float* out, hipStream_t s);

@@ -22,7 +22,10 @@ from .dp import shard_rows
 def epoch_indices(n_rows, batch_size, *, epoch=0, seed=0, shuffle=True, drop_last=False, rank=0, world=1):
     """The index tensors (int64, CPU) of this rank's batches for one epoch.  A global batch is
     `batch_size * world` consecutive entries of the epoch's permutation; the last one may be short
-    (DataLoader's drop_last=False) and is split over the ranks like the others."""
+    (DataLoader's drop_last=False).  With world > 1 every rank must run the same number of steps on the
+    same number of rows (the gradient all-reduce and SyncBN are collectives; training-mode BatchNorm needs
+    >= 2 rows): the short tail batch is trimmed to a multiple of `world` rows and dropped on EVERY rank when
+    that leaves fewer than 2 rows per rank."""
     if n_rows <= 0 or batch_size <= 0 or not (0 <= rank < world):
         raise ValueError("bad feeder geometry")
     if shuffle:
@@ -37,10 +40,23 @@ def epoch_indices(n_rows, batch_size, *, epoch=0, seed=0, shuffle=True, drop_las
         chunk = perm[start:start + gb]
         if chunk.numel() < gb and drop_last:
             break
+        if world > 1 and chunk.numel() < gb:
+            per = chunk.numel() // world
+            if per < 2:
+                break
+            chunk = chunk[:per * world]
         lo, hi = shard_rows(chunk.numel(), rank, world)
-        if hi > lo:
-            out.append(chunk[lo:hi])
+        out.append(chunk[lo:hi])
     return out
+
+
+def epoch_steps(n_rows, batch_size, *, drop_last=False, world=1):
+    """Number of batches epoch_indices() yields -- the same on every rank."""
+    gb = batch_size * world
+    full, tail = divmod(n_rows, gb)
+    if drop_last or tail == 0:
+        return full
+    return full + (1 if (world == 1 or tail // world >= 2) else 0)
 
 
 class PoseFeeder:
@@ -77,8 +93,7 @@ class PoseFeeder:
                              drop_last=self.drop_last, rank=self.rank, world=self.world)
 
     def __len__(self):
-        gb = self.batch_size * self.world
-        return self.n // gb if self.drop_last else (self.n + gb - 1) // gb
+        return epoch_steps(self.n, self.batch_size, drop_last=self.drop_last, world=self.world)
 
     def __iter__(self):
         return self._iter_resident() if self.resident else self._iter_streamed()

@@ -57,8 +57,39 @@ class GradSync:
     bucket_bytes splits the arena into contiguous buckets (default: one bucket -- at 17 MB a
     single RCCL call is latency-optimal on the fully connected xGMI mesh)."""
 
-    def __init__(self, group=None, bucket_bytes=None):
+    def __init__(self, group=None, bucket_bytes=None, overlap=True):
         self.group, self.bucket_bytes = group, bucket_bytes
+        self._pending = []
+        self._overlap, self._defer = bool(overlap), 0
+
+    # ---- when may backward launch buckets? -----------------------------------------------------
+    # Only from the backward that completes the optimizer step's gradient: LinearModel launches them from the
+    # backward of the last live graph (two lifter calls in one graph contribute first), and the caller marks
+    # gradient-accumulation micro-batches with no_sync(), exactly as with DistributedDataParallel.  Whatever was
+    # not overlapped is reduced as one whole-arena all-reduce in __call__.
+    def overlap_enabled(self):
+        return self._overlap and self._defer == 0
+
+    def no_sync(self):
+        """Context manager: backward passes inside it launch no all-reduce (gradient accumulation)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            self._defer += 1
+            try:
+                yield self
+            finally:
+                self._defer -= 1
+        return _cm()
+
+    def has_pending(self):
+        return bool(self._pending)
+
+    def abandon(self):
+        """Wait for and forget buckets in flight (their result is unusable)."""
+        for w in self._pending:
+            w.wait()
         self._pending = []
 
     def world(self):
@@ -86,8 +117,8 @@ class GradSync:
 
     def __call__(self, model):
         """Scale to apply to the summed gradients.  Waits for buckets launched during backward;
-        if backward launched none (no overlap attached, or gradient accumulation) the whole arena
-        is reduced here."""
+        if backward launched none (no overlap attached, no_sync() micro-batches, several lifter calls in
+        one graph) the whole arena is reduced here."""
         if self._pending:
             for w in self._pending:
                 w.wait()

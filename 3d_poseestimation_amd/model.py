@@ -47,12 +47,35 @@ class _EvalNoBackward(torch.autograd.Function):
         raise NotImplementedError("backward through an eval-mode LinearModel is not built yet")
 
 
+class _GraphTicket:
+    """One training forward whose backward has not run yet.  LinearModel counts the live ones: the
+    data-parallel overlap launches its all-reduce buckets only from the backward of the LAST live graph
+    (two lifter calls in one graph -- the phase5 cycle -- must both have contributed first)."""
+
+    def __init__(self, model):
+        self.model, self.open = weakref.ref(model), True
+        model._live_graphs += 1
+
+    def close(self):
+        if self.open:
+            self.open = False
+            m = self.model()
+            if m is not None:
+                m._live_graphs -= 1
+
+
 class _LifterFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2, model, ws, *params):
-        y = model._run_fwd_train(x2, ws)
+        try:
+            y = model._run_fwd_train(x2, ws)
+        except BaseException:
+            model._release_workspace(ws, ws["busy"])     # a failed library call must not leak the workspace
+            raise
         ctx.model, ctx.ws, ctx.token = model, ws, ws["busy"]
+        ctx.ticket = _GraphTicket(model)
         weakref.finalize(ctx, LinearModel._release_workspace, ws, ws["busy"])
+        weakref.finalize(ctx, ctx.ticket.close)          # a graph dropped without backward
         ctx.save_for_backward(x2)
         ctx.need_dx = x2.requires_grad
         return y
@@ -61,8 +84,16 @@ class _LifterFn(torch.autograd.Function):
     def backward(ctx, gy):
         (x2,) = ctx.saved_tensors
         model, ws = ctx.model, ctx.ws
-        dx = model._run_bwd(x2, gy.contiguous(), ws, ctx.need_dx)
-        model._release_workspace(ws, ctx.token)
+        if not ctx.ticket.open:
+            # the workspace was handed back after the first backward and may hold a later forward by now
+            raise _lib.PoseliftError("second backward through the same LinearModel forward (retain_graph): the saved "
+                                     "activations were released after the first one -- run the forward again")
+        last = model._live_graphs == 1
+        try:
+            dx = model._run_bwd(x2, gy.contiguous(), ws, ctx.need_dx, last_graph=last)
+        finally:
+            ctx.ticket.close()
+            model._release_workspace(ws, ctx.token)
         # parameter gradients were written straight into the flat gradient arena and
         # attached as .grad views (one arena = one all-reduce, one fused AdamW launch)
         return (dx, None, None) + (None,) * len(model._param_list)
@@ -81,13 +112,15 @@ class LinearModel(nn.Module):
         self.linear_stages = nn.ModuleList(Linear(linear_size, p_dropout, BN) for _ in range(num_stage))
         self.w2 = nn.Linear(linear_size, o_dim)
         self.BN = BN
-        self.compute_dtype = {"fp32": _lib.PL_F32, "bf16": _lib.PL_BF16, "bf16x6": _lib.PL_BF16X6}[compute_dtype]
+        self.compute_dtype = {"fp32": _lib.PL_F32, "bf16": _lib.PL_BF16, "bf16x6": _lib.PL_BF16X6,
+                              "f16x3": _lib.PL_F16X3}[compute_dtype]
         self._slots, self._arena_floats = param_slots(i_dim, linear_size, o_dim, num_stage)
         self._seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
         self._step = 0
         self._inject_keep = None
         self._grad_sync = None
         self._dp_cuts = None
+        self._live_graphs = 0
         self._sync_struct = self._gather_cb = self._sync_group = self._active_ws = self._cb_error = None
         self._flat = self._flat_grad = self._flat_grad_tmp = None
         self._ws_pool, self._ws_token = {}, 0
@@ -144,6 +177,7 @@ class LinearModel(nn.Module):
     def __setstate__(self, st):
         self.__dict__.update(st)
         self._grad_sync = self._inject_keep = self._dp_cuts = None
+        self._live_graphs = 0
         self._sync_struct = self._gather_cb = self._sync_group = self._active_ws = self._cb_error = None
         self._ws_pool, self._ws_token = {}, 0
         self._flatten()
@@ -325,9 +359,17 @@ class LinearModel(nn.Module):
         self.last_workspace = ws
         return y
 
-    def _run_bwd(self, x2, gy, ws, need_dx):
+    def _run_bwd(self, x2, gy, ws, need_dx, last_graph=True):
         B = x2.shape[0]
         accumulate = any(p.grad is not None for p in self._param_list)
+        sync = self._grad_sync
+        if accumulate and sync is not None and sync.has_pending():
+            # an earlier backward of this optimizer step already all-reduced its buckets: adding local gradients
+            # to summed ones would make the replicas diverge silently
+            sync.abandon()
+            raise _lib.PoseliftError(
+                "gradient accumulation with overlapped all-reduce: wrap every backward but the last of an optimizer "
+                "step in `with sync.no_sync():` (dp.GradSync), as with DistributedDataParallel")
         if accumulate:
             if self._flat_grad_tmp is None:
                 self._flat_grad_tmp = torch.zeros_like(self._flat)
@@ -337,8 +379,7 @@ class LinearModel(nn.Module):
         dx = torch.empty_like(x2) if need_dx else None
         args = (ctypes.byref(self._desc), x2.data_ptr(), gy.data_ptr(), B, ws["buf"].data_ptr(), ws["bytes"],
                 dx.data_ptr() if need_dx else None, target.data_ptr())
-        sync = self._grad_sync
-        if sync is not None and not accumulate and sync.world() > 1:
+        if sync is not None and not accumulate and last_graph and sync.overlap_enabled() and sync.world() > 1:
             # data-parallel overlap: after each layer range the tail of the arena down to that
             # range's lowest layer is final and is all-reduced while the layers below compute
             for hi, lo, a_lo, a_hi in self._bwd_ranges():
@@ -379,7 +420,7 @@ class LinearModel(nn.Module):
                     ctypes.byref(self._desc), x2.data_ptr(), target.data_ptr(), B, ws["buf"].data_ptr(), ws["bytes"],
                     self._seed, self._step, y.data_ptr(), loss.data_ptr(), grads.data_ptr(), hi, lo,
                     _lib.current_stream_ptr()), "pl_lifter_train_fwd_bwd")
-            if sync is not None and sync.world() > 1:
+            if sync is not None and sync.world() > 1 and sync.overlap_enabled():
                 for hi, lo, a_lo, a_hi in self._bwd_ranges():
                     call(hi, lo)
                     sync.launch_bucket(grads[a_lo:a_hi])

@@ -46,6 +46,27 @@ class FlatAdamW(torch.optim.Optimizer):
         self._step_tensor.fill_(float(self._t))
         self._m, self._v, self._bound_arena = m, v, flat
 
+    def _active_ranges(self):
+        """Arena ranges [lo, hi) (floats) the step updates.  torch.optim.AdamW skips a parameter whose grad is None:
+        with BN=False the reference never touches the (unused) BatchNorm weights and biases -- no moment update and,
+        in particular, no weight decay -- and the same goes for requires_grad=False tensors.  Everything active (the
+        normal case) is ONE launch over the whole arena; otherwise one launch per run of adjacent active tensors."""
+        model = self._model
+        active = [p.requires_grad and (model.BN or "batch_norm" not in s.name)
+                  for s, p in zip(model._slots, model._param_list)]
+        if all(active):
+            return [(0, model.flat_params.numel())]
+        runs = []
+        for k, (s, on) in enumerate(zip(model._slots, active)):
+            if not on:
+                continue
+            end = model._slots[k + 1].offset if k + 1 < len(model._slots) else model.flat_params.numel()
+            if runs and runs[-1][1] == s.offset:
+                runs[-1] = (runs[-1][0], end)
+            else:
+                runs.append((s.offset, end))
+        return runs
+
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._bound_arena = None          # loaded tensors are copies: re-bind into the arenas
@@ -65,10 +86,12 @@ class FlatAdamW(torch.optim.Optimizer):
         g = self.param_groups[0]
         self._t += 1
         with torch.cuda.device(flat.device):
-            rc = _lib.lib().pl_adamw_flat(
-                flat.data_ptr(), grads.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), flat.numel(),
-                float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                float(g["weight_decay"]), self._t, float(grad_scale), _lib.current_stream_ptr())
-        _lib.check(rc, "pl_adamw_flat")
+            for lo, hi in self._active_ranges():
+                rc = _lib.lib().pl_adamw_flat(
+                    flat.data_ptr() + 4 * lo, grads.data_ptr() + 4 * lo, self._m.data_ptr() + 4 * lo,
+                    self._v.data_ptr() + 4 * lo, hi - lo,
+                    float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                    float(g["weight_decay"]), self._t, float(grad_scale), _lib.current_stream_ptr())
+                _lib.check(rc, "pl_adamw_flat")
         self._step_tensor.fill_(float(self._t))
         return loss

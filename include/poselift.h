@@ -42,8 +42,13 @@ typedef enum PLStatus {
  *   PL_F32     v_mfma_f32_32x32x2_f32, exact fp32 products                  (meets the 1e-3 mm gate)
  *   PL_BF16    operands rounded to bf16, v_mfma_f32_32x32x16_bf16           (~1 mm MPJPE)
  *   PL_BF16X6  each fp32 operand split into 3 bf16 pieces, 6 bf16 MFMAs per product term:
- *              fp32-grade results (meets the gate too) at 6/16 of the fp32 matrix time; what bench.py runs */
-typedef enum PLDtype { PL_F32 = 0, PL_BF16 = 1, PL_BF16X6 = 2 } PLDtype;
+ *              fp32-grade results (meets the gate too) at 6/16 of the fp32 matrix time
+ *   PL_F16X3   fp32-grade on HALF the matrix work of PL_BF16X6: every operand tensor is written by its producing
+ *              kernel as two fp16 planes, S x = h + l / 2048 (h = fp16(S x), l = fp16((S x - h) 2048), S a per-tensor
+ *              power of two: 22-23 significant bits), and a b = h_a h_b + (h_a l_b + l_a h_b) / 2048 is accumulated on
+ *              two fp32 accumulators by three fp16 MFMAs; the GEMM stages the planes with LDS-DMA and does no split
+ *              work.  Whole 128-tiles with BatchNorm and local statistics; other shapes run PL_BF16X6 arithmetic. */
+typedef enum PLDtype { PL_F32 = 0, PL_BF16 = 1, PL_BF16X6 = 2, PL_F16X3 = 3 } PLDtype;
 
 /* Cross-rank BatchNorm statistics ("SyncBN"; data-parallel extension, SURVEY 8e -- the reference is
  * single-process and has no counterpart).  With PLDesc.sync set and world > 1, training-mode BatchNorm
@@ -325,6 +330,15 @@ int pl_gemm_f32(int layout, const float* A, const float* B, float* C, int64_t M,
 int pl_gemm_arith(int layout, int arith, const float* A, const float* B, float* C, int64_t M,
                   int64_t N, int64_t K, const float* bias, int split_k, float* slabs,
                   void* stream);
+
+/* The same product computed the way the PL_F16X3 / PL_BF16-storage lifter computes its 1024-wide Linears: A and B are
+ * split into 16-bit operand planes in `scratch` (the lifter's own producers -- BatchNorm apply / backward, the weight
+ * split -- write planes directly), then one planes GEMM (LDS-DMA staging, no split work in the loop).  mode PL_F16X3:
+ * scale_a, scale_b are the power-of-two tensor scales (|scale * x| must stay below 65504); mode PL_BF16: one bf16 plane
+ * per operand, scales ignored.  M, N % 128 == 0, K % 32 == 0. */
+size_t pl_gemm_planes_scratch_bytes(int64_t M, int64_t N, int64_t K);
+int pl_gemm_planes(int layout, int mode, const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K,
+                   const float* bias, float scale_a, float scale_b, void* scratch, void* stream);
 
 /* ---- next row N1: fused softmax + integral soft-argmax ----------------------------------- */
 /* Tail of Model_3D.forward  phase4_joined/Model.py:94-133 (ncoord 3, centred 1: (E/dim - 0.5)*2)

@@ -31,8 +31,8 @@ def pkg():
 DEV = "cuda:0"
 
 
-def _model_from_state(pkg, st, hidden, S, p, bn):
-    m = pkg.LinearModel(34, 51, linear_size=hidden, num_stage=S, p_dropout=p, BN=bn).to(DEV)
+def _model_from_state(pkg, st, hidden, S, p, bn, dtype="fp32"):
+    m = pkg.LinearModel(34, 51, linear_size=hidden, num_stage=S, p_dropout=p, BN=bn, compute_dtype=dtype).to(DEV)
     m.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in st.items()})
     return m
 
@@ -183,10 +183,11 @@ def test_bf16x6_planes_pipeline_is_bitwise_the_fragment_split(pkg, layout, M, N,
 
 
 # ---------------------------------------------------------------------------- golden vectors
-@pytest.mark.parametrize("dtype", ["fp32", "bf16x6"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x6", "f16x3"])
 def test_g1_eval_forward_vs_reference(pkg, dtype):
-    """The BASELINE.json gate.  bf16x6 (three-way bf16 split, six MFMAs per product) must meet it
-    too; the batch is tiled to 128 rows so that its whole-tile MFMA path is the one that runs."""
+    """The BASELINE.json gate.  bf16x6 (three-way bf16 split, six MFMAs per product) and f16x3 (two fp16 planes
+    written by the producers, three MFMAs) must meet it too; the batch is tiled to 128 rows so that their
+    whole-tile MFMA paths are the ones that run."""
     g = load_golden("g1_eval_full.npz")
     st = orc.init_state(34, 51, 1024, 2, rng=np.random.default_rng(int(g["weight_seed"])), nontrivial_bn=True)
     m = pkg.LinearModel(34, 51, linear_size=1024, compute_dtype=dtype).to(DEV)
@@ -200,15 +201,18 @@ def test_g1_eval_forward_vs_reference(pkg, dtype):
     assert orc.mpjpe_mm(y, g["y_fp64"]) < 1e-3       # and against the reference run in fp64
 
 
-@pytest.mark.parametrize("tag", ["small", "nobn", "s3", "full"])
+@pytest.mark.parametrize("tag", ["small", "nobn", "s3", "full", "full-f16x3"])
 def test_g2_train_nodrop_vs_reference(pkg, tag):
+    dtype = "fp32"
+    if tag == "full-f16x3":          # B = 128, H = 1024: the fp16-planes GEMM path, against the same reference outputs
+        tag, dtype = "full", "f16x3"
     g = load_golden(f"g2_train_nodrop_{tag}.npz")
     H, S, bn = int(g["hidden"]), int(g["num_stage"]), bool(g["bn"])
     if tag == "full":
         st = orc.init_state(34, 51, H, S, rng=np.random.default_rng(int(g["weight_seed"])), nontrivial_bn=True)
     else:
         st = golden_state(g)
-    m = _model_from_state(pkg, st, H, S, 0.0, bn).train()
+    m = _model_from_state(pkg, st, H, S, 0.0, bn, dtype).train()
     x = _t(g["x"]).requires_grad_(True)
     pred = m(x).reshape(g["pred"].shape)
     loss = pkg.mse_loss(pred, _t(g["t"]))
@@ -699,11 +703,12 @@ def test_flip_tta_eval_vs_oracle(pkg):
         pkg.predict_flip_tta(m.train(), x)
 
 
-def test_bf16x6_mode_is_fp32_grade(pkg):
-    """PL_BF16X6 at the bench size: train fwd/bwd against the oracle with the fp32 tolerances."""
+@pytest.mark.parametrize("dtype", ["bf16x6", "f16x3"])
+def test_bf16x6_mode_is_fp32_grade(pkg, dtype):
+    """PL_BF16X6 / PL_F16X3 at the bench size: train fwd/bwd against the oracle with the fp32 tolerances."""
     torch.manual_seed(0)
     B, H = 1024, 1024
-    m = pkg.LinearModel(34, 51, linear_size=H, p_dropout=0.5, compute_dtype="bf16x6").to(DEV).train()
+    m = pkg.LinearModel(34, 51, linear_size=H, p_dropout=0.5, compute_dtype=dtype).to(DEV).train()
     st = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
     x, y = pkg.synth.synthetic_batch(B, 31, DEV)
     m.manual_seed(8, step=0)

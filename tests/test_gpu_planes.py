@@ -1,0 +1,187 @@
+"""GPU tests of the operand-planes GEMM path (csrc/gemm_planes.h, gemm_planes.hip): PL_F16X3 -- fp32-grade products
+from two fp16 planes per operand written by the producing kernels, three MFMAs per product term -- and the planes
+GEMM itself in all three layouts.  The golden-vector / oracle gates of this mode (g1 eval forward, g2 'full' train
+step, the 1024 x 1024 train step against the oracle) are parametrisations of the tests in test_gpu_parity.py; here:
+the GEMM against fp64, tensor scales, bitwise properties at BASELINE.json's full size, the fallbacks."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lifter_oracle as orc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+PL_BF16, PL_F16X3 = 1, 3
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as ge
+    p = ge.build()
+    assert torch.cuda.is_available()
+    return p
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _planes_gemm(pkg, layout, mode, a, b, bias=None, sa=1.0, sb=1.0):
+    """a [M][K], b [K][N] (numpy) -> C on the device through pl_gemm_planes."""
+    M, K = a.shape
+    N = b.shape[1]
+    A = _t(a if layout != 2 else a.T)
+    Bm = _t(b.T if layout == 0 else b)
+    C = torch.full((M, N), float("nan"), device=DEV)
+    L = pkg.lib()
+    scratch = torch.empty(L.pl_gemm_planes_scratch_bytes(M, N, K), dtype=torch.uint8, device=DEV)
+    bt = _t(bias) if bias is not None else None
+    rc = L.pl_gemm_planes(layout, mode, A.data_ptr(), Bm.data_ptr(), C.data_ptr(), M, N, K,
+                          bt.data_ptr() if bt is not None else None, sa, sb, scratch.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, L.pl_last_error()
+    return C.cpu().numpy()
+
+
+@pytest.mark.parametrize("mode,tol", [(PL_F16X3, 2e-6), (PL_BF16, 2e-2)])
+@pytest.mark.parametrize("layout,M,N,K", [(0, 4096, 1024, 1024), (1, 4096, 1024, 1024), (2, 1024, 1024, 4096),
+                                          (0, 128, 128, 32), (0, 256, 128, 96), (1, 128, 384, 64), (2, 128, 256, 512),
+                                          (2, 256, 128, 160)])
+def test_planes_gemm_vs_fp64(pkg, mode, tol, layout, M, N, K):
+    """Every layout (k-contiguous rows through ds_read_b128, k-strided through the transposing LDS read), K from one
+    tile to 128 tiles (prologue / steady state / tail of the DMA pipeline), with a bias in the epilogue.  f16x3 must
+    stay inside the bound of an fp32 evaluation; bf16 shows bf16-sized error."""
+    rng = np.random.default_rng(M + 3 * N + 7 * K + layout)
+    a = rng.standard_normal((M, K)).astype(np.float32)
+    b = (rng.standard_normal((K, N)) * 0.05).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    got = _planes_gemm(pkg, layout, mode, a, b, bias, sa=1.0, sb=16.0)
+    want = a.astype(np.float64) @ b.astype(np.float64) + bias
+    bound = tol * (np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64) + np.abs(bias)) + 1e-7
+    err = np.abs(got - want)
+    assert np.all(err <= bound), float((err / bound).max())
+    if mode == PL_BF16:
+        assert err.max() > 1e-4                       # really one bf16 product
+
+
+def test_planes_gemm_asymmetric_operands_catch_transposes(pkg):
+    """A = I with an asymmetric B returns B itself: a swapped fragment or accumulator map cannot hide."""
+    n = 256
+    b = (np.arange(n * n, dtype=np.float32).reshape(n, n) % 251) / 16.0
+    eye = np.eye(n, dtype=np.float32)
+    for layout in (0, 1, 2):
+        got = _planes_gemm(pkg, layout, PL_F16X3, eye, b)
+        np.testing.assert_array_equal(got, b)
+        got = _planes_gemm(pkg, layout, PL_F16X3, b, eye)
+        np.testing.assert_array_equal(got, b)
+
+
+@pytest.mark.parametrize("mag,scale", [(3e-7, 2.0 ** 34), (5e-3, 2.0 ** 20), (300.0, 2.0 ** 5)])
+def test_f16x3_tensor_scale_keeps_small_and_large_operands_fp32_grade(pkg, mag, scale):
+    """Gradient-sized (1e-7) and large operands: with the power-of-two tensor scale the fp16 planes carry 22+ bits."""
+    rng = np.random.default_rng(5)
+    a = (rng.standard_normal((256, 512)) * mag).astype(np.float32)
+    b = (rng.standard_normal((512, 128)) * 0.03).astype(np.float32)
+    for layout in (1, 2):
+        got = _planes_gemm(pkg, layout, PL_F16X3, a, b, sa=scale, sb=16.0)
+        want = a.astype(np.float64) @ b.astype(np.float64)
+        bound = 2e-6 * (np.abs(a).astype(np.float64) @ np.abs(b).astype(np.float64))
+        assert np.all(np.abs(got - want) <= bound)
+
+
+def test_planes_gemm_rejects_what_it_cannot_tile(pkg):
+    L = pkg.lib()
+    one = torch.zeros(130 * 64, device=DEV)
+    scratch = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    rc = L.pl_gemm_planes(0, PL_F16X3, one.data_ptr(), one.data_ptr(), one.data_ptr(), 130, 64, 32, None, 1.0, 1.0,
+                          scratch.data_ptr(), None)
+    assert rc != 0 and b"unsupported" in L.pl_last_error()
+    assert L.pl_gemm_planes(0, 2, one.data_ptr(), one.data_ptr(), one.data_ptr(), 128, 128, 32, None, 1.0, 1.0,
+                            scratch.data_ptr(), None) != 0                     # PL_BF16X6 has no planes form
+
+
+@pytest.fixture(scope="module")
+def full(pkg):
+    torch.manual_seed(0)
+    m = pkg.LinearModel(34, 51, linear_size=1024, num_stage=2, p_dropout=0.5, BN=True, compute_dtype="f16x3").to(DEV)
+    x, y = pkg.synth.synthetic_batch(4096, 1234, DEV)
+    return m, x, y
+
+
+def test_f16x3_full_size_properties(pkg, full):
+    """BASELINE.json's size (B = 4096, H = 1024) on the planes path: size-independent properties."""
+    m, x, y = full
+    m.eval()
+    with torch.no_grad():
+        y_all = m(x)
+        y_head = m(x[:1024])
+    # rows are independent and the contraction order does not depend on the batch: bit-exact
+    assert torch.equal(y_all[:1024], y_head)
+    # against the fp32 arithmetic of the same library on the same weights: both inside the gate of each other
+    m32 = pkg.LinearModel(34, 51, linear_size=1024, p_dropout=0.5, compute_dtype="fp32").to(DEV).eval()
+    m32.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        assert orc.mpjpe_mm(y_all.cpu().numpy(), m32(x).cpu().numpy()) < 1e-3
+    # the training step is bitwise reproducible for a fixed (seed, step)
+    outs = []
+    for _ in range(2):
+        m.train().manual_seed(11, step=3)
+        m.zero_grad(set_to_none=True)
+        sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+        pred = m(x)
+        pkg.mse_loss(pred.reshape(-1, 17, 3), y).backward()
+        outs.append((pred.detach().clone(), m.flat_grads.clone()))
+        m.load_state_dict(sd0)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert torch.isfinite(outs[0][1]).all()
+    # BatchNorm really normalised over the batch
+    ws = m.last_workspace
+    z = m.workspace_view(ws, 0, 2).double()
+    mean, rstd = m.workspace_view(ws, 3, 2).double(), m.workspace_view(ws, 4, 2).double()
+    zhat = (z - mean) * rstd
+    assert zhat.mean(0).abs().max() < 1e-5 and (zhat.var(0, unbiased=False) - 1).abs().max() < 1e-3
+    # odd hidden layers feed GEMMs only: they exist as fp16 planes, the fp32 view says so
+    with pytest.raises(pkg.PoseliftError, match="planes"):
+        m.workspace_view(ws, 1, 1)
+    assert m.workspace_view(ws, 1, 2).shape == (4096, 1024)
+    # gradients of the planes path against the fp32-MFMA path of the same library, same dropout stream
+    m32.train().manual_seed(11, step=3)
+    m32.zero_grad(set_to_none=True)
+    pkg.mse_loss(m32(x).reshape(-1, 17, 3), y).backward()
+    g16, g32 = outs[0][1].double(), m32.flat_grads.double()
+    assert float((g16 - g32).norm() / g32.norm()) < 2e-4
+
+
+def test_f16x3_gradient_scale_invariance(pkg, full):
+    """The dz planes are range-scaled per layer from a bound computed in BatchNorm-backward pass 1: a loss 1e4 x
+    larger or smaller gives gradients 1e4 x larger or smaller (to fp32 round-off), never an fp16 overflow or flush."""
+    m, x, y = full
+    grads = {}
+    for fac in (1.0, 1e4, 1e-4):
+        m.train().manual_seed(5, step=1)
+        m.zero_grad(set_to_none=True)
+        (pkg.mse_loss(m(x).reshape(-1, 17, 3), y) * fac).backward()
+        grads[fac] = m.flat_grads.double().clone()
+        assert torch.isfinite(grads[fac]).all()
+    for fac in (1e4, 1e-4):
+        rel = float((grads[fac] / fac - grads[1.0]).norm() / grads[1.0].norm())
+        assert rel < 1e-5, (fac, rel)
+
+
+@pytest.mark.parametrize("B,bn", [(100, True), (4097, True), (256, False)])
+def test_f16x3_falls_back_to_the_fp32_grade_kernels_off_the_tile_grid(pkg, B, bn):
+    """Ragged batches and BN=False do not meet the planes path's conditions: the same request runs PL_BF16X6 / fp32-MFMA
+    arithmetic on the round-1 kernels (never a lower precision, never a CPU path) and still matches the oracle."""
+    torch.manual_seed(1)
+    H = 256
+    m = pkg.LinearModel(34, 51, linear_size=H, p_dropout=0.0, BN=bn, compute_dtype="f16x3").to(DEV).train()
+    st = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    x, y = pkg.synth.synthetic_batch(B, 3, DEV)
+    pred = m(x).reshape(B, 17, 3)
+    pkg.mse_loss(pred, y).backward()
+    opred, cache = orc.forward(st, x.cpu().numpy(), num_stage=2, train=True, use_bn=bn, p_dropout=0.0)
+    p64, _ = orc.forward({k: v.copy() for k, v in st.items()}, x.cpu().numpy(), num_stage=2, train=True, use_bn=bn,
+                         p_dropout=0.0, dtype=np.float64)
+    e_gpu, e_ref = orc.mpjpe_mm(pred.detach().cpu().numpy(), p64), orc.mpjpe_mm(opred, p64)
+    assert e_gpu <= 3 * e_ref + 1e-4, (e_gpu, e_ref)
+    assert torch.isfinite(m.flat_grads).all()

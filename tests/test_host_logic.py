@@ -107,6 +107,29 @@ def test_same_seed_gives_reference_initialisation(pkg):
         assert abs(float(sd[k].double().sum()) - float(g["sum:" + k])) < 1e-6 * max(1.0, abs(float(g["sum:" + k])))
 
 
+def test_weight_init_vs_reference_golden(pkg):
+    """weight_init (baselineModel.py:10-12, applied as main.py:396 `model.apply(weight_init)`): golden g10 = the
+    reference's function run under a seed.  Linear weights are re-drawn Kaiming-normal (the same stream: bit-equal),
+    biases and BatchNorm tensors stay untouched, and the parameters stay views into the flat arena."""
+    g = load_golden("g10_weight_init.npz")
+    torch.manual_seed(int(g["model_seed"]))
+    m = pkg.LinearModel(34, 51, p_dropout=0.5, linear_size=int(g["hidden"]), BN=True)
+    for k, v in m.state_dict().items():
+        np.testing.assert_array_equal(v.numpy(), g["before:" + k], err_msg=k)
+    torch.manual_seed(int(g["init_seed"]))
+    m.apply(pkg.weight_init)
+    changed = 0
+    for k, v in m.state_dict().items():
+        np.testing.assert_array_equal(v.numpy(), g["after:" + k], err_msg=k)
+        changed += int(not np.array_equal(g["after:" + k], g["before:" + k]))
+    assert changed == 6                       # the six nn.Linear weights, nothing else
+    assert m._arenas_intact()
+    s = m._slots[0]
+    assert torch.equal(m.flat_params[s.offset:s.offset + s.numel].view(s.shape), m.w1.weight)
+    w = torch.from_numpy(g["after:linear_stages.0.w1.weight"])
+    assert abs(float(w.std()) - (2.0 / w.shape[1]) ** 0.5) < 0.05 * (2.0 / w.shape[1]) ** 0.5   # fan_in, gain sqrt(2)
+
+
 def test_no_cpu_fallback(pkg):
     m = pkg.LinearModel(34, 51, linear_size=64)
     with pytest.raises(pkg.PoseliftError, match="no CPU path"):
@@ -195,16 +218,25 @@ def test_feeder_epoch_indices_partition_the_table():
     N, bs, world = 1003, 64, 3
     per_rank = [data.epoch_indices(N, bs, epoch=2, seed=5, rank=r, world=world) for r in range(world)]
     allidx = torch.cat([torch.cat(b) for b in per_rank])
-    assert sorted(allidx.tolist()) == list(range(N))
+    tail = N % (bs * world)
+    assert len(set(allidx.tolist())) == allidx.numel() == N - tail % world      # the tail is trimmed to equal shards
     n_batches = len(per_rank[0])
-    assert n_batches == (N + bs * world - 1) // (bs * world)
+    assert n_batches == (N + bs * world - 1) // (bs * world) == data.epoch_steps(N, bs, world=world)
+    assert all(len(per_rank[r]) == n_batches for r in range(world))             # same number of steps on every rank
     for k in range(n_batches - 1):
         assert all(per_rank[r][k].numel() == bs for r in range(world))
-    assert sum(per_rank[r][-1].numel() for r in range(world)) == N - (n_batches - 1) * bs * world
-    # one process sees the same global batches as the ranks together
+    assert all(per_rank[r][-1].numel() == tail // world for r in range(world))
+    # one process sees the same global batches as the ranks together (up to the trimmed rows of the tail)
     whole = data.epoch_indices(N, bs * world, epoch=2, seed=5)
     for k in range(n_batches):
-        assert torch.equal(whole[k], torch.cat([per_rank[r][k] for r in range(world) if k < len(per_rank[r])]))
+        together = torch.cat([per_rank[r][k] for r in range(world)])
+        assert torch.equal(whole[k][:together.numel()], together)
+    # a tail that would leave a rank with fewer than two rows (BatchNorm raises on one row; an empty shard would skip
+    # the collective the other ranks enter) is dropped on EVERY rank
+    for n_small in (bs * world * 2 + 1, bs * world * 2 + world, bs * world * 2 + 2 * world - 1):
+        counts = [len(data.epoch_indices(n_small, bs, epoch=0, seed=1, rank=r, world=world)) for r in range(world)]
+        assert counts == [2] * world == [data.epoch_steps(n_small, bs, world=world)] * world
+    assert data.epoch_steps(bs * world * 2 + 2 * world, bs, world=world) == 3
     other = data.epoch_indices(N, bs, epoch=3, seed=5, rank=0, world=world)
     assert not torch.equal(other[0], per_rank[0][0])
     dropped = data.epoch_indices(N, bs, epoch=2, seed=5, rank=0, world=world, drop_last=True)

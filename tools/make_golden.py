@@ -80,7 +80,56 @@ def sample_idx(rng, n, k=1024):
     return np.sort(rng.choice(n, size=min(k, n), replace=False)).astype(np.int64)
 
 
+def _ref_losses():
+    """phase5_loop/losses.py imported as-is (pure torch)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_losses", "/root/reference/phase5_loop/losses.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def golden_g5(stats):
+    """G5: loss_MPJPE + epoch reduction.  train_1.py cannot be imported (cv2 / wandb / torchvision absent), but the
+    function at train_1.py:19-23 is byte-identical to phase5_loop/losses.py:3-7, which CAN: the metric below is the
+    reference's own function run on CPU; only the two-line epoch reduction (train_1.py:100-104) is restated."""
+    rng = np.random.default_rng(501)
+    _, a = synth_batch(rng, 48, stats)
+    _, b = synth_batch(rng, 48, stats)
+    metric = _ref_losses().loss_MPJPE(torch.from_numpy(a), torch.from_numpy(b))
+    epoch = torch.mean((metric / 48)[1:17]) * (17 / 16) * 1000
+    np.savez(os.path.join(OUT, "g5_mpjpe.npz"), pred=a, tgt=b, metric=metric.numpy(),
+             epoch_mm=np.float64(epoch.item()))
+
+
+def golden_g10():
+    """G10: the reference's weight_init (baselineModel.py:10-12) applied as main.py:396 does, under a seed: what it
+    touches (Linear weights: re-drawn, Kaiming normal) and what it leaves alone (biases, BatchNorm tensors)."""
+    torch.manual_seed(11)
+    m = ref.LinearModel(34, 51, p_dropout=0.5, linear_size=64, BN=True)
+    before = state_of(m)
+    torch.manual_seed(12)
+    m.apply(ref.weight_init)
+    rec = {}
+    for k, v in state_of(m).items():
+        rec["before:" + k] = before[k]
+        rec["after:" + k] = v
+    np.savez_compressed(os.path.join(OUT, "g10_weight_init.npz"), model_seed=11, init_seed=12, hidden=64, **rec)
+
+
 def main():
+    only = None
+    if "--only" in sys.argv:
+        only = set(sys.argv[sys.argv.index("--only") + 1].split(","))
+    if only is not None:
+        stats = h36m_stats()
+        if "g5" in only:
+            golden_g5(stats)
+        if "g10" in only:
+            golden_g10()
+        for f in sorted(os.listdir(OUT)):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+        return
     stats = h36m_stats()
     np.savez(os.path.join(OUT, "h36m_stats.npz"), **stats)
 
@@ -181,17 +230,10 @@ def main():
         rec["final:" + k] = v
     np.savez_compressed(os.path.join(OUT, "g4_adamw_small.npz"), **rec)
 
-    # ---- G5: loss_MPJPE (train_1.py:19-23) + epoch reduction (:100-104) ----------------
-    sys.path.insert(0, ROOT)
-    rng = np.random.default_rng(501)
-    _, a = synth_batch(rng, 48, stats)
-    _, b = synth_batch(rng, 48, stats)
-    ta, tb = torch.from_numpy(a), torch.from_numpy(b)
-    # restated from train_1.py:19-23 with stock torch ops (train_1.py itself needs cv2/wandb)
-    metric = torch.sum(torch.norm(ta - tb, dim=-1), dim=0)
-    epoch = torch.mean((metric / 48)[1:17]) * (17 / 16) * 1000
-    np.savez(os.path.join(OUT, "g5_mpjpe.npz"), pred=a, tgt=b, metric=metric.numpy(),
-             epoch_mm=np.float64(epoch.item()))
+    # ---- G5: loss_MPJPE (the reference's own function) + epoch reduction ------------------
+    golden_g5(stats)
+    # ---- G10: weight_init ------------------------------------------------------------------
+    golden_g10()
 
     # ---- G7: initial weights of the reference under torch.manual_seed(0) -----------------
     torch.manual_seed(0)
@@ -203,10 +245,7 @@ def main():
             rec["sum:" + k] = np.float64(v.double().sum().item())
     np.savez(os.path.join(OUT, "g7_init_seed0.npz"), **rec)
     # ---- G8: TriangleLoss of the phase5 cycle step (phase5_loop/losses.py, imported as-is) ---
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("ref_losses", "/root/reference/phase5_loop/losses.py")
-    ref_losses = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(ref_losses)
+    ref_losses = _ref_losses()
     rng = np.random.default_rng(808)
     B = 24
     rec = {}
