@@ -40,6 +40,7 @@ class PLDesc(ctypes.Structure):
         ("reserved", ctypes.c_int32),
         ("params", ctypes.c_void_p), ("bn_running", ctypes.c_void_p), ("bn_batches", ctypes.c_void_p),
         ("sync", ctypes.POINTER(PLSync)),
+        ("step_dev", ctypes.c_void_p),
     ]
 
 
@@ -73,6 +74,8 @@ SIGNATURES = {
     "pl_mpjpe_accum": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P, _P]),
     "pl_adamw_flat": (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_float, _c.c_float, _c.c_float,
                                  _c.c_float, _c.c_float, _c.c_int64, _c.c_float, _P]),
+    "pl_adamw_flat_dev": (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _P, _c.c_float, _c.c_float, _c.c_float,
+                                     _c.c_float, _c.c_int64, _P, _c.c_float, _P]),
     "pl_flip_pose": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P]),
     "pl_softargmax3d_nhwc_fwd": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _P]),
     "pl_softargmax3d_nhwc_bwd": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P]),

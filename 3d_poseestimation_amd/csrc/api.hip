@@ -66,10 +66,15 @@ int sync_gather(const PLDesc* d, float* base, int64_t floats_per_rank, hipStream
 // (gemm_planes.hip).  That path wants whole 128x128 tiles, BatchNorm (its backward pass 1 supplies the range bound
 // of dz) and local statistics; anything else runs the same fp32-grade arithmetic class on the round-1 kernels
 // (PL_BF16X6: fp32 operands split inside the GEMM) -- never a lower precision, never the CPU.
-inline bool planes_path(const PLDesc* d, int64_t B) {
-  return d->dtype == PL_F16X3 && d->bn && sync_world(d) == 1 && d->hidden % 128 == 0 && B % 128 == 0 &&
-         d->num_stage >= 1 && B * (int64_t)d->hidden * 4 < (1ll << 30);
+// PL_BF16 takes the same path with ONE bf16 plane per tensor (kind 1): bf16 STORAGE of the GEMM operands
+// (activations, dz, weight shadow), no scales -- bf16 has fp32's exponent range.
+inline int planes_kind(const PLDesc* d, int64_t B) {       // PlaneOut::kind of the operand planes, 0 = not on that path
+  const bool ok = d->bn && sync_world(d) == 1 && d->hidden % 128 == 0 && B % 128 == 0 && d->num_stage >= 1 &&
+                  B * (int64_t)d->hidden * 4 < (1ll << 30);
+  if (!ok) return 0;
+  return d->dtype == PL_F16X3 ? 2 : (d->dtype == PL_BF16 ? 1 : 0);
 }
+inline bool planes_path(const PLDesc* d, int64_t B) { return planes_kind(d, B) != 0; }
 inline int arith_of(const PLDesc* d) { return d->dtype == PL_F16X3 ? (int)PL_BF16X6 : d->dtype; }
 
 struct ParamLayout {
@@ -126,6 +131,7 @@ struct Ws {
   size_t act_bytes, bits_bytes;
   // PL_F16X3 planes path
   bool planes;
+  int pkind;                          // PlaneOut::kind: 2 fp16 pair (PL_F16X3), 1 bf16 (PL_BF16)
   std::vector<size_t> actp, wp;       // activation planes of layers 0..L-2, weight planes of layers 1..L-1
   std::vector<char> act_f32;          // is the fp32 activation of layer l materialised?
   size_t dzp, amax, dzscale;
@@ -145,7 +151,8 @@ Ws plan(const PLDesc* d, int64_t B) {
   };
   w.act_bytes = (size_t)B * H * sizeof(float);
   w.bits_bytes = (size_t)B * bitmap_words_per_row(H) * sizeof(uint64_t);
-  w.planes = planes_path(d, B);
+  w.pkind = planes_kind(d, B);
+  w.planes = w.pkind != 0;
   for (int l = 0; l < w.L; ++l) {
     // planes path: a layer's output is kept in fp32 only where something reads it as fp32 -- the skip connection
     // (even layers) and the output Linear (last layer); the odd layers feed GEMMs only and exist as planes
@@ -240,17 +247,20 @@ inline unsigned short* u16(void* ws, size_t off) { return reinterpret_cast<unsig
 int split_weight_planes(const PLDesc* d, const ParamLayout& P, const Ws& w, void* ws, hipStream_t s) {
   const int64_t n = (int64_t)d->hidden * d->hidden;
   for (int l = 1; l < w.L; ++l) {
-    PlaneOut po = {u16(ws, w.wp[l]), u16(ws, w.wp[l]) + n, kWeightPlaneScale, nullptr, 2};
+    PlaneOut po = {u16(ws, w.wp[l]), u16(ws, w.wp[l]) + n, kWeightPlaneScale, nullptr, w.pkind};
     PL_TRY(launch_split_planes(d->params + P.off[4 * l], n, po, s));
   }
   return PL_OK;
 }
 
-PlanesGemmArgs planes_args(const unsigned short* A, int64_t a_plane, int lda, const unsigned short* Bm, int64_t b_plane,
-                           int ldb, float* C, int M, int N, int K, float out_scale, const float* dyn_inv) {
+PlanesGemmArgs planes_args(int pkind, const unsigned short* A, int64_t a_plane, int lda, const unsigned short* Bm,
+                           int64_t b_plane, int ldb, float* C, int M, int N, int K, float out_scale,
+                           const float* dyn_inv) {
   PlanesGemmArgs g = {};
   g.A = A; g.B = Bm; g.a_plane = a_plane; g.b_plane = b_plane; g.lda = lda; g.ldb = ldb;
-  g.mode = 2; g.out_scale = out_scale; g.dyn_inv = dyn_inv;
+  g.mode = pkind == 2 ? 2 : 0;                    // plp::kF16x3 / plp::kBf16
+  g.out_scale = pkind == 2 ? out_scale : 1.0f;
+  g.dyn_inv = pkind == 2 ? dyn_inv : nullptr;
   g.e.C = C; g.e.M = M; g.e.N = N; g.e.K = K; g.e.ldc = N; g.e.split_k = 1;
   return g;
 }
@@ -328,7 +338,7 @@ extern "C" int pl_workspace_view(const PLDesc* d, int64_t B, int which, int64_t 
     case 0: *off = w.z[layer]; *size = w.act_bytes; break;
     case 1:
       if (!w.act_f32[layer])
-        PL_FAIL(PL_EINVAL, "pl_workspace_view: PL_F16X3 keeps the output of hidden layer %lld as fp16 planes only", (long long)layer);
+        PL_FAIL(PL_EINVAL, "pl_workspace_view: the planes path keeps the output of hidden layer %lld as 16-bit planes only", (long long)layer);
       *off = w.act[layer]; *size = w.act_bytes; break;
     case 2: *off = w.bits[layer]; *size = w.bits_bytes; break;
     case 3: *off = w.mean[layer]; *size = hb; break;
@@ -372,7 +382,7 @@ extern "C" int pl_lifter_fwd_eval(const PLDesc* d, const float* x, float* y, int
     g.relu = 1;
     if (l >= 2 && (l % 2) == 0) g.resid = f32(ws, w.act[l - 2]);
     if (w.planes && l > 0) {
-      PlanesGemmArgs pg = planes_args(u16(ws, w.actp[l - 1]), BH, H, u16(ws, w.wp[l]), (int64_t)H * H, H, out, (int)B, H, H,
+      PlanesGemmArgs pg = planes_args(w.pkind, u16(ws, w.actp[l - 1]), BH, H, u16(ws, w.wp[l]), (int64_t)H * H, H, out, (int)B, H, H,
                                       1.0f / (kActPlaneScale * kWeightPlaneScale), nullptr);
       pg.e.col_scale = g.col_scale; pg.e.col_shift = g.col_shift; pg.e.relu = 1; pg.e.resid = g.resid;
       PL_TRY(launch_gemm_planes(kNT, pg, s));
@@ -380,7 +390,7 @@ extern "C" int pl_lifter_fwd_eval(const PLDesc* d, const float* x, float* y, int
       PL_TRY(launch_gemm_f32(kNT, g, s));
     }
     if (w.planes && l + 1 < w.L) {
-      PlaneOut po = {u16(ws, w.actp[l]), u16(ws, w.actp[l]) + BH, kActPlaneScale, nullptr, 2};
+      PlaneOut po = {u16(ws, w.actp[l]), u16(ws, w.actp[l]) + BH, kActPlaneScale, nullptr, w.pkind};
       PL_TRY(launch_split_planes(out, BH, po, s));
     }
     a_in = out;
@@ -425,7 +435,7 @@ extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, in
     if (skinny) {
       PL_TRY(launch_skinny_wide_out(a_in, ly.W, ly.b, g.C, (int)B, ly.K, H, false, g.stat_sum, g.stat_m2, s));
     } else if (w.planes && l > 0) {
-      PlanesGemmArgs pg = planes_args(u16(ws, w.actp[l - 1]), BH, H, u16(ws, w.wp[l]), (int64_t)H * H, H, g.C, (int)B, H, H,
+      PlanesGemmArgs pg = planes_args(w.pkind, u16(ws, w.actp[l - 1]), BH, H, u16(ws, w.wp[l]), (int64_t)H * H, H, g.C, (int)B, H, H,
                                       1.0f / (kActPlaneScale * kWeightPlaneScale), nullptr);
       pg.e.bias = ly.b; pg.e.stat_sum = g.stat_sum; pg.e.stat_m2 = g.stat_m2;
       PL_TRY(launch_gemm_planes(kNT, pg, s));
@@ -444,11 +454,11 @@ extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, in
     }
     const float* resid = (l >= 2 && (l % 2) == 0) ? f32(ws, w.act[l - 2]) : nullptr;
     PlaneOut po = {nullptr, nullptr, kActPlaneScale, nullptr, 0};
-    if (w.planes && l + 1 < w.L) { po.h = u16(ws, w.actp[l]); po.l = po.h + BH; po.kind = 2; }
+    if (w.planes && l + 1 < w.L) { po.h = u16(ws, w.actp[l]); po.l = po.h + BH; po.kind = w.pkind; }
     float* act = w.act_f32[l] ? f32(ws, w.act[l]) : nullptr;
     PL_TRY(launch_bn_apply(g.C, scale, shift, resid, act, u64(ws, w.bits[l]), (int)B, H,
                            d->p_dropout, seed, step, l,
-                           inject_keep ? inject_keep + (size_t)l * inj_stride : nullptr, s, &po));
+                           inject_keep ? inject_keep + (size_t)l * inj_stride : nullptr, s, &po, d->step_dev));
     a_in = act;
   }
   return gemm_out_layer(a_in, d->params + P.off[4 * w.L], d->params + P.off[4 * w.L + 1], y, (int)B,
@@ -512,24 +522,24 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
     const uint64_t* bits = u64(ws, w.bits[l]);
     const float* z = f32(ws, w.z[l]);
     const bool pl_layer = w.planes && l > 0;       // this layer's dz feeds the planes GEMM pair
-    float* dzs = pl_layer ? f32(ws, w.dzscale) + 2 * l : nullptr;
+    float* dzs = (pl_layer && w.pkind == 2) ? f32(ws, w.dzscale) + 2 * l : nullptr;   // fp16 planes of dz are range-scaled
     if (d->bn) {
       // (pass 1 was tried inside the producing GEMM's epilogue: +17 us per GEMM for the 7.5 us
       //  kernel it removed -- every tile finishes at once, so epilogue work is pure tail)
       float* stat = f32(ws, w.stat);
       float* mine = stat + (size_t)sync_rank(d) * 2 * w.RC * H;
       PL_TRY(launch_bn_bwd_reduce(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), kscale, Bi, H,
-                                  mine, mine + (size_t)w.RC * H, s, 0, pl_layer ? f32(ws, w.amax) : nullptr));
+                                  mine, mine + (size_t)w.RC * H, s, 0, dzs ? f32(ws, w.amax) : nullptr));
       PL_TRY(sync_gather(d, stat, (int64_t)2 * w.RC * H, s));
       PL_TRY(launch_bn_bwd_finalize(stat, w.RC, sync_world(d), sync_rank(d), Bi, H, ly.gamma,
                                     f32(ws, w.rstd[l]), f32(ws, w.coef), ly.ggamma, ly.gbeta, s,
-                                    pl_layer ? f32(ws, w.amax) : nullptr, n_amax, dzs));
+                                    dzs ? f32(ws, w.amax) : nullptr, n_amax, dzs));
     } else {
       PL_TRY(launch_fill(ly.ggamma, H, 0.f, s));
       PL_TRY(launch_fill(ly.gbeta, H, 0.f, s));
     }
     PlaneOut dzo = {nullptr, nullptr, 1.0f, dzs, 0};
-    if (pl_layer) { dzo.h = u16(ws, w.dzp); dzo.l = dzo.h + BH; dzo.kind = 2; }
+    if (pl_layer) { dzo.h = u16(ws, w.dzp); dzo.l = dzo.h + BH; dzo.kind = w.pkind; }
     PL_TRY(launch_bn_bwd_dz(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), f32(ws, w.coef), kscale,
                             d->bn, Bi, H, pl_layer ? nullptr : DZ, f32(ws, w.dbpart[l]), s, 0, &dzo));
     jpart.push_back(f32(ws, w.dbpart[l])); jout.push_back(ly.gb); jR.push_back(w.RC); jH.push_back(H);
@@ -537,11 +547,11 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
     if (pl_layer) {
       // dX = dz W (NN) and dW = dz^T a (TN, split-K slabs) on the planes: one launch
       const int splits = tn_splits(H, H, Bi);
-      PlanesGemmArgs nn = planes_args(u16(ws, w.dzp), BH, H, u16(ws, w.wp[l]), (int64_t)H * H, H,
-                                      (l % 2 == 1) ? GA : GB, Bi, H, H, 1.0f / kWeightPlaneScale, dzs + 1);
+      PlanesGemmArgs nn = planes_args(w.pkind, u16(ws, w.dzp), BH, H, u16(ws, w.wp[l]), (int64_t)H * H, H,
+                                      (l % 2 == 1) ? GA : GB, Bi, H, H, 1.0f / kWeightPlaneScale, dzs ? dzs + 1 : nullptr);
       if (l % 2 == 1) nn.e.addend = GA;
-      PlanesGemmArgs tn = planes_args(u16(ws, w.dzp), BH, H, u16(ws, w.actp[l - 1]), BH, H,
-                                      splits > 1 ? slabs : ly.gW, H, H, Bi, 1.0f / kActPlaneScale, dzs + 1);
+      PlanesGemmArgs tn = planes_args(w.pkind, u16(ws, w.dzp), BH, H, u16(ws, w.actp[l - 1]), BH, H,
+                                      splits > 1 ? slabs : ly.gW, H, H, Bi, 1.0f / kActPlaneScale, dzs ? dzs + 1 : nullptr);
       tn.e.split_k = splits;
       PL_TRY(launch_gemm_planes_pair(nn, tn, s));
       if (splits > 1) PL_TRY(launch_reduce_slabs(slabs, splits, (int64_t)H * H, ly.gW, s));
@@ -691,7 +701,8 @@ extern "C" int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const fl
   const int L = 1 + 2 * d->num_stage;
   if (hi == L) {
     PL_TRY(pl_lifter_fwd_train(d, x, y, B, ws, ws_bytes, seed, step, nullptr, stream));
-    PL_TRY(pl_mse_fwd_bwd(y, target, B * d->out_dim, 1.0f, dy, loss, f32(ws, w.mse), stream));
+    PL_TRY(mse_fwd_bwd_tick(y, target, B * d->out_dim, 1.0f, dy, loss, f32(ws, w.mse),
+                            const_cast<uint64_t*>(d->step_dev), stream));
   }
   return bwd_impl(d, x, dy, B, ws, ws_bytes, nullptr, grads, stream, hi == L, hi == L ? L - 1 : hi, lo);
 }

@@ -270,8 +270,15 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(
     const float* __restrict__ z, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* resid, float* act, uint64_t* __restrict__ bits, int B, int H, int mode,
     uint32_t thr, float kscale, uint32_t k0, uint32_t k1, uint32_t c3, uint32_t layer,
-    const uint64_t* __restrict__ inject, int Hc, PlaneOut po) {
+    const uint64_t* __restrict__ inject, int Hc, PlaneOut po, const uint64_t* __restrict__ step_dev,
+    uint32_t seed_hi) {
   const PlaneDst pd = plane_dst(po);
+  if (step_dev) {
+    // graph replay: the step number is base (baked into c3 / k1's slot as the low / high word) + the device counter
+    const uint64_t step = (((uint64_t)k1 << 32) | c3) + step_dev[0];
+    c3 = (uint32_t)step;
+    k1 = seed_hi ^ (uint32_t)(step >> 32);
+  }
   // Hc: real columns behind the H virtual ones (bn_colstats_kernel); Hc == H for the lifter
   // mode: 0 keep all, 1 philox, 2 injected bitmap, 3 drop all; + 8: no ReLU (BatchNorm alone; bitmap all ones)
   const bool norelu = (mode & 8) != 0;
@@ -652,12 +659,17 @@ __global__ __launch_bounds__(NTHR) void mse_partial_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(NTHR) void mse_final_kernel(const float* __restrict__ part, int np,
-                                                         float inv_n, float* __restrict__ loss) {
+                                                         float inv_n, float* __restrict__ loss, uint64_t* tick) {
   __shared__ float sm[4];
   float acc = 0.f;
   for (int i = threadIdx.x; i < np; i += blockDim.x) acc += part[i];
   const float t = block_sum(acc, sm);
-  if (threadIdx.x == 0) loss[0] = t * inv_n;
+  if (threadIdx.x == 0) {
+    loss[0] = t * inv_n;
+    // graph replay: one training step is complete as far as its readers of the counter go (every dropout kernel of the
+    // forward ran before this kernel, AdamW runs after it)
+    if (tick) tick[0] += 1;
+  }
 }
 
 // ---- L1(mean) terms, forward + backward, several (a, b) pairs per launch -----------------------
@@ -788,6 +800,33 @@ struct AdamWK {
   float eps, gscale;
 };
 
+// What the step is given; the per-step constants are derived ON THE DEVICE (every thread, once: two double pow),
+// so that a captured graph advances them by itself: t = t_base + *t_dev, lr = *lr_dev when the pointers are set
+// (the eager call passes them by value through the same code, hence the same bits).
+struct AdamWIn {
+  float lr, beta1, beta2, eps, wd, gscale;
+  int64_t t;
+  const float* lr_dev;
+  const uint64_t* t_dev;
+};
+
+__device__ __forceinline__ AdamWK adamw_consts(const AdamWIn& a) {
+  const double lr = a.lr_dev ? (double)a.lr_dev[0] : (double)a.lr;
+  const double t = (double)(a.t + (a.t_dev ? (int64_t)a.t_dev[0] : 0));
+  const double bc1 = 1.0 - pow((double)a.beta1, t);
+  const double bc2 = 1.0 - pow((double)a.beta2, t);
+  AdamWK k;
+  k.decay = (float)(1.0 - lr * (double)a.wd);
+  k.one_m_b1 = (float)(1.0 - (double)a.beta1);
+  k.b2 = a.beta2;
+  k.one_m_b2 = (float)(1.0 - (double)a.beta2);
+  k.step_size = (float)(lr / bc1);
+  k.bc2_sqrt = (float)sqrt(bc2);
+  k.eps = a.eps;
+  k.gscale = a.gscale;
+  return k;
+}
+
 __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v, const AdamWK& k) {
   g *= k.gscale;
   p *= k.decay;
@@ -799,7 +838,8 @@ __device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v,
 
 __global__ __launch_bounds__(NTHR) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                      float* __restrict__ m, float* __restrict__ v,
-                                                     int64_t n, AdamWK k, int vec) {
+                                                     int64_t n, AdamWIn in, int vec) {
+  const AdamWK k = adamw_consts(in);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (vec) {
@@ -845,7 +885,8 @@ int launch_bn_finalize(const float* stat, int G, int world, int B, int H,
 
 int launch_bn_apply(const float* z, const float* scale, const float* shift, const float* resid,
                     float* act, uint64_t* bits, int B, int H, float p, uint64_t seed, uint64_t step,
-                    int layer, const uint64_t* inject_keep, hipStream_t s, const PlaneOut* planes) {
+                    int layer, const uint64_t* inject_keep, hipStream_t s, const PlaneOut* planes,
+                    const uint64_t* step_dev) {
   int mode = 0;
   const PlaneOut po = planes ? *planes : PlaneOut{nullptr, nullptr, 1.f, nullptr, 0};
   if (!act && !po.kind) PL_FAIL(PL_EINVAL, "bn_apply: nothing to write");
@@ -856,11 +897,13 @@ int launch_bn_apply(const float* z, const float* scale, const float* shift, cons
     kscale = 1.0f / (1.0f - p);
   }
   const uint32_t thr = dropout_threshold(p);
-  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32);
+  // step_dev: the kernel forms the key itself from (step + *step_dev); it receives the step's two words instead
+  const uint32_t k0 = (uint32_t)seed, seed_hi = (uint32_t)(seed >> 32);
+  const uint32_t k1 = step_dev ? (uint32_t)(step >> 32) : seed_hi ^ (uint32_t)(step >> 32);
   const int strips = (H + 255) / 256;
   dim3 grid(strips, stream_rows_grid(B, strips));
   hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NTHR), 0, s, z, scale, shift, resid, act, bits, B, H,
-                     mode, thr, kscale, k0, k1, (uint32_t)step, (uint32_t)layer, inject_keep, H, po);
+                     mode, thr, kscale, k0, k1, (uint32_t)step, (uint32_t)layer, inject_keep, H, po, step_dev, seed_hi);
   PL_CHECK_LAUNCH("bn_apply");
   return PL_OK;
 }
@@ -1011,8 +1054,18 @@ static int mse_blocks(int64_t n) {
 
 extern "C" size_t pl_mse_scratch_bytes(int64_t n) { return (size_t)mse_blocks(n > 0 ? n : 1) * sizeof(float); }
 
+namespace pl {
+int mse_fwd_bwd_tick(const float* pred, const float* tgt, int64_t n, float grad_scale, float* dpred, float* loss_out,
+                     void* scratch, uint64_t* tick, void* stream);
+}
+
 extern "C" int pl_mse_fwd_bwd(const float* pred, const float* tgt, int64_t n, float grad_scale,
                               float* dpred, float* loss_out, void* scratch, void* stream) {
+  return mse_fwd_bwd_tick(pred, tgt, n, grad_scale, dpred, loss_out, scratch, nullptr, stream);
+}
+
+int pl::mse_fwd_bwd_tick(const float* pred, const float* tgt, int64_t n, float grad_scale, float* dpred,
+                         float* loss_out, void* scratch, uint64_t* tick, void* stream) {
   if (!pred || !tgt || !loss_out || !scratch) PL_FAIL(PL_EINVAL, "pl_mse_fwd_bwd: null pointer");
   if (n <= 0) PL_FAIL(PL_ESHAPE, "pl_mse_fwd_bwd: n = %lld", (long long)n);
   hipStream_t s = (hipStream_t)stream;
@@ -1022,7 +1075,7 @@ extern "C" int pl_mse_fwd_bwd(const float* pred, const float* tgt, int64_t n, fl
                      (float*)scratch);
   PL_CHECK_LAUNCH("mse_partial");
   hipLaunchKernelGGL(mse_final_kernel, dim3(1), dim3(NTHR), 0, s, (const float*)scratch, nb,
-                     1.0f / (float)n, loss_out);
+                     1.0f / (float)n, loss_out, tick);
   PL_CHECK_LAUNCH("mse_final");
   return PL_OK;
 }
@@ -1053,30 +1106,32 @@ extern "C" int pl_mpjpe_accum(const float* pred, const float* tgt, int64_t B, in
   return PL_OK;
 }
 
-extern "C" int pl_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr,
-                             float beta1, float beta2, float eps, float weight_decay, int64_t t,
-                             float grad_scale, void* stream) {
+static int adamw_launch(float* p, const float* g, float* m, float* v, int64_t n, const AdamWIn& in, void* stream) {
   if (!p || !g || !m || !v) PL_FAIL(PL_EINVAL, "pl_adamw_flat: null pointer");
-  if (n <= 0 || t < 1) PL_FAIL(PL_ESHAPE, "pl_adamw_flat: n=%lld t=%lld", (long long)n, (long long)t);
-  AdamWK k;
-  const double bc1 = 1.0 - pow((double)beta1, (double)t);
-  const double bc2 = 1.0 - pow((double)beta2, (double)t);
-  k.decay = (float)(1.0 - (double)lr * (double)weight_decay);
-  k.one_m_b1 = (float)(1.0 - (double)beta1);
-  k.b2 = beta2;
-  k.one_m_b2 = (float)(1.0 - (double)beta2);
-  k.step_size = (float)((double)lr / bc1);
-  k.bc2_sqrt = (float)sqrt(bc2);
-  k.eps = eps;
-  k.gscale = grad_scale;
+  if (n <= 0 || in.t < (in.t_dev ? 0 : 1)) PL_FAIL(PL_ESHAPE, "pl_adamw_flat: n=%lld t=%lld", (long long)n, (long long)in.t);
   const int vec = aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v);
   int64_t work = vec ? (n >> 2) : n;
   int blocks = (int)((work + NTHR - 1) / NTHR);
   if (blocks > 2048) blocks = 2048;
   if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(NTHR), 0, (hipStream_t)stream, p, g, m, v, n, k, vec);
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(NTHR), 0, (hipStream_t)stream, p, g, m, v, n, in, vec);
   PL_CHECK_LAUNCH("adamw");
   return PL_OK;
+}
+
+extern "C" int pl_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int64_t t,
+                             float grad_scale, void* stream) {
+  const AdamWIn in = {lr, beta1, beta2, eps, weight_decay, grad_scale, t, nullptr, nullptr};
+  return adamw_launch(p, g, m, v, n, in, stream);
+}
+
+extern "C" int pl_adamw_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev,
+                                 float beta1, float beta2, float eps, float weight_decay, int64_t t_base,
+                                 const uint64_t* t_dev, float grad_scale, void* stream) {
+  if (!lr_dev || !t_dev) PL_FAIL(PL_EINVAL, "pl_adamw_flat_dev: null lr / t pointer");
+  const AdamWIn in = {0.f, beta1, beta2, eps, weight_decay, grad_scale, t_base, lr_dev, t_dev};
+  return adamw_launch(p, g, m, v, n, in, stream);
 }
 
 extern "C" int pl_flip_pose(const float* in, float* out, int64_t B, int64_t joints, int64_t D, void* stream) {
@@ -1192,7 +1247,7 @@ extern "C" int pl_bn_train_fwd(const float* z, int64_t rows, int64_t C, const fl
   dim3 grid(strips, stream_rows_grid(B, strips));
   hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NTHR), 0, s, z, scale, shift, (const float*)nullptr, y, bits, B, H,
                      relu ? 0 : 8, 0u, 1.0f, 0u, 0u, 0u, 0u, (const uint64_t*)nullptr, Hc,
-                     PlaneOut{nullptr, nullptr, 1.f, nullptr, 0});
+                     PlaneOut{nullptr, nullptr, 1.f, nullptr, 0}, (const uint64_t*)nullptr, 0u);
   PL_CHECK_LAUNCH("bn_apply");
   return PL_OK;
 }

@@ -1046,6 +1046,18 @@ static ProfRec* prof_begin(const GemmArgs& a, hipStream_t s) {
   return r;
 }
 
+// the same hook for launches made elsewhere (gemm_planes.hip)
+void* prof_begin_flops(double flops, hipStream_t s) {
+  GemmArgs a = {};
+  a.M = 1; a.N = 1; a.K = 1;
+  ProfRec* r = prof_begin(a, s);
+  if (r) r->flops = flops;
+  return r;
+}
+void prof_end(void* rec, hipStream_t s) {
+  if (rec) (void)hipEventRecord(static_cast<ProfRec*>(rec)->e1, s);
+}
+
 // hot path: whole 128x128x32 tiles in every split, 16-byte aligned rows
 static bool whole_tiles(const GemmArgs& a) {
   const int splits = a.split_k > 1 ? a.split_k : 1;

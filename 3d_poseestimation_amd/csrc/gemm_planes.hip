@@ -107,6 +107,7 @@ int launch_gemm_planes(GemmLayout layout, const PlanesGemmArgs& a, hipStream_t s
   if (!planes_gemm_ok(layout, a)) PL_FAIL(PL_ESHAPE, "gemm_planes: unsupported problem %dx%dx%d (layout %d, mode %d)", a.e.M, a.e.N, a.e.K, (int)layout, a.mode);
   const PlanesKern k = kern_of(layout, a);
   const dim3 grid(grid_of(a)), block(512);
+  void* prof = prof_begin_flops(2.0 * a.e.M * a.e.N * a.e.K, s);
 #define PL_PLANES_LAUNCH(MODE)                                                                                   \
   switch (layout) {                                                                                              \
     case kNT: hipLaunchKernelGGL((planes_gemm_kernel<false, false, MODE>), grid, block, 0, s, k); break;         \
@@ -116,6 +117,7 @@ int launch_gemm_planes(GemmLayout layout, const PlanesGemmArgs& a, hipStream_t s
   }
   if (a.mode == plp::kF16x3) { PL_PLANES_LAUNCH(plp::kF16x3) } else { PL_PLANES_LAUNCH(plp::kBf16) }
 #undef PL_PLANES_LAUNCH
+  prof_end(prof, s);
   PL_CHECK_LAUNCH("gemm_planes");
   return PL_OK;
 }
@@ -125,10 +127,12 @@ int launch_gemm_planes_pair(const PlanesGemmArgs& nn, const PlanesGemmArgs& tn, 
     PL_FAIL(PL_ESHAPE, "gemm_planes_pair: unsupported problems");
   const PlanesKern k0 = kern_of(kNN, nn), k1 = kern_of(kTN, tn);
   const int g0 = grid_of(nn), g1 = grid_of(tn);
+  void* prof = prof_begin_flops(2.0 * nn.e.M * nn.e.N * nn.e.K + 2.0 * tn.e.M * tn.e.N * tn.e.K, s);
   if (nn.mode == plp::kF16x3)
     hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kF16x3>), dim3(g0 + g1), dim3(512), 0, s, k0, k1, g0);
   else
     hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kBf16>), dim3(g0 + g1), dim3(512), 0, s, k0, k1, g0);
+  prof_end(prof, s);
   PL_CHECK_LAUNCH("gemm_planes_dual");
   return PL_OK;
 }

@@ -108,6 +108,8 @@ int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s);
 int launch_gemm_f32_pair(const GemmArgs& nn, const GemmArgs& tn, hipStream_t s);
 int gemm_stat_groups(int M);  // number of 64-row groups the stats epilogue emits
 int prof_enable(int on);
+void* prof_begin_flops(double flops, hipStream_t s);   // NULL when this launch is not sampled
+void prof_end(void* rec, hipStream_t s);
 int prof_read(double min_flops, double max_flops, double* ms_total, int64_t* launches, double* flops_total);
 
 // ---------------------------------------------------------------------------------
@@ -127,7 +129,10 @@ int launch_bn_finalize(const float* stat, int G, int world, int B, int H,
 int launch_bn_apply(const float* z, const float* scale, const float* shift, const float* resid,
                     float* act, uint64_t* bits, int B, int H, float p, uint64_t seed,
                     uint64_t step, int layer, const uint64_t* inject_keep, hipStream_t s,
-                    const PlaneOut* planes = nullptr);
+                    const PlaneOut* planes = nullptr, const uint64_t* step_dev = nullptr);
+// pl_mse_fwd_bwd + (tick != NULL) tick[0] += 1 once the loss is written (PLDesc.step_dev, graph replay)
+int mse_fwd_bwd_tick(const float* pred, const float* tgt, int64_t n, float grad_scale, float* dpred, float* loss_out,
+                     void* scratch, uint64_t* tick, void* stream);
 
 int bwd_row_chunks(int B, int H);
 // pass 1: partial column sums of dy and dy*zhat, dy = g * bits * keep_scale

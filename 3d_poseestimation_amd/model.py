@@ -47,6 +47,12 @@ class _EvalNoBackward(torch.autograd.Function):
         raise NotImplementedError("backward through an eval-mode LinearModel is not built yet")
 
 
+def _overlap_ok(sync):
+    """dp.GradSync.overlap_enabled(); any other object with launch_bucket()/world() overlaps unconditionally."""
+    fn = getattr(sync, "overlap_enabled", None)
+    return True if fn is None else bool(fn())
+
+
 class _GraphTicket:
     """One training forward whose backward has not run yet.  LinearModel counts the live ones: the
     data-parallel overlap launches its all-reduce buckets only from the backward of the LAST live graph
@@ -363,7 +369,7 @@ class LinearModel(nn.Module):
         B = x2.shape[0]
         accumulate = any(p.grad is not None for p in self._param_list)
         sync = self._grad_sync
-        if accumulate and sync is not None and sync.has_pending():
+        if accumulate and sync is not None and getattr(sync, "has_pending", lambda: False)():
             # an earlier backward of this optimizer step already all-reduced its buckets: adding local gradients
             # to summed ones would make the replicas diverge silently
             sync.abandon()
@@ -379,7 +385,7 @@ class LinearModel(nn.Module):
         dx = torch.empty_like(x2) if need_dx else None
         args = (ctypes.byref(self._desc), x2.data_ptr(), gy.data_ptr(), B, ws["buf"].data_ptr(), ws["bytes"],
                 dx.data_ptr() if need_dx else None, target.data_ptr())
-        if sync is not None and not accumulate and last_graph and sync.overlap_enabled() and sync.world() > 1:
+        if sync is not None and not accumulate and last_graph and _overlap_ok(sync) and sync.world() > 1:
             # data-parallel overlap: after each layer range the tail of the arena down to that
             # range's lowest layer is final and is all-reduced while the layers below compute
             for hi, lo, a_lo, a_hi in self._bwd_ranges():
@@ -402,10 +408,12 @@ class LinearModel(nn.Module):
         return dx
 
     # ------------------------------------------------------------------ fused train step
-    def fused_train_fwd_bwd(self, x2, target, sync=None):
+    def fused_train_fwd_bwd(self, x2, target, sync=None, step_dev=None):
         """forward + MSE(mean) + backward in one library call (two when a data-parallel sync wants
         the upper layers' gradients early).  Returns (loss, y) device tensors; parameter gradients
-        land in the flat arena and stay attached as .grad views."""
+        land in the flat arena and stay attached as .grad views.
+        step_dev (graph capture, train.GraphedTrainStep): device counter of completed steps; the dropout stream
+        of the captured launches uses (the step number at capture) + *step_dev."""
         B = x2.shape[0]
         ws = self._acquire_workspace(B)
         try:
@@ -414,19 +422,21 @@ class LinearModel(nn.Module):
             grads = self.flat_grads
             self._step += 1
             L = _lib.lib()
+            self._desc.step_dev = step_dev.data_ptr() if step_dev is not None else None
 
             def call(hi, lo):
                 self._guarded(ws, lambda: L.pl_lifter_train_fwd_bwd(
                     ctypes.byref(self._desc), x2.data_ptr(), target.data_ptr(), B, ws["buf"].data_ptr(), ws["bytes"],
                     self._seed, self._step, y.data_ptr(), loss.data_ptr(), grads.data_ptr(), hi, lo,
                     _lib.current_stream_ptr()), "pl_lifter_train_fwd_bwd")
-            if sync is not None and sync.world() > 1 and sync.overlap_enabled():
+            if sync is not None and sync.world() > 1 and _overlap_ok(sync):
                 for hi, lo, a_lo, a_hi in self._bwd_ranges():
                     call(hi, lo)
                     sync.launch_bucket(grads[a_lo:a_hi])
             else:
                 call(len(self._named_holders()), 0)
         finally:
+            self._desc.step_dev = None
             self._release_workspace(ws)
         if self._param_list[-1].grad is None or self._param_list[-1].grad.data_ptr() != \
                 grads.data_ptr() + 4 * self._slots[-1].offset:

@@ -95,3 +95,24 @@ class FlatAdamW(torch.optim.Optimizer):
                 _lib.check(rc, "pl_adamw_flat")
         self._step_tensor.fill_(float(self._t))
         return loss
+
+    # ---- graph replay (train.GraphedTrainStep): the step with t and lr read from device memory ----------------
+    def _enqueue_dev(self, lr_dev, t_base, t_dev, grad_scale=1.0):
+        """Enqueue (or capture) one step whose t = t_base + *t_dev and lr = *lr_dev; host-side counters are the
+        caller's business (a captured launch runs many times)."""
+        self._bind()
+        model = self._model
+        flat, grads = model.flat_params, model.flat_grads
+        g = self.param_groups[0]
+        with torch.cuda.device(flat.device):
+            for lo, hi in self._active_ranges():
+                rc = _lib.lib().pl_adamw_flat_dev(
+                    flat.data_ptr() + 4 * lo, grads.data_ptr() + 4 * lo, self._m.data_ptr() + 4 * lo,
+                    self._v.data_ptr() + 4 * lo, hi - lo, lr_dev.data_ptr(),
+                    float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
+                    int(t_base), t_dev.data_ptr(), float(grad_scale), _lib.current_stream_ptr())
+                _lib.check(rc, "pl_adamw_flat_dev")
+
+    def _advance_host(self, n=1):
+        self._t += n
+        self._step_tensor.fill_(float(self._t))

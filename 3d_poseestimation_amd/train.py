@@ -125,6 +125,65 @@ def train_step(model, optimizer, y1, y2, grad_sync=None):
     return loss, y2_hat
 
 
+class GraphedTrainStep:
+    """The train_1.py:75-100 step captured ONCE as a hipGraph (torch.cuda.graph) and replayed: the ~50 kernel launches
+    of a step become one graph launch, which is what a launch-bound step wants (B = 64, BASELINE configs[0]: the
+    host needs ~3.5 us per launch, the kernels far less).
+
+        step = GraphedTrainStep(model, optimizer, x_example, y_example)
+        loss, y_hat = step(x, y)            # same results, bit for bit, as train_step(model, optimizer, x, y)
+
+    What changes from step to step lives in device memory and is advanced INSIDE the graph: the dropout stream's
+    step number and AdamW's t come from one device counter (PLDesc.step_dev, pl_adamw_flat_dev), the learning rate
+    from a device scalar the host refreshes when a scheduler changed it.  Single process (a captured RCCL
+    all-reduce is not wired); LinearModel + FlatAdamW; fixed batch shape."""
+
+    def __init__(self, model, optimizer, y1, y2):
+        y1, y2 = y1.float(), y2.float()
+        if not _fusable(model, optimizer, y1, y2) or model._grad_sync is not None:
+            raise _lib.PoseliftError("GraphedTrainStep needs a training-mode LinearModel on the GPU with its FlatAdamW "
+                                     "and no gradient sync attached")
+        self.model, self.opt = model, optimizer
+        B = y1.shape[0]
+        dev = y1.device
+        self._x = y1.reshape(B, -1).contiguous().clone()
+        self._y = y2.reshape(B, -1).contiguous().clone()
+        self._out_shape = tuple(y2.shape)
+        self._tick = torch.zeros(1, dtype=torch.int64, device=dev)          # completed replays
+        self._lr = float(optimizer.param_groups[0]["lr"])
+        self._lr_dev = torch.full((1,), self._lr, dtype=torch.float32, device=dev)
+        optimizer._bind()
+        with torch.cuda.device(dev):
+            # one eager step on a snapshot: every kernel is loaded and the workspace sits in the model's pool before
+            # anything is captured; the snapshot is then restored (the step must not count)
+            snap = [t.clone() for t in (model.flat_params, model._bn_running, model._bn_batches, optimizer._m, optimizer._v)]
+            step0, t0 = model._step, optimizer._t
+            train_step(model, optimizer, self._x, self._y.reshape(self._out_shape))
+            for dst, src in zip((model.flat_params, model._bn_running, model._bn_batches, optimizer._m, optimizer._v), snap):
+                dst.copy_(src)
+            model._step, optimizer._t = step0, t0
+            optimizer._step_tensor.fill_(float(t0))
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss, y_hat = model.fused_train_fwd_bwd(self._x, self._y, None, step_dev=self._tick)
+                optimizer._enqueue_dev(self._lr_dev, t0, self._tick)
+            self.y_hat = y_hat.reshape(self._out_shape)
+            model._step = step0                                              # capturing ran nothing
+
+    def __call__(self, y1, y2):
+        lr = float(self.opt.param_groups[0]["lr"])
+        if lr != self._lr:                                                   # ReduceLROnPlateau et al. (train_1.py:106)
+            self._lr = lr
+            self._lr_dev.fill_(lr)
+        self._x.copy_(y1.reshape(self._x.shape))
+        self._y.copy_(y2.reshape(self._y.shape))
+        self.graph.replay()
+        self.model._step += 1
+        self.opt._advance_host(1)
+        return self.loss, self.y_hat
+
+
 @torch.no_grad()
 def predict_flip_tta(model, y1, out_dims=3):
     """(flip_pose(model(flip_pose(y1))) + model(y1)) / 2 for a model in eval mode, as ONE forward

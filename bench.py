@@ -6,22 +6,25 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port P bench.py --gpus N --steps K --warmup W
 
-GEMM arithmetic (--dtype): "bf16x6" (default: every fp32 operand split into three bf16 pieces, six
-bf16 MFMAs per product, fp32 accumulate -- fp32-grade results, meets the 1e-3 mm parity gate),
-"fp32" (exact v_mfma_f32_32x32x2_f32, also meets it) or "bf16" (operands rounded to bf16, ~1 mm).
-Storage is fp32 in every mode.  The modes not chosen are measured beside the headline (other_modes).
+GEMM arithmetic (--dtype): "f16x3" (default: every operand tensor written by its producer as two fp16 planes,
+S x = h + l/2048, three fp16 MFMAs per product on two fp32 accumulators -- fp32-grade results, meets the 1e-3 mm
+parity gate), "bf16x6" (fp32 operands split into three bf16 pieces inside the GEMM, six MFMAs -- also fp32-grade),
+"fp32" (exact v_mfma_f32_32x32x2_f32) or "bf16" (operands rounded to bf16, ~1 mm: never the parity-gated number).
+The modes not chosen are measured beside the headline (other_modes).
 
 One JSON line on rank 0 (contract in the task statement).  Also in that line:
   roofline      the dominant kernel by time, the backward dual launch (dX = dz W and dW = dz^T a of one
                 layer, 2 x 8.59 GFLOP): ALGORITHMIC FLOPs per launch / mean launch duration, measured
                 with HIP events recorded on the launch stream around every such launch INSIDE the
                 timed region (pl_prof_enable), against the gfx950 dense MFMA peak of the arithmetic
-                type (fp32 matrix 157.3 TF, bf16 2,516 TF); roofline_forward_gemm: the same for the
-                forward kernel.  bf16x6 issues 6 MFMA FLOPs per algorithmic FLOP (mfma_issue_frac).
+                type (fp32 matrix 157.3 TF, bf16 / fp16 2,516 TF); roofline_forward_gemm: the same for the
+                forward kernel.  f16x3 issues 3 and bf16x6 6 MFMA FLOPs per algorithmic FLOP (mfma_issue_frac).
                 traffic = PMC HBM-side bytes per launch (profiles/traffic.json).
   cpu_baseline  the restated reference step (oracle/torch_twin.py: stock PyTorch CPU eager, the
-                ATen kernels the reference dispatches to) timed on this node's host cores on a
-                bounded sample -- rank 0, N=1 only.  A reported baseline, not the target.
+                ATen kernels the reference dispatches to) timed on this node's host cores as BASELINE.md
+                section 4 plans it: 20 warm-up steps, then the MEDIAN of >= 50 timed steps, at B = 4096 (the
+                value) and B = 64 (batch_64) -- rank 0, N=1 only.  A reported baseline, not the target.
+  batch_64      the HIP step's latency at the reference's own batch size (config 0), same protocol.
   parity        eval-forward MPJPE (mm) of the HIP path against the numpy oracle on the bench
                 batch, in the same run (gate 1e-3 mm, BASELINE.json).
   other_modes   this library's other arithmetic modes and stock PyTorch-ROCm eager of the same module
@@ -56,9 +59,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (default: BASELINE config 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket GEMM launches with HIP events")
-    ap.add_argument("--dtype", choices=["fp32", "bf16", "bf16x6"], default="bf16x6",
-                    help="GEMM arithmetic of the headline run.  bf16x6 (default) and fp32 both meet the 1e-3 mm "
+    ap.add_argument("--dtype", choices=["fp32", "bf16", "bf16x6", "f16x3"], default="f16x3",
+                    help="GEMM arithmetic of the headline run.  f16x3 (default), bf16x6 and fp32 meet the 1e-3 mm "
                          "parity gate; bf16 does not (about 1 mm)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N>1 only: one whole-arena all-reduce after backward instead of buckets overlapped with it")
     ap.add_argument("--sync-bn", action="store_true",
                     help="N>1 only: BatchNorm statistics over the global batch (10 small all-gathers per step); "
                          "off by default = statistics per shard, the DDP convention")
@@ -90,30 +95,54 @@ def host_cores():
     return max(1, min(n, 16))
 
 
-def cpu_baseline(batch, budget_s=20.0):
-    """Time the restated reference step on the host cores (bounded sample)."""
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
+def cpu_baseline(batch, warm=20, steps=50):
+    """The restated reference step on the host cores, BASELINE.md section 4's protocol: `warm` warm-up steps, the
+    median of `steps` timed steps, at B = batch (the value) and at the reference's own B = 64."""
+    import platform
     import torch
     from oracle.torch_twin import TwinLifter, twin_train_step
     cores = host_cores()
     torch.set_num_threads(cores)
     pkg = importlib.import_module("3d_poseestimation_amd")
-    torch.manual_seed(0)
-    model = TwinLifter(34, 51, linear_size=1024, num_stage=2, p_dropout=0.5, BN=True).train()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
-    x, y = pkg.synth.synthetic_batch(batch, 1234)
-    for _ in range(2):
-        twin_train_step(model, opt, x, y)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        twin_train_step(model, opt, x, y)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt > budget_s or n >= 40:
-            break
-    return {"value": round(batch * n / dt, 1), "unit": "poses/s", "cores": cores, "kind": "port",
-            "sample": f"{n} train_1.py-style steps (fwd+MSE+bwd+AdamW) of the stock-PyTorch eager twin "
-                      f"at batch {batch}, fp32, {cores} threads, after 2 warm-up steps",
-            "ms_per_step": round(1e3 * dt / n, 2)}
+
+    def measure(b):
+        torch.manual_seed(0)
+        model = TwinLifter(34, 51, linear_size=1024, num_stage=2, p_dropout=0.5, BN=True).train()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+        x, y = pkg.synth.synthetic_batch(b, 1234)
+        full, fb = [], []
+        for i in range(warm + steps):
+            t0 = time.perf_counter()
+            twin_train_step(model, opt, x, y)
+            if i >= warm:
+                full.append(time.perf_counter() - t0)
+        for i in range(3 + max(5, steps // 5)):                 # forward + backward only, reported beside it
+            t0 = time.perf_counter()
+            opt.zero_grad()
+            torch.nn.functional.mse_loss(model(x).reshape(y.shape), y).backward()
+            if i >= 3:
+                fb.append(time.perf_counter() - t0)
+        return _median(full), _median(fb)
+
+    t_full, t_fb = measure(batch)
+    t64, t64_fb = measure(64)
+    cpu = platform.processor() or platform.machine()
+    try:
+        cpu = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
+    except (OSError, IndexError):
+        pass
+    return {"value": round(batch / t_full, 1), "unit": "poses/s", "cores": cores, "kind": "port",
+            "sample": f"median of {steps} train_1.py-style steps (zero_grad+fwd+MSE+bwd+AdamW) of the stock-PyTorch "
+                      f"eager twin at batch {batch}, fp32, {cores} threads, after {warm} warm-up steps",
+            "ms_per_step": round(1e3 * t_full, 2), "fwd_bwd_only_poses_per_s": round(batch / t_fb, 1),
+            "batch_64": {"poses_per_s": round(64 / t64, 1), "ms_per_step": round(1e3 * t64, 3),
+                         "fwd_bwd_only_poses_per_s": round(64 / t64_fb, 1)},
+            "cpu_model": cpu, "torch": torch.__version__}
 
 
 def read_rooflines(pkg, L, dtype, one, traffic):
@@ -121,7 +150,7 @@ def read_rooflines(pkg, L, dtype, one, traffic):
     achieved = ALGORITHMIC FLOPs per launch / mean launch duration; peak = dense MFMA peak of the
     arithmetic type (bf16x6 issues 6 bf16 MFMA FLOPs per algorithmic FLOP: `mfma_issue_frac`)."""
     peak = PEAK_F32_MATRIX_TFLOPS if dtype == "fp32" else PEAK_BF16_MATRIX_TFLOPS
-    redundancy = 6 if dtype == "bf16x6" else 1
+    redundancy = {"bf16x6": 6, "f16x3": 3}.get(dtype, 1)
 
     def read(lo, hi, kernel, tkey):
         ms, n_l, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
@@ -140,8 +169,10 @@ def read_rooflines(pkg, L, dtype, one, traffic):
         return r
     # dominant kernel by time: the backward dual launch (dX = dz W and dW = dz^T a of one layer,
     # 2 x 8.59 GFLOP); the forward single-GEMM kernel is reported beside it
-    kd = "gemm_x6_planes_dual_kernel" if dtype == "bf16x6" else "gemm_f32_dual_kernel<%s>" % dtype
-    ks = "gemm_x6_planes_kernel<NT>" if dtype == "bf16x6" else "gemm_f32_kernel<NT,%s>" % dtype
+    kd = {"bf16x6": "gemm_x6_planes_dual_kernel", "f16x3": "planes_gemm_dual_kernel<f16x3>"}.get(
+        dtype, "gemm_f32_dual_kernel<%s>" % dtype)
+    ks = {"bf16x6": "gemm_x6_planes_kernel<NT>", "f16x3": "planes_gemm_kernel<NT,f16x3>"}.get(
+        dtype, "gemm_f32_kernel<NT,%s>" % dtype)
     dual = read(1.9 * one, 2.1 * one, kd + " (4096x1024x1024 dX + 1024x1024x4096 dW in one launch, 4 launches/step)",
                 "gemm_f32_dual_hbm_bytes_per_launch")
     single = read(0.99 * one, 1.01 * one, ks + " (4096x1024x1024 forward, 4 launches/step)",
@@ -158,7 +189,7 @@ def side_measurements(pkg, a, dev, x_eval, y_oracle):
     from oracle.torch_twin import TwinLifter, twin_train_step
     res = {}
 
-    def timed(step, n=60, warm=10):
+    def timed(step, n=60, warm=30):
         for _ in range(warm):
             step()
         torch.cuda.synchronize()
@@ -169,7 +200,7 @@ def side_measurements(pkg, a, dev, x_eval, y_oracle):
         return a.batch * n / (time.perf_counter() - t0)
 
     xb, yb = pkg.synth.synthetic_batch(a.batch, 99, dev)
-    for other in ("fp32", "bf16x6", "bf16"):
+    for other in ("f16x3", "bf16x6", "fp32", "bf16"):
         if other == a.dtype:
             continue
         torch.manual_seed(0)
@@ -210,6 +241,26 @@ def side_measurements(pkg, a, dev, x_eval, y_oracle):
     return res
 
 
+def batch64_latency(pkg, a, dev, warm=20, steps=50):
+    """BASELINE configs[0]'s batch on the GPU: one train_1.py step at B = 64 (launch-bound), median of `steps`."""
+    import torch
+    torch.manual_seed(0)
+    m = pkg.LinearModel(34, 51, compute_dtype=a.dtype).to(dev).train()
+    opt = pkg.FlatAdamW(m, lr=1e-4)
+    x, y = pkg.synth.synthetic_batch(64, 77, dev)
+    ts = []
+    for i in range(warm + steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pkg.train_step(m, opt, x, y)
+        torch.cuda.synchronize()
+        if i >= warm:
+            ts.append(time.perf_counter() - t0)
+    t = _median(ts)
+    return {"ms_per_step": round(1e3 * t, 4), "poses_per_s": round(64 / t, 1),
+            "how": f"median of {steps} synchronised steps after {warm} warm-ups (host launch latency included)"}
+
+
 def main():
     a = parse()
     import torch
@@ -231,7 +282,7 @@ def main():
     if a.sync_bn and world > 1:
         model.set_sync_bn(True)
     opt = pkg.FlatAdamW(model, lr=1e-4)                     # train_1.py:39 (weight_decay 0.01)
-    sync = pkg.dp.GradSync() if world > 1 else None
+    sync = pkg.dp.GradSync(overlap=not a.no_overlap) if world > 1 else None
     model.set_grad_sync(sync)                               # all-reduce overlapped with the backward tail
     pool = [pkg.synth.synthetic_batch(a.batch, 1234 + 1000 * rank + i, dev) for i in range(8)]
     torch.cuda.synchronize()
@@ -272,6 +323,32 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # N > 1: what the gradient all-reduce costs the step -- the same steps with the collective stubbed out (every
+    # rank keeps its local gradients; results are discarded).  exposed = synchronised step - stubbed step.
+    exposed_us = None
+    if world > 1:
+        class _NoSync(pkg.dp.GradSync):
+            def launch_bucket(self, flat_slice):
+                pass
+
+            def __call__(self, m):
+                return 1.0 / self.world()
+        stub = _NoSync()
+        model.set_grad_sync(stub)
+        n_st = max(10, a.steps // 4)
+        for i in range(5):
+            pkg.train_step(model, opt, *pool[i % len(pool)], grad_sync=stub)
+        barrier(); torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for i in range(n_st):
+            pkg.train_step(model, opt, *pool[i % len(pool)], grad_sync=stub)
+        torch.cuda.synchronize(); barrier()
+        t = torch.tensor([(time.perf_counter() - ts) / n_st], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exposed_us = round(1e6 * (dt / a.steps - float(t.item())), 1)
+        model.set_grad_sync(sync)
+        pkg.dp.broadcast_model(model)                            # the stubbed steps let the replicas drift
+
     # forward+backward only (no optimizer / all-reduce), reported beside the headline number
     def run_fb(n):
         for i in range(n):
@@ -305,16 +382,21 @@ def main():
             "metric": "poses/sec fwd+bwd, 17-joint lifting batch 4096; MPJPE vs ref",
             "value": round(value, 1), "unit": "poses/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "bf16x6": "bf16x6 (3-way bf16 split of fp32 operands, fp32 accumulate)"}[a.dtype], "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": {"fp32": "f32", "bf16": "bf16", "bf16x6": "bf16x6 (3-way bf16 split of fp32 operands, fp32 accumulate)",
+                      "f16x3": "f16x3 (two fp16 planes per fp32 operand, 3 fp16 MFMAs per product, fp32 accumulate)"}[a.dtype],
+            "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: phase1_lifting "
                                    "LinearModel 34-1024-2x(1024-1024)-51, BN+ReLU+Dropout(0.5), one train_1.py "
                                    "step = zero_grad+forward+MSE+backward+AdamW"
                                    + ("+RCCL grad all-reduce" if world > 1 else ""),
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}" + ("+syncbn" if a.sync_bn and world > 1 else ""),
-                       "gemm_arith": "fp32 MFMA (v_mfma_f32_32x32x2_f32)" if a.dtype == "fp32"
-                       else "bf16 MFMA (v_mfma_f32_32x32x16_bf16), fp32 accumulate and storage"
-                       + (", three-way operand split x 6 products (fp32-grade)" if a.dtype == "bf16x6" else "")},
+                       "gemm_arith": {
+                           "fp32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
+                           "bf16": "bf16 MFMA (v_mfma_f32_32x32x16_bf16), operands rounded to bf16, fp32 accumulate",
+                           "bf16x6": "bf16 MFMA, three-way operand split x 6 products (fp32-grade), fp32 accumulate and storage",
+                           "f16x3": "fp16 MFMA (v_mfma_f32_32x32x16_f16), operands as two fp16 planes (22-23 bits) x 3 "
+                                    "products on two fp32 accumulators (fp32-grade); planes staged by LDS-DMA"}[a.dtype]},
             "step_tflops": round(value * FLOP_PER_POSE / 1e12, 2),
             "step_frac_of_matrix_peak": round(value * FLOP_PER_POSE / 1e12 / (
                 (PEAK_F32_MATRIX_TFLOPS if a.dtype == "fp32" else PEAK_BF16_MATRIX_TFLOPS) * world), 4),
@@ -323,6 +405,12 @@ def main():
             "roofline": roofline,
             "roofline_forward_gemm": roofline_single,
         }
+        if world > 1:
+            out["allreduce"] = {"overlap": not a.no_overlap, "exposed_us_per_step": exposed_us,
+                                "bytes": int(model.flat_grads.numel()) * 4,
+                                "how": "step time with the collective minus the same steps with it stubbed out"}
+        if world == 1:
+            out["batch_64"] = batch64_latency(pkg, a, dev)
         if world == 1 and not a.no_extras:
             out["other_modes"] = side_measurements(pkg, a, dev, x, y_orc)
         if world == 1 and not a.no_cpu_baseline:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PL_VERSION 100 /* 0.1.0 */
+#define PL_VERSION 101 /* 0.1.1: PLDesc.step_dev, PL_F16X3, pl_adamw_flat_dev, pl_gemm_planes */
 
 typedef enum PLStatus {
   PL_OK = 0,
@@ -38,9 +38,12 @@ typedef enum PLStatus {
   PL_ESYNC = -7         /* the PLSync gather callback reported a failure         */
 } PLStatus;
 
-/* arithmetic of the 1024-wide GEMMs (storage is fp32 in every mode):
+/* arithmetic (and operand storage) of the 1024-wide GEMMs:
  *   PL_F32     v_mfma_f32_32x32x2_f32, exact fp32 products                  (meets the 1e-3 mm gate)
- *   PL_BF16    operands rounded to bf16, v_mfma_f32_32x32x16_bf16           (~1 mm MPJPE)
+ *   PL_BF16    operands rounded to bf16, v_mfma_f32_32x32x16_bf16           (~1 mm MPJPE).  On whole 128-tiles with
+ *              BatchNorm the operands are STORED as bf16 by their producers (activations, dz, a bf16 weight shadow)
+ *              and staged by LDS-DMA; z, the gradient flow and every reduction stay fp32.  Other shapes keep fp32
+ *              storage and round while staging: the same values, the same products.
  *   PL_BF16X6  each fp32 operand split into 3 bf16 pieces, 6 bf16 MFMAs per product term:
  *              fp32-grade results (meets the gate too) at 6/16 of the fp32 matrix time
  *   PL_F16X3   fp32-grade on HALF the matrix work of PL_BF16X6: every operand tensor is written by its producing
@@ -96,6 +99,11 @@ typedef struct PLDesc {
   float* bn_running;
   int64_t* bn_batches;
   const PLSync* sync;  /* NULL = BatchNorm over the local batch (the reference's behaviour) */
+  /* Graph replay (hipGraph / torch.cuda.graph capture of the train step; no reference counterpart): a device counter of
+   * completed steps.  When set, pl_lifter_fwd_train's dropout stream uses step + *step_dev (the kernels read it), and
+   * pl_lifter_train_fwd_bwd increments it once per call, after the forward's last reader -- so a captured step draws fresh
+   * dropout masks on every replay.  NULL: the `step` argument alone (the eager behaviour). */
+  const uint64_t* step_dev;
 } PLDesc;
 
 int pl_version(void);
@@ -315,6 +323,14 @@ int pl_flip_tta_merge(const float* yy, float* y, int64_t B, int64_t joints, int6
 int pl_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay,
                   int64_t t, float grad_scale, void* stream);
+
+/* The same step with its two per-step inputs read from device memory, so that a captured graph advances by itself:
+ * t = t_base + *t_dev (t_dev: a step counter such as PLDesc.step_dev, incremented elsewhere in the graph) and
+ * lr = *lr_dev (the host-side LR scheduler writes it).  Bias corrections are derived on the device from t by the
+ * code pl_adamw_flat runs, so a replayed step equals the eager one bit for bit. */
+int pl_adamw_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev,
+                      float beta1, float beta2, float eps, float weight_decay, int64_t t_base,
+                      const uint64_t* t_dev, float grad_scale, void* stream);
 
 /* ---- building blocks exported for tests ------------------------------------------ */
 /* C[M][N] = op(A) op(B) on the fp32 MFMA path.

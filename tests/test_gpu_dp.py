@@ -129,10 +129,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend="gloo"):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), POSELIFT_DIST_BACKEND="gloo")
+                      MASTER_PORT=str(port), POSELIFT_DIST_BACKEND=backend, HSA_ENABLE_IPC_MODE_LEGACY="0")
     import importlib
     import torch.distributed as dist
     pkg = importlib.import_module("3d_poseestimation_amd")
@@ -199,9 +199,87 @@ def _worker(rank, world, port, q):
     gathered = [torch.zeros_like(m.flat_params) for _ in range(world)]
     dist.all_gather(gathered, m.flat_params)
     assert all(torch.equal(gathered[0], g) for g in gathered), "ranks diverged under SyncBN"
+
+    # ---- more than one backward per optimizer step, with the overlapped all-reduce attached -------------
+    def same_on_all_ranks(t, what):
+        got = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(got, t)
+        assert all(torch.equal(got[0], g) for g in got), what
+
+    def accumulate(overlap):
+        """two micro-batches: every backward but the last inside no_sync(), as with DistributedDataParallel"""
+        torch.manual_seed(0)
+        m = pkg.LinearModel(34, 51, linear_size=128, p_dropout=0.0).to(dev).train()
+        pkg.dp.broadcast_model(m)
+        opt = pkg.FlatAdamW(m, lr=1e-3)
+        sync = pkg.dp.GradSync(overlap=overlap)
+        m.set_grad_sync(sync)
+        half = (hi - lo) // 2
+        opt.zero_grad()
+        with sync.no_sync():
+            pkg.mse_loss(m(xs[lo:lo + half]).reshape(-1, 17, 3), ys[lo:lo + half]).backward()
+        pkg.mse_loss(m(xs[lo + half:hi]).reshape(-1, 17, 3), ys[lo + half:hi]).backward()
+        opt.step(grad_scale=sync(m))
+        torch.cuda.synchronize()
+        return m.flat_params.clone()
+    p_acc = accumulate(True)
+    same_on_all_ranks(p_acc, "ranks diverged under gradient accumulation")
+    assert torch.equal(p_acc, accumulate(False)), "accumulation with the overlap attached changed the result"
+
+    # without no_sync the second backward would add local gradients to already summed ones: loud, not silent
+    torch.manual_seed(0)
+    m = pkg.LinearModel(34, 51, linear_size=128, p_dropout=0.0).to(dev).train()
+    sync = pkg.dp.GradSync()
+    m.set_grad_sync(sync)
+    pkg.mse_loss(m(xs[lo:hi]).reshape(-1, 17, 3), ys[lo:hi]).backward()
+    try:
+        pkg.mse_loss(m(xs[lo:hi]).reshape(-1, 17, 3), ys[lo:hi]).backward()
+        raise AssertionError("second backward with buckets in flight did not raise")
+    except pkg.PoseliftError as e:
+        assert "no_sync" in str(e)
+    assert not sync.has_pending()
+
+    def cycle(overlap):
+        """the phase5 pattern: the lifter twice in ONE graph (train_5 copy.py:167-168, 184-185)"""
+        torch.manual_seed(0)
+        m = pkg.LinearModel(34, 51, linear_size=128, p_dropout=0.0).to(dev).train()
+        pkg.dp.broadcast_model(m)
+        opt = pkg.FlatAdamW(m, lr=1e-3)
+        sync = pkg.dp.GradSync(overlap=overlap)
+        m.set_grad_sync(sync)
+        opt.zero_grad()
+        xa = xs[lo:hi].clone().requires_grad_(True)
+        la = pkg.mse_loss(m(xa).reshape(-1, 17, 3), ys[lo:hi])
+        lb = pkg.mse_loss(m(xs[lo:hi] * 0.9).reshape(-1, 17, 3), ys[lo:hi])
+        (la + lb).backward()
+        assert m._live_graphs == 0
+        opt.step(grad_scale=sync(m))
+        torch.cuda.synchronize()
+        return m.flat_params.clone()
+    p_cyc = cycle(True)
+    same_on_all_ranks(p_cyc, "ranks diverged with two lifter calls in one graph")
+    assert torch.equal(p_cyc, cycle(False))
     dist.barrier()
     dist.destroy_process_group()
     q.put(rank)
+
+
+def test_two_rank_rccl_on_two_gpus():
+    """The same worker over RCCL (backend "nccl"), one GPU per rank: overlapped buckets == plain all-reduce bit for
+    bit, replicas identical, SyncBN == the concatenated batch, accumulation / two-calls-per-graph.  Needs two visible
+    GPUs: skipped on the 1-GPU test box, runs wherever the driver has a multi-GPU node."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL over xGMI)")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, "nccl")) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
 
 
 def test_two_rank_rehearsal_on_one_gpu():

@@ -185,3 +185,38 @@ def test_f16x3_falls_back_to_the_fp32_grade_kernels_off_the_tile_grid(pkg, B, bn
     e_gpu, e_ref = orc.mpjpe_mm(pred.detach().cpu().numpy(), p64), orc.mpjpe_mm(opred, p64)
     assert e_gpu <= 3 * e_ref + 1e-4, (e_gpu, e_ref)
     assert torch.isfinite(m.flat_grads).all()
+
+
+@pytest.mark.parametrize("dtype,B,H", [("f16x3", 256, 256), ("fp32", 64, 128), ("f16x3", 4096, 1024)])
+def test_graphed_train_step_is_bitwise_the_eager_one(pkg, dtype, B, H):
+    """The whole train_1.py step (forward, MSE, backward, AdamW) captured once as a hipGraph and replayed: dropout
+    masks, AdamW bias corrections and the learning rate advance inside the graph (device step counter, device lr), so
+    every replay equals the eager step of the same number bit for bit -- losses, outputs, parameters, BN buffers."""
+    def make():
+        torch.manual_seed(3)
+        m = pkg.LinearModel(34, 51, linear_size=H, p_dropout=0.5, compute_dtype=dtype).to(DEV).train()
+        m.manual_seed(99, step=0)
+        return m, pkg.FlatAdamW(m, lr=1e-3)
+    batches = [pkg.synth.synthetic_batch(B, 40 + i, DEV) for i in range(4)]
+    me, oe = make()
+    eager = []
+    for i, (x, y) in enumerate(batches):
+        if i == 2:
+            oe.param_groups[0]["lr"] = 5e-4                      # a scheduler stepping between two steps
+        loss, yh = pkg.train_step(me, oe, x, y)
+        eager.append((loss.clone(), yh.clone()))
+    mg, og = make()
+    step = pkg.GraphedTrainStep(mg, og, *batches[0])
+    assert torch.equal(mg.flat_params, make()[0].flat_params)   # building the graph trained nothing
+    for i, (x, y) in enumerate(batches):
+        if i == 2:
+            og.param_groups[0]["lr"] = 5e-4
+        loss, yh = step(x, y)
+        assert torch.equal(loss, eager[i][0]) and torch.equal(yh, eager[i][1]), i
+    assert torch.equal(mg.flat_params, me.flat_params)
+    assert torch.equal(mg._bn_running, me._bn_running) and torch.equal(mg._bn_batches, me._bn_batches)
+    assert torch.equal(og._m, oe._m) and torch.equal(og._v, oe._v) and og._t == oe._t == 4
+    # and the eager path carries on from where the graph left off
+    l1, _ = pkg.train_step(mg, og, *batches[0])
+    l2, _ = pkg.train_step(me, oe, *batches[0])
+    assert torch.equal(l1, l2)
