@@ -41,7 +41,20 @@ class PLDesc(ctypes.Structure):
         ("params", ctypes.c_void_p), ("bn_running", ctypes.c_void_p), ("bn_batches", ctypes.c_void_p),
         ("sync", ctypes.POINTER(PLSync)),
         ("step_dev", ctypes.c_void_p),
+        ("wplanes", ctypes.c_void_p), ("wplanes_valid", ctypes.c_int32), ("reserved2", ctypes.c_int32),
     ]
+
+
+ADAMW_MAX_SEGS = 8
+
+
+class PLAdamWSeg(ctypes.Structure):
+    _fields_ = [("offset", ctypes.c_int64), ("numel", ctypes.c_int64), ("h", ctypes.c_void_p), ("l", ctypes.c_void_p)]
+
+
+class PLAdamWPlanes(ctypes.Structure):
+    _fields_ = [("nseg", ctypes.c_int32), ("kind", ctypes.c_int32), ("scale", ctypes.c_float),
+                ("reserved", ctypes.c_int32), ("seg", PLAdamWSeg * ADAMW_MAX_SEGS)]
 
 
 _c = ctypes
@@ -63,6 +76,8 @@ SIGNATURES = {
     "pl_lifter_fwd_train": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _c.c_uint64,
                                        _c.c_uint64, _P, _P]),
     "pl_lifter_bwd": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _P, _P, _P]),
+    "pl_lifter_fwd_eval_saved": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _P]),
+    "pl_lifter_bwd_eval": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _P, _P, _P]),
     "pl_lifter_bwd_layers": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _P, _P, _c.c_int, _c.c_int, _P]),
     "pl_lifter_train_fwd_bwd": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _c.c_uint64, _c.c_uint64,
                                            _P, _P, _P, _c.c_int, _c.c_int, _P]),
@@ -76,11 +91,19 @@ SIGNATURES = {
                                  _c.c_float, _c.c_float, _c.c_int64, _c.c_float, _P]),
     "pl_adamw_flat_dev": (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _P, _c.c_float, _c.c_float, _c.c_float,
                                      _c.c_float, _c.c_int64, _P, _c.c_float, _P]),
+    "pl_adamw_flat_planes": (_c.c_int, [_P, _P, _P, _P, _c.c_int64, _c.c_float, _P, _c.c_float, _c.c_float, _c.c_float,
+                                        _c.c_float, _c.c_int64, _P, _c.c_float, _c.POINTER(PLAdamWPlanes), _P]),
+    "pl_wplanes_bytes": (_c.c_size_t, [_D]),
+    "pl_wplanes_layer_bytes": (_c.c_size_t, [_D]),
+    "pl_weight_plane_scale": (_c.c_float, []),
+    "pl_wplanes_refresh": (_c.c_int, [_D, _P]),
     "pl_flip_pose": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P]),
     "pl_softargmax3d_nhwc_fwd": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _P]),
     "pl_softargmax3d_nhwc_bwd": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P]),
     "pl_conv2d_nhwc_scratch_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64,
                                                   _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
+    "pl_conv2d_nhwc_scratch_bytes_ex": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64,
+                                                     _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int]),
     "pl_conv2d_nhwc_fwd": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int,
                                       _c.c_int, _c.c_int, _c.c_int, _P, _P, _P, _c.c_int, _P, _P, _c.c_int, _P, _c.c_size_t,
                                       _P]),

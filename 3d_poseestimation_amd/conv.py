@@ -75,7 +75,8 @@ def conv2d_nhwc(x, w_ohwi, stride=1, padding=0, scale=None, shift=None, bias=Non
            _opt(resid, "resid", y.numel())]
     ptr = [t.data_ptr() if t is not None else None for t in opt]
     L = _lib.lib()
-    nbytes = L.pl_conv2d_nhwc_scratch_bytes(B, H, W, Cin, Cout, KH, KW, stride, padding)
+    nbytes = L.pl_conv2d_nhwc_scratch_bytes_ex(B, H, W, Cin, Cout, KH, KW, stride, padding, int(bias is not None),
+                                               int(resid is not None), int(relu))
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
     with torch.cuda.device(x.device):
         rc = L.pl_conv2d_nhwc_fwd(x.data_ptr(), B, H, W, Cin, w.data_ptr(), Cout, KH, KW, stride, padding,

@@ -7,6 +7,7 @@
 // 2+2s (its w2) (baselineModel.py:23-27,33-45); "final" is LinearModel.w2 (:77,100).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -74,7 +75,6 @@ inline int planes_kind(const PLDesc* d, int64_t B) {       // PlaneOut::kind of 
   if (!ok) return 0;
   return d->dtype == PL_F16X3 ? 2 : (d->dtype == PL_BF16 ? 1 : 0);
 }
-inline bool planes_path(const PLDesc* d, int64_t B) { return planes_kind(d, B) != 0; }
 inline int arith_of(const PLDesc* d) { return d->dtype == PL_F16X3 ? (int)PL_BF16X6 : d->dtype; }
 
 struct ParamLayout {
@@ -243,11 +243,24 @@ int check_ws(const Ws& w, void* ws, size_t bytes) {
 
 inline unsigned short* u16(void* ws, size_t off) { return reinterpret_cast<unsigned short*>(static_cast<char*>(ws) + off); }
 
-// fp16 operand planes of every 1024-wide weight matrix (layers 1..L-1), from the fp32 parameter arena
+// operand planes of hidden layer l's weight: in the caller's persistent buffer (PLDesc.wplanes) or in the workspace
+inline unsigned short* wplane(const PLDesc* d, const Ws& w, void* ws, int l) {
+  if (d->wplanes) {
+    const size_t per = (size_t)d->hidden * d->hidden * 2 * (w.pkind == 2 ? 2 : 1);
+    return reinterpret_cast<unsigned short*>(static_cast<char*>(d->wplanes) + (size_t)(l - 1) * per);
+  }
+  return u16(ws, w.wp[l]);
+}
+
+// operand planes of every 1024-wide weight matrix (layers 1..L-1), from the fp32 parameter arena -- unless the
+// caller keeps them current across calls (PLDesc.wplanes + wplanes_valid: pl_adamw_flat_planes refreshed them)
 int split_weight_planes(const PLDesc* d, const ParamLayout& P, const Ws& w, void* ws, hipStream_t s) {
+  if (d->wplanes && d->wplanes_valid) return PL_OK;
+  if (d->wplanes && (reinterpret_cast<uintptr_t>(d->wplanes) & 15)) PL_FAIL(PL_EINVAL, "wplanes not 16-byte aligned");
   const int64_t n = (int64_t)d->hidden * d->hidden;
   for (int l = 1; l < w.L; ++l) {
-    PlaneOut po = {u16(ws, w.wp[l]), u16(ws, w.wp[l]) + n, kWeightPlaneScale, nullptr, w.pkind};
+    unsigned short* q = wplane(d, w, ws, l);
+    PlaneOut po = {q, q + n, kWeightPlaneScale, nullptr, w.pkind};
     PL_TRY(launch_split_planes(d->params + P.off[4 * l], n, po, s));
   }
   return PL_OK;
@@ -322,6 +335,25 @@ extern "C" int64_t pl_param_arena_floats(const PLDesc* d) {
   return param_layout(d).total;
 }
 
+extern "C" size_t pl_wplanes_layer_bytes(const PLDesc* d) {
+  if (check_desc(d, false) != PL_OK) return 0;
+  if (!(d->bn && d->hidden % 128 == 0 && d->num_stage >= 1) || (d->dtype != PL_F16X3 && d->dtype != PL_BF16)) return 0;
+  return (size_t)d->hidden * d->hidden * 2 * (d->dtype == PL_F16X3 ? 2 : 1);
+}
+extern "C" size_t pl_wplanes_bytes(const PLDesc* d) { return pl_wplanes_layer_bytes(d) * 2 * (size_t)(d ? d->num_stage : 0); }
+extern "C" float pl_weight_plane_scale(void) { return kWeightPlaneScale; }
+
+// refresh PLDesc.wplanes from the current parameters (what a forward call does first when wplanes_valid == 0)
+extern "C" int pl_wplanes_refresh(const PLDesc* d, void* stream) {
+  PL_TRY(check_desc(d, true));
+  if (!d->wplanes || pl_wplanes_bytes(d) == 0) PL_FAIL(PL_EINVAL, "pl_wplanes_refresh: this descriptor has no weight planes");
+  PLDesc t = *d;
+  t.wplanes_valid = 0;
+  const Ws w = plan(&t, 128);            // any batch on the planes path: only the layer count and plane kind are used
+  if (!w.planes) PL_FAIL(PL_EINVAL, "pl_wplanes_refresh: this descriptor has no planes path");
+  return split_weight_planes(&t, param_layout(&t), w, nullptr, (hipStream_t)stream);
+}
+
 extern "C" size_t pl_workspace_bytes(const PLDesc* d, int64_t B) {
   if (check_desc(d, false) != PL_OK || B <= 0) return 0;
   return plan(d, B).total;
@@ -382,7 +414,7 @@ extern "C" int pl_lifter_fwd_eval(const PLDesc* d, const float* x, float* y, int
     g.relu = 1;
     if (l >= 2 && (l % 2) == 0) g.resid = f32(ws, w.act[l - 2]);
     if (w.planes && l > 0) {
-      PlanesGemmArgs pg = planes_args(w.pkind, u16(ws, w.actp[l - 1]), BH, H, u16(ws, w.wp[l]), (int64_t)H * H, H, out, (int)B, H, H,
+      PlanesGemmArgs pg = planes_args(w.pkind, u16(ws, w.actp[l - 1]), BH, H, wplane(d, w, ws, l), (int64_t)H * H, H, out, (int)B, H, H,
                                       1.0f / (kActPlaneScale * kWeightPlaneScale), nullptr);
       pg.e.col_scale = g.col_scale; pg.e.col_shift = g.col_shift; pg.e.relu = 1; pg.e.resid = g.resid;
       PL_TRY(launch_gemm_planes(kNT, pg, s));
@@ -402,13 +434,29 @@ extern "C" int pl_lifter_fwd_eval(const PLDesc* d, const float* x, float* y, int
 // ---------------------------------------------------------------------------------------
 // forward, training mode
 // ---------------------------------------------------------------------------------------
+// eval_bn: the forward of model.eval() computed by the TRAINING kernels, so that everything a backward pass needs is
+// saved in the workspace (pre-activations, ReLU bitmaps): BatchNorm normalises with the running statistics (which are
+// not touched), Dropout is the identity.  pl_lifter_fwd_eval is the fast, nothing-saved form of the same function.
+static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, void* ws, size_t ws_bytes,
+                          uint64_t seed, uint64_t step, const uint64_t* inject_keep, void* stream, bool eval_bn);
+
 extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, int64_t B, void* ws,
                                    size_t ws_bytes, uint64_t seed, uint64_t step,
                                    const uint64_t* inject_keep, void* stream) {
+  return fwd_saved_impl(d, x, y, B, ws, ws_bytes, seed, step, inject_keep, stream, false);
+}
+
+extern "C" int pl_lifter_fwd_eval_saved(const PLDesc* d, const float* x, float* y, int64_t B, void* ws,
+                                        size_t ws_bytes, void* stream) {
+  return fwd_saved_impl(d, x, y, B, ws, ws_bytes, 0, 0, nullptr, stream, true);
+}
+
+static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, void* ws, size_t ws_bytes,
+                          uint64_t seed, uint64_t step, const uint64_t* inject_keep, void* stream, bool eval_bn) {
   PL_TRY(check_desc(d, true));
   if (!x || !y) PL_FAIL(PL_EINVAL, "pl_lifter_fwd_train: null x/y");
   if (B <= 0) PL_FAIL(PL_ESHAPE, "pl_lifter_fwd_train: B=%lld", (long long)B);
-  if (d->bn && B < 2)
+  if (d->bn && B < 2 && !eval_bn)
     PL_FAIL(PL_EBATCH, "Expected more than 1 value per channel when training (B=%lld)", (long long)B);
   const Ws w = plan(d, B);
   PL_TRY(check_ws(w, ws, ws_bytes));
@@ -428,14 +476,14 @@ extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, in
     const bool skinny = l == 0 && skinny_supported(ly.K, H);
     const int groups = skinny ? skinny_stat_groups((int)B) : w.G;
     float* stat = f32(ws, w.stat);
-    if (d->bn) {
+    if (d->bn && !eval_bn) {
       g.stat_sum = stat + (size_t)sync_rank(d) * 2 * groups * H;
       g.stat_m2 = g.stat_sum + (size_t)groups * H;
     }
     if (skinny) {
       PL_TRY(launch_skinny_wide_out(a_in, ly.W, ly.b, g.C, (int)B, ly.K, H, false, g.stat_sum, g.stat_m2, s));
     } else if (w.planes && l > 0) {
-      PlanesGemmArgs pg = planes_args(w.pkind, u16(ws, w.actp[l - 1]), BH, H, u16(ws, w.wp[l]), (int64_t)H * H, H, g.C, (int)B, H, H,
+      PlanesGemmArgs pg = planes_args(w.pkind, u16(ws, w.actp[l - 1]), BH, H, wplane(d, w, ws, l), (int64_t)H * H, H, g.C, (int)B, H, H,
                                       1.0f / (kActPlaneScale * kWeightPlaneScale), nullptr);
       pg.e.bias = ly.b; pg.e.stat_sum = g.stat_sum; pg.e.stat_m2 = g.stat_m2;
       PL_TRY(launch_gemm_planes(kNT, pg, s));
@@ -443,7 +491,13 @@ extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, in
       PL_TRY(launch_gemm_f32(kNT, g, s));
     }
     const float *scale = nullptr, *shift = nullptr;
-    if (d->bn) {
+    if (d->bn && eval_bn) {
+      float* sc = f32(ws, w.scale) + (size_t)l * H;
+      float* sh = f32(ws, w.shift) + (size_t)l * H;
+      PL_TRY(launch_bn_eval_stats(ly.gamma, ly.beta, ly.rm, ly.rv, d->bn_eps, H, f32(ws, w.mean[l]), f32(ws, w.rstd[l]),
+                                  sc, sh, s));
+      scale = sc; shift = sh;
+    } else if (d->bn) {
       float* sc = f32(ws, w.scale) + (size_t)l * H;
       float* sh = f32(ws, w.shift) + (size_t)l * H;
       PL_TRY(sync_gather(d, stat, (int64_t)2 * groups * H, s));
@@ -457,8 +511,9 @@ extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, in
     if (w.planes && l + 1 < w.L) { po.h = u16(ws, w.actp[l]); po.l = po.h + BH; po.kind = w.pkind; }
     float* act = w.act_f32[l] ? f32(ws, w.act[l]) : nullptr;
     PL_TRY(launch_bn_apply(g.C, scale, shift, resid, act, u64(ws, w.bits[l]), (int)B, H,
-                           d->p_dropout, seed, step, l,
-                           inject_keep ? inject_keep + (size_t)l * inj_stride : nullptr, s, &po, d->step_dev));
+                           eval_bn ? 0.f : d->p_dropout, seed, step, l,
+                           inject_keep ? inject_keep + (size_t)l * inj_stride : nullptr, s, &po,
+                           eval_bn ? nullptr : d->step_dev));
     a_in = act;
   }
   return gemm_out_layer(a_in, d->params + P.off[4 * w.L], d->params + P.off[4 * w.L + 1], y, (int)B,
@@ -473,7 +528,7 @@ extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, in
 // at any layer boundary: the data-parallel driver all-reduces the first half's gradients while
 // the second half is still computing.
 static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B, void* ws, size_t ws_bytes,
-                    float* dx, float* grads, void* stream, bool do_output, int l_hi, int l_lo) {
+                    float* dx, float* grads, void* stream, bool do_output, int l_hi, int l_lo, bool eval_bn = false) {
   PL_TRY(check_desc(d, true));
   if (!x || !dy || !grads) PL_FAIL(PL_EINVAL, "pl_lifter_bwd: null x/dy/flat_grads");
   if (B <= 0) PL_FAIL(PL_ESHAPE, "pl_lifter_bwd: B=%lld", (long long)B);
@@ -482,7 +537,7 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
   const ParamLayout P = param_layout(d);
   hipStream_t s = (hipStream_t)stream;
   const int H = d->hidden, O = d->out_dim, Bi = (int)B;
-  const float kscale = (d->p_dropout > 0.f && d->p_dropout < 1.f) ? 1.0f / (1.0f - d->p_dropout) : 1.0f;
+  const float kscale = (!eval_bn && d->p_dropout > 0.f && d->p_dropout < 1.f) ? 1.0f / (1.0f - d->p_dropout) : 1.0f;
   float* slabs = f32(ws, w.slabs);
   float* GA = f32(ws, w.ga);
   float* GB = f32(ws, w.gb);
@@ -523,31 +578,31 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
     const float* z = f32(ws, w.z[l]);
     const bool pl_layer = w.planes && l > 0;       // this layer's dz feeds the planes GEMM pair
     float* dzs = (pl_layer && w.pkind == 2) ? f32(ws, w.dzscale) + 2 * l : nullptr;   // fp16 planes of dz are range-scaled
+    PlaneOut dzo = {nullptr, nullptr, 1.0f, dzs, 0};
+    if (pl_layer) { dzo.h = u16(ws, w.dzp); dzo.l = dzo.h + BH; dzo.kind = w.pkind; }
     if (d->bn) {
       // (pass 1 was tried inside the producing GEMM's epilogue: +17 us per GEMM for the 7.5 us
       //  kernel it removed -- every tile finishes at once, so epilogue work is pure tail)
       float* stat = f32(ws, w.stat);
-      float* mine = stat + (size_t)sync_rank(d) * 2 * w.RC * H;
+      float* mine = stat + (size_t)(eval_bn ? 0 : sync_rank(d)) * 2 * w.RC * H;
       PL_TRY(launch_bn_bwd_reduce(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), kscale, Bi, H,
-                                  mine, mine + (size_t)w.RC * H, s, 0, dzs ? f32(ws, w.amax) : nullptr));
-      PL_TRY(sync_gather(d, stat, (int64_t)2 * w.RC * H, s));
-      PL_TRY(launch_bn_bwd_finalize(stat, w.RC, sync_world(d), sync_rank(d), Bi, H, ly.gamma,
+                                  mine, mine + (size_t)w.RC * H, s, 0, dzs ? f32(ws, w.amax) : nullptr, w.RC));
+      if (!eval_bn) PL_TRY(sync_gather(d, stat, (int64_t)2 * w.RC * H, s));
+      PL_TRY(launch_bn_bwd_finalize(stat, w.RC, eval_bn ? 1 : sync_world(d), eval_bn ? 0 : sync_rank(d), Bi, H, ly.gamma,
                                     f32(ws, w.rstd[l]), f32(ws, w.coef), ly.ggamma, ly.gbeta, s,
-                                    dzs ? f32(ws, w.amax) : nullptr, n_amax, dzs));
+                                    dzs ? f32(ws, w.amax) : nullptr, n_amax, dzs, eval_bn ? 1 : 0));
     } else {
       PL_TRY(launch_fill(ly.ggamma, H, 0.f, s));
       PL_TRY(launch_fill(ly.gbeta, H, 0.f, s));
     }
-    PlaneOut dzo = {nullptr, nullptr, 1.0f, dzs, 0};
-    if (pl_layer) { dzo.h = u16(ws, w.dzp); dzo.l = dzo.h + BH; dzo.kind = w.pkind; }
     PL_TRY(launch_bn_bwd_dz(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), f32(ws, w.coef), kscale,
-                            d->bn, Bi, H, pl_layer ? nullptr : DZ, f32(ws, w.dbpart[l]), s, 0, &dzo));
+                            d->bn, Bi, H, pl_layer ? nullptr : DZ, f32(ws, w.dbpart[l]), s, 0, &dzo, w.RC));
     jpart.push_back(f32(ws, w.dbpart[l])); jout.push_back(ly.gb); jR.push_back(w.RC); jH.push_back(H);
     const float* a_in = l == 0 ? x : (w.planes ? nullptr : f32(ws, w.act[l - 1]));
     if (pl_layer) {
       // dX = dz W (NN) and dW = dz^T a (TN, split-K slabs) on the planes: one launch
       const int splits = tn_splits(H, H, Bi);
-      PlanesGemmArgs nn = planes_args(w.pkind, u16(ws, w.dzp), BH, H, u16(ws, w.wp[l]), (int64_t)H * H, H,
+      PlanesGemmArgs nn = planes_args(w.pkind, u16(ws, w.dzp), BH, H, wplane(d, w, ws, l), (int64_t)H * H, H,
                                       (l % 2 == 1) ? GA : GB, Bi, H, H, 1.0f / kWeightPlaneScale, dzs ? dzs + 1 : nullptr);
       if (l % 2 == 1) nn.e.addend = GA;
       PlanesGemmArgs tn = planes_args(w.pkind, u16(ws, w.dzp), BH, H, u16(ws, w.actp[l - 1]), BH, H,
@@ -592,6 +647,12 @@ extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, i
                              size_t ws_bytes, float* dx, float* grads, void* stream) {
   if (!d) PL_FAIL(PL_EINVAL, "descriptor is NULL");
   return bwd_impl(d, x, dy, B, ws, ws_bytes, dx, grads, stream, true, 2 * d->num_stage, 0);
+}
+
+extern "C" int pl_lifter_bwd_eval(const PLDesc* d, const float* x, const float* dy, int64_t B, void* ws,
+                                  size_t ws_bytes, float* dx, float* grads, void* stream) {
+  if (!d) PL_FAIL(PL_EINVAL, "descriptor is NULL");
+  return bwd_impl(d, x, dy, B, ws, ws_bytes, dx, grads, stream, true, 2 * d->num_stage, 0, true);
 }
 
 static int check_range(const PLDesc* d, int hi, int lo, const char* who) {

@@ -564,19 +564,33 @@ int conv_core(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, cons
 
 using namespace pl;
 
-extern "C" size_t pl_conv2d_nhwc_scratch_bytes(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH,
-                                               int KW, int stride, int pad) {
+// The 7x7 / Cin 3 stem has a scratch-free kernel of its own, but only for the epilogue it folds (BatchNorm scale / shift,
+// ReLU before the add): with a bias, a residual or relu == 2 the call takes the im2col path.  The plain query cannot
+// know the epilogue, so it answers for that worst case; pl_conv2d_nhwc_scratch_bytes_ex takes the epilogue flags
+// and answers exactly (0 for the stem as Model_3D calls it).
+static size_t conv_scratch(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH, int KW, int stride, int pad,
+                           bool stem_kernel_ok) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0) return 0;
   const int64_t Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
   if (Ho <= 0 || Wo <= 0) return 0;
   const int64_t M = B * Ho * Wo, K = (int64_t)KH * KW * Cin;
-  if (Cin == 3 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && Cout == 64) return 0;      // stem7x7_c3_kernel
+  if (stem_kernel_ok && Cin == 3 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && Cout == 64) return 0;   // stem7x7_c3_kernel
   if ((KH == 1 && KW == 1 && stride == 1 && pad == 0) || implicit_ok(M, Cin, Cout, K)) {
     const int splits = M % 128 == 0 && Cout % 128 == 0 ? conv_fwd_splits(M, Cout, K, PL_BF16X6) : 1;   // split-K slabs
     return splits > 1 ? (size_t)splits * M * Cout * sizeof(float) : 0;
   }
   const int64_t Kp = (K + 31) / 32 * 32;
   return ((size_t)M * Kp + (size_t)Cout * Kp) * sizeof(float);
+}
+
+extern "C" size_t pl_conv2d_nhwc_scratch_bytes(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH,
+                                               int KW, int stride, int pad) {
+  return conv_scratch(B, H, W, Cin, Cout, KH, KW, stride, pad, false);
+}
+
+extern "C" size_t pl_conv2d_nhwc_scratch_bytes_ex(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH,
+                                                  int KW, int stride, int pad, int has_bias, int has_resid, int relu) {
+  return conv_scratch(B, H, W, Cin, Cout, KH, KW, stride, pad, !has_bias && !has_resid && relu != 2);
 }
 
 extern "C" int pl_conv2d_nhwc_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* w,

@@ -11,6 +11,8 @@
 // partials, then a small finalize kernel): results are bitwise reproducible, no float
 // atomics anywhere.
 #include "philox.h"
+#include <stdlib.h>
+
 #include "pl_internal.h"
 
 namespace pl {
@@ -77,6 +79,24 @@ __device__ __forceinline__ float parts_sum(float v, float (*red)[RCOLS], int cl,
   return t;
 }
 
+// Pieces of the statistics finalize.  Floating-point contraction is OFF inside them: "SyncBN == one process on the
+// concatenated batch, bit for bit" is a tested property, and it must not depend on what the compiler contracts.
+__device__ __forceinline__ float bn_m2_term(float gsum, float gm2, float fn, float mean) {
+#pragma clang fp contract(off)
+  const float d = gsum / fn - mean;
+  return gm2 + fn * d * d;
+}
+__device__ __forceinline__ float bn_shift_of(float beta, float mean, float sc) {
+#pragma clang fp contract(off)
+  return beta - mean * sc;
+}
+__device__ __forceinline__ void bn_running_update(float& rm, float& rv, float mean, float var, float Bt, float mo) {
+#pragma clang fp contract(off)
+  const float unbiased = var * (Bt / (Bt - 1.0f));
+  rm = (1.0f - mo) * rm + mo * mean;
+  rv = (1.0f - mo) * rv + mo * unbiased;
+}
+
 // BatchNorm statistics finalize: Chan merge of (sum, M2) over 64-row groups.
 // stat = [world][2][G][H] (rank-major: G rows of sums, then G rows of M2); Br rows per rank.  Walking
 // the world*G partials in rank-major order is walking the concatenated batch's groups in row order,
@@ -112,8 +132,7 @@ __global__ __launch_bounds__(NTHR) void bn_finalize_kernel(
       const int n = max(0, min(gs, Br - gl * gs));
       if (n > 0) {
         const size_t at = (size_t)r * 2 * GH + (size_t)gl * H + c;
-        const float d = stat[at] / (float)n - mean;
-        m2 += stat[at + GH] + (float)n * d * d;
+        m2 += bn_m2_term(stat[at], stat[at + GH], (float)n, mean);
       }
     }
   const float m2t = parts_sum(m2, red, cl, part);
@@ -124,11 +143,11 @@ __global__ __launch_bounds__(NTHR) void bn_finalize_kernel(
     mean_out[c] = mean;
     rstd_out[c] = rstd;
     scale_out[c] = sc;
-    shift_out[c] = beta[c] - mean * sc;
+    shift_out[c] = bn_shift_of(beta[c], mean, sc);
     if (running_mean) {
-      const float unbiased = var * (Bt / (Bt - 1.0f));
-      running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
-      running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+      float rm = running_mean[c], rv = running_var[c];
+      bn_running_update(rm, rv, mean, var, Bt, momentum);
+      running_mean[c] = rm; running_var[c] = rv;
     }
   }
   if (batches && blockIdx.x == 0 && threadIdx.x == 0) batches[0] += 1;
@@ -266,30 +285,20 @@ __global__ __launch_bounds__(NTHR) void mask_by_bits_kernel(const float* __restr
 // grid = (ceil(H/256), gy), block = 256: wave w walks rows blockIdx.y*4+w, +4*gy, ...
 // Bitmap layout: row r, 256-column strip q, word j (0..3): bit l <-> column 256q + 4l + j.
 // -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHR) void bn_apply_kernel(
-    const float* __restrict__ z, const float* __restrict__ scale, const float* __restrict__ shift,
-    const float* resid, float* act, uint64_t* __restrict__ bits, int B, int H, int mode,
-    uint32_t thr, float kscale, uint32_t k0, uint32_t k1, uint32_t c3, uint32_t layer,
-    const uint64_t* __restrict__ inject, int Hc, PlaneOut po, const uint64_t* __restrict__ step_dev,
-    uint32_t seed_hi) {
-  const PlaneDst pd = plane_dst(po);
-  if (step_dev) {
-    // graph replay: the step number is base (baked into c3 / k1's slot as the low / high word) + the device counter
-    const uint64_t step = (((uint64_t)k1 << 32) | c3) + step_dev[0];
-    c3 = (uint32_t)step;
-    k1 = seed_hi ^ (uint32_t)(step >> 32);
-  }
-  // Hc: real columns behind the H virtual ones (bn_colstats_kernel); Hc == H for the lifter
-  // mode: 0 keep all, 1 philox, 2 injected bitmap, 3 drop all; + 8: no ReLU (BatchNorm alone; bitmap all ones)
-  const bool norelu = (mode & 8) != 0;
-  mode &= 7;
+// the row loop of bn_apply_kernel (sc, sh: the lane's four columns).
+// (Round 2 tried folding the statistics finalize into this kernel -- every workgroup re-deriving mean / rstd of its
+//  256-column strip from the 64 partials -- to drop the 6.6 us finalize launch per layer; likewise for the backward
+//  pass.  Same-box A/B, B = 4096: 0.7095 ms per step unfused against 0.80 (64 rows per workgroup), 0.80 (32), 0.92
+//  (128), 0.90 (16): the 128 KB prologue per workgroup costs more than the launch it removes.  Not kept.)
+__device__ __forceinline__ void bn_apply_rows(
+    const float* __restrict__ z, const float4 sc, const float4 sh, const float* resid, float* act,
+    uint64_t* __restrict__ bits, int B, int H, int mode, bool norelu, uint32_t thr, float kscale, uint32_t k0,
+    uint32_t k1, uint32_t c3, uint32_t layer, const uint64_t* __restrict__ inject, const PlaneDst& pd) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int strip = blockIdx.x;
   const int c = strip * 256 + lane * 4;
   const bool active = c < H;
   const int wpr = ((H + 255) >> 8) * 4;
-  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (active && scale) { sc = ld4(scale + c % Hc); sh = ld4(shift + c % Hc); }
   for (int r = blockIdx.y * 4 + wave; r < B; r += gridDim.y * 4) {
     const size_t off = (size_t)r * H + c;
     float y[4] = {0.f, 0.f, 0.f, 0.f};
@@ -335,6 +344,29 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(
       if (pd.kind) store_planes4(pd, off, out);
     }
   }
+}
+
+__global__ __launch_bounds__(NTHR) void bn_apply_kernel(
+    const float* __restrict__ z, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* resid, float* act, uint64_t* __restrict__ bits, int B, int H, int mode,
+    uint32_t thr, float kscale, uint32_t k0, uint32_t k1, uint32_t c3, uint32_t layer,
+    const uint64_t* __restrict__ inject, int Hc, PlaneOut po, const uint64_t* __restrict__ step_dev,
+    uint32_t seed_hi) {
+  const PlaneDst pd = plane_dst(po);
+  if (step_dev) {
+    // graph replay: the step number is base (baked into c3 / k1's slot as the low / high word) + the device counter
+    const uint64_t step = (((uint64_t)k1 << 32) | c3) + step_dev[0];
+    c3 = (uint32_t)step;
+    k1 = seed_hi ^ (uint32_t)(step >> 32);
+  }
+  // Hc: real columns behind the H virtual ones (bn_colstats_kernel); Hc == H for the lifter
+  // mode: 0 keep all, 1 philox, 2 injected bitmap, 3 drop all; + 8: no ReLU (BatchNorm alone; bitmap all ones)
+  const bool norelu = (mode & 8) != 0;
+  mode &= 7;
+  const int c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < H && scale) { sc = ld4(scale + c % Hc); sh = ld4(shift + c % Hc); }
+  bn_apply_rows(z, sc, sh, resid, act, bits, B, H, mode, norelu, thr, kscale, k0, k1, c3, layer, inject, pd);
 }
 
 // -------------------------------------------------------------------------------------
@@ -407,7 +439,7 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_finalize_kernel(
     const float* __restrict__ part_all, int RC, int world, int rank, int Br, int H,
     const float* __restrict__ gamma, const float* __restrict__ rstd, float* __restrict__ coef,
     float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ part_amax, int n_amax,
-    float* __restrict__ dz_scale) {
+    float* __restrict__ dz_scale, int eval_mode) {
   __shared__ float red[RPARTS][RCOLS];
   if (dz_scale && blockIdx.x == gridDim.x - 1) {
     // the extra workgroup: range bound of dz = c0 (dy - c1 - zhat c2), |c1| <= max|dy|, |c2| <= max|dy| (mean |zhat| <= 1):
@@ -468,8 +500,9 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_finalize_kernel(
   if (part == 0 && ok) {
     const float Bt = (float)Br * (float)world;
     coef[c] = gamma[c] * rstd[c];
-    coef[H + c] = tdy / Bt;
-    coef[2 * H + c] = tdyz / Bt;
+    // eval mode (running statistics are constants of the graph): dz = gamma rstd dy, no batch-mean terms
+    coef[H + c] = eval_mode ? 0.f : tdy / Bt;
+    coef[2 * H + c] = eval_mode ? 0.f : tdyz / Bt;
     dgamma[c] = rank < 0 ? tdyz : sdyz;
     dbeta[c] = rank < 0 ? tdy : sdy;
   }
@@ -492,24 +525,17 @@ __global__ __launch_bounds__(NTHR) void reduce_rows_kernel(const float* __restri
 // -------------------------------------------------------------------------------------
 // BN backward pass 2: dz = c0*(dy - c1 - zhat*c2) (or dz = dy without BN) + db partials.
 // -------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHR) void bn_bwd_dz_kernel(
-    const float* __restrict__ g, const uint64_t* __restrict__ bits, const float* __restrict__ z,
-    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ coef,
-    float kscale, int bn, int B, int H, float* __restrict__ dz, float* __restrict__ part_db, int Hc, PlaneOut po) {
-  __shared__ float4 sm[4][64];
-  const PlaneDst pd = plane_dst(po);
+// the row loop of bn_bwd_dz_kernel
+__device__ __forceinline__ void bn_bwd_dz_rows(
+    const float* __restrict__ g, const uint64_t* __restrict__ bits, const float* __restrict__ z, const float4 mu,
+    const float4 rs, const float4 c0, const float4 c1, const float4 c2, float kscale, int bn, int B, int H,
+    float* __restrict__ dz, float* __restrict__ part_db, const PlaneDst& pd, float4 (*sm)[64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int strip = blockIdx.x;
   const int c = strip * 256 + lane * 4;
   const bool active = c < H;
   const int wpr = ((H + 255) >> 8) * 4;
-  float4 zero = make_float4(0, 0, 0, 0);
-  float4 mu = zero, rs = zero, c0 = zero, c1 = zero, c2 = zero, sdb = zero;
-  if (active && bn) {
-    const int cc = c % Hc;
-    mu = ld4(mean + cc); rs = ld4(rstd + cc);
-    c0 = ld4(coef + cc); c1 = ld4(coef + Hc + cc); c2 = ld4(coef + 2 * Hc + cc);
-  }
+  float4 sdb = make_float4(0, 0, 0, 0);
   for (int r = blockIdx.y * 4 + wave; r < B; r += gridDim.y * 4) {
     if (!active) continue;
     const size_t off = (size_t)r * H + c;
@@ -533,6 +559,23 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_dz_kernel(
   }
   const float4 t = combine4(sdb, sm, wave, lane);
   if (wave == 0 && active) st4(part_db + (size_t)blockIdx.y * H + c, t);
+}
+
+__global__ __launch_bounds__(NTHR) void bn_bwd_dz_kernel(
+    const float* __restrict__ g, const uint64_t* __restrict__ bits, const float* __restrict__ z,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ coef,
+    float kscale, int bn, int B, int H, float* __restrict__ dz, float* __restrict__ part_db, int Hc, PlaneOut po) {
+  __shared__ float4 sm[4][64];
+  const PlaneDst pd = plane_dst(po);
+  const int c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
+  float4 zero = make_float4(0, 0, 0, 0);
+  float4 mu = zero, rs = zero, c0 = zero, c1 = zero, c2 = zero;
+  if (c < H && bn) {
+    const int cc = c % Hc;
+    mu = ld4(mean + cc); rs = ld4(rstd + cc);
+    c0 = ld4(coef + cc); c1 = ld4(coef + Hc + cc); c2 = ld4(coef + 2 * Hc + cc);
+  }
+  bn_bwd_dz_rows(g, bits, z, mu, rs, c0, c1, c2, kscale, bn, B, H, dz, part_db, pd, sm);
 }
 
 // -------------------------------------------------------------------------------------
@@ -621,6 +664,17 @@ __global__ void bn_fold_eval_kernel(const float* __restrict__ bias, const float*
     scale[c] = 1.f;
     shift[c] = bias[c];
   }
+}
+
+// eval-mode BatchNorm as the training kernels see it: "batch" statistics := the running ones
+__global__ void bn_eval_stats_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ rm, const float* __restrict__ rv, float eps, int H,
+                                     float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
+                                     float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= H) return;
+  const float r = 1.0f / sqrtf(rv[c] + eps), sc = gamma[c] * r;
+  mean[c] = rm[c]; rstd[c] = r; scale[c] = sc; shift[c] = bn_shift_of(beta[c], rm[c], sc);
 }
 
 __global__ void fill_kernel(float* p, int64_t n, float v) {
@@ -808,6 +862,13 @@ struct AdamWIn {
   int64_t t;
   const float* lr_dev;
   const uint64_t* t_dev;
+  // GEMM operand planes of the 1024-wide weight matrices, refreshed by the step that changes them (PLAdamWPlanes):
+  // the forward then needs no split pass of its own
+  int nseg, kind;
+  float pscale;
+  int64_t seg_off[PL_ADAMW_MAX_SEGS], seg_n[PL_ADAMW_MAX_SEGS];
+  unsigned short* seg_h[PL_ADAMW_MAX_SEGS];
+  unsigned short* seg_l[PL_ADAMW_MAX_SEGS];
 };
 
 __device__ __forceinline__ AdamWK adamw_consts(const AdamWIn& a) {
@@ -852,6 +913,18 @@ __global__ __launch_bounds__(NTHR) void adamw_kernel(float* __restrict__ p, cons
       adamw_one(pv.z, gv.z, mv.z, vv.z, k);
       adamw_one(pv.w, gv.w, mv.w, vv.w, k);
       st4(p + 4 * i, pv); st4(m + 4 * i, mv); st4(v + 4 * i, vv);
+      if (in.nseg) {                      // segment starts and lengths are multiples of 4: a float4 lies inside one
+        const int64_t e = 4 * i;
+#pragma unroll 1
+        for (int q = 0; q < in.nseg; ++q) {
+          const int64_t r = e - in.seg_off[q];
+          if (r >= 0 && r < in.seg_n[q]) {
+            const PlaneDst d = {in.seg_h[q], in.seg_l[q], in.pscale, in.kind};
+            store_planes4(d, (size_t)r, pv);
+            break;
+          }
+        }
+      }
     }
     i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   }
@@ -923,8 +996,8 @@ int bwd_row_chunks(int B, int H) {
 
 int launch_bn_bwd_reduce(const float* g, const uint64_t* bits, const float* z, const float* mean,
                          const float* rstd, float keep_scale, int B, int H, float* part_dy,
-                         float* part_dyz, hipStream_t s, int Hc, float* part_amax) {
-  dim3 grid((H + 255) / 256, bwd_row_chunks(B, H));
+                         float* part_dyz, hipStream_t s, int Hc, float* part_amax, int rc) {
+  dim3 grid((H + 255) / 256, rc > 0 ? rc : bwd_row_chunks(B, H));
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(NTHR), 0, s, g, bits, z, mean, rstd, keep_scale, B,
                      H, part_dy, part_dyz, Hc > 0 ? Hc : H, part_amax);
   PL_CHECK_LAUNCH("bn_bwd_reduce");
@@ -933,17 +1006,18 @@ int launch_bn_bwd_reduce(const float* g, const uint64_t* bits, const float* z, c
 
 int launch_bn_bwd_finalize(const float* part, int RC, int world, int rank, int B, int H,
                            const float* gamma, const float* rstd, float* coef, float* dgamma,
-                           float* dbeta, hipStream_t s, const float* part_amax, int n_amax, float* dz_scale) {
+                           float* dbeta, hipStream_t s, const float* part_amax, int n_amax, float* dz_scale,
+                           int eval_mode) {
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((H + RCOLS - 1) / RCOLS + (dz_scale ? 1 : 0)), dim3(NTHR), 0, s, part,
-                     RC, world, rank, B, H, gamma, rstd, coef, dgamma, dbeta, part_amax, n_amax, dz_scale);
+                     RC, world, rank, B, H, gamma, rstd, coef, dgamma, dbeta, part_amax, n_amax, dz_scale, eval_mode);
   PL_CHECK_LAUNCH("bn_bwd_finalize");
   return PL_OK;
 }
 
 int launch_bn_bwd_dz(const float* g, const uint64_t* bits, const float* z, const float* mean,
                      const float* rstd, const float* coef, float keep_scale, int bn, int B, int H,
-                     float* dz, float* part_db, hipStream_t s, int Hc, const PlaneOut* planes) {
-  dim3 grid((H + 255) / 256, bwd_row_chunks(B, H));
+                     float* dz, float* part_db, hipStream_t s, int Hc, const PlaneOut* planes, int rc) {
+  dim3 grid((H + 255) / 256, rc > 0 ? rc : bwd_row_chunks(B, H));
   const PlaneOut po = planes ? *planes : PlaneOut{nullptr, nullptr, 1.f, nullptr, 0};
   if (!dz && !po.kind) PL_FAIL(PL_EINVAL, "bn_bwd_dz: nothing to write");
   hipLaunchKernelGGL(bn_bwd_dz_kernel, grid, dim3(NTHR), 0, s, g, bits, z, mean, rstd, coef, keep_scale,
@@ -1027,6 +1101,14 @@ int launch_bn_fold_eval(const float* bias, const float* gamma, const float* beta
   hipLaunchKernelGGL(bn_fold_eval_kernel, dim3((H + NTHR - 1) / NTHR), dim3(NTHR), 0, s, bias, gamma, beta,
                      rm, rv, eps, bn, H, scale, shift);
   PL_CHECK_LAUNCH("bn_fold_eval");
+  return PL_OK;
+}
+
+int launch_bn_eval_stats(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int H,
+                         float* mean, float* rstd, float* scale, float* shift, hipStream_t s) {
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((H + NTHR - 1) / NTHR), dim3(NTHR), 0, s, gamma, beta, rm, rv, eps, H,
+                     mean, rstd, scale, shift);
+  PL_CHECK_LAUNCH("bn_eval_stats");
   return PL_OK;
 }
 
@@ -1119,18 +1201,47 @@ static int adamw_launch(float* p, const float* g, float* m, float* v, int64_t n,
   return PL_OK;
 }
 
+static AdamWIn adamw_in(float lr, float beta1, float beta2, float eps, float wd, float gscale, int64_t t,
+                        const float* lr_dev, const uint64_t* t_dev) {
+  AdamWIn in = {};
+  in.lr = lr; in.beta1 = beta1; in.beta2 = beta2; in.eps = eps; in.wd = wd; in.gscale = gscale; in.t = t;
+  in.lr_dev = lr_dev; in.t_dev = t_dev;
+  return in;
+}
+
 extern "C" int pl_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n, float lr,
                              float beta1, float beta2, float eps, float weight_decay, int64_t t,
                              float grad_scale, void* stream) {
-  const AdamWIn in = {lr, beta1, beta2, eps, weight_decay, grad_scale, t, nullptr, nullptr};
-  return adamw_launch(p, g, m, v, n, in, stream);
+  return adamw_launch(p, g, m, v, n, adamw_in(lr, beta1, beta2, eps, weight_decay, grad_scale, t, nullptr, nullptr), stream);
 }
 
 extern "C" int pl_adamw_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev,
                                  float beta1, float beta2, float eps, float weight_decay, int64_t t_base,
                                  const uint64_t* t_dev, float grad_scale, void* stream) {
   if (!lr_dev || !t_dev) PL_FAIL(PL_EINVAL, "pl_adamw_flat_dev: null lr / t pointer");
-  const AdamWIn in = {0.f, beta1, beta2, eps, weight_decay, grad_scale, t_base, lr_dev, t_dev};
+  return adamw_launch(p, g, m, v, n, adamw_in(0.f, beta1, beta2, eps, weight_decay, grad_scale, t_base, lr_dev, t_dev), stream);
+}
+
+extern "C" int pl_adamw_flat_planes(float* p, const float* g, float* m, float* v, int64_t n, float lr, const float* lr_dev,
+                                    float beta1, float beta2, float eps, float weight_decay, int64_t t,
+                                    const uint64_t* t_dev, float grad_scale, const PLAdamWPlanes* planes, void* stream) {
+  if ((lr_dev != nullptr) != (t_dev != nullptr)) PL_FAIL(PL_EINVAL, "pl_adamw_flat_planes: lr_dev and t_dev go together");
+  AdamWIn in = adamw_in(lr, beta1, beta2, eps, weight_decay, grad_scale, t, lr_dev, t_dev);
+  if (planes && planes->nseg > 0) {
+    if (planes->nseg > PL_ADAMW_MAX_SEGS || (planes->kind != 1 && planes->kind != 2) || !(planes->scale > 0.f))
+      PL_FAIL(PL_EINVAL, "pl_adamw_flat_planes: bad plane description");
+    if (!(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v)) || (n & 3))
+      PL_FAIL(PL_EINVAL, "pl_adamw_flat_planes: arenas must be 16-byte aligned, n %% 4 == 0");
+    in.nseg = planes->nseg; in.kind = planes->kind; in.pscale = planes->scale;
+    for (int q = 0; q < planes->nseg; ++q) {
+      const PLAdamWSeg& sg = planes->seg[q];
+      if (sg.offset < 0 || sg.numel <= 0 || (sg.offset & 3) || (sg.numel & 3) || sg.offset + sg.numel > n || !sg.h ||
+          (planes->kind == 2 && !sg.l) || (reinterpret_cast<uintptr_t>(sg.h) & 7) || (reinterpret_cast<uintptr_t>(sg.l) & 7))
+        PL_FAIL(PL_EINVAL, "pl_adamw_flat_planes: segment %d", q);
+      in.seg_off[q] = sg.offset; in.seg_n[q] = sg.numel;
+      in.seg_h[q] = static_cast<unsigned short*>(sg.h); in.seg_l[q] = static_cast<unsigned short*>(sg.l);
+    }
+  }
   return adamw_launch(p, g, m, v, n, in, stream);
 }
 

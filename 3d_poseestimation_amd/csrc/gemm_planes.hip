@@ -5,6 +5,8 @@
 // and their autograd), like gemm_f32.hip; same 128x128 tile per workgroup, same register epilogue (gemm_epilogue.h:
 // bias, training-mode BatchNorm partial statistics, eval-mode BN fold + ReLU + skip, residual-gradient addend, split-K
 // slabs).  512 threads: wavefronts 0-3 compute, wavefronts 4-7 drive the LDS-DMA.
+#include <stdlib.h>
+
 #include "gemm_epilogue.h"
 #include "gemm_planes.h"
 #include "pl_internal.h"
@@ -17,6 +19,7 @@ struct PlanesKern {
   GemmArgs e;
   float out_scale;
   const float* dyn_inv;
+  int vec_addend;          // POSELIFT_ADDEND_SCALAR=1 (same-box A/B): the addend through gemm_epilogue's dword loads
 };
 
 template <bool A_KS, bool B_KS, int MODE>
@@ -38,12 +41,48 @@ __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block
           acc[0][a][b][r] = fmaf(acc[1][a][b][r], 1.0f / plp::kF16LoScale, acc[0][a][b][r]) * os;
   }
   float* C = k.e.C + (k.e.split_k > 1 ? (size_t)slice * k.e.M * k.e.ldc : 0);
+  // dX of a residual block's first Linear adds the skip gradient (addend): read through gemm_epilogue's accumulator
+  // layout that is 64 dword loads per lane on 128-byte row segments and cost +14 us per launch (rocprofv3: 68.8 / 72.6 us
+  // for the two launches with an addend against 59.8 / 54.7 without).  Here: the wave's 64x64 block goes through its own
+  // 16 KB of LDS (free after the main loop) and the addend / result move as 16-byte accesses on 256-byte row segments.
+  if (k.vec_addend && k.e.addend && k.e.split_k <= 1 && !k.e.bias && !k.e.stat_sum && !k.e.col_scale && !k.e.resid && !k.e.relu &&
+      (k.e.ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(k.e.addend)) & 15) == 0) {
+    __syncthreads();                                   // every computing wave is done reading operand tiles
+    float* ldsw = reinterpret_cast<float*>(lds) + wave * 64 * 68;     // row stride 68 floats: conflict-free both ways
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ldsw[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + b * 32 + i] = acc[0][a][b][r];
+    const int lr = lane >> 4, lc = (lane & 15) * 4;
+    const size_t o0 = (size_t)(m0 + wm * 64 + lr) * k.e.ldc + n0 + wn * 64 + lc;
+    float4 q[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) q[it] = *reinterpret_cast<const float4*>(k.e.addend + o0 + (size_t)it * 4 * k.e.ldc);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const float4 v = *reinterpret_cast<const float4*>(ldsw + (it * 4 + lr) * 68 + lc);
+      // (same operation order as gemm_epilogue: v += addend)
+      *reinterpret_cast<float4*>(C + o0 + (size_t)it * 4 * k.e.ldc) =
+          make_float4(v.x + q[it].x, v.y + q[it].y, v.z + q[it].z, v.w + q[it].w);
+    }
+    return;
+  }
   gemm_epilogue<false, 2>(k.e, C, acc[0], m0, n0, wm, wn, i, h);
+}
+
+// LDS: three operand stages, and never less than the 4 x 17 KB the addend epilogue stages the output block in
+template <int MODE>
+constexpr int lds_bytes() {
+  constexpr int stages = plp::PlanesCfg<32, plp::ModeCfg<MODE>::NPL, 3>::LDS;
+  return stages > 4 * 64 * 68 * 4 ? stages : 4 * 64 * 68 * 4;
 }
 
 template <bool A_KS, bool B_KS, int MODE>
 __global__ __launch_bounds__(512) void planes_gemm_kernel(PlanesKern k) {
-  __shared__ __attribute__((aligned(16))) char lds[plp::PlanesCfg<32, plp::ModeCfg<MODE>::NPL, 3>::LDS];
+  __shared__ __attribute__((aligned(16))) char lds[lds_bytes<MODE>()];
   planes_body<A_KS, B_KS, MODE>(k, blockIdx.x, gridDim.x, lds);
 }
 
@@ -52,7 +91,7 @@ __global__ __launch_bounds__(512) void planes_gemm_kernel(PlanesKern k) {
 // and the tail of the first problem, which the second one's workgroups fill.
 template <int MODE>
 __global__ __launch_bounds__(512) void planes_gemm_dual_kernel(PlanesKern k0, PlanesKern k1, int n0) {
-  __shared__ __attribute__((aligned(16))) char lds[plp::PlanesCfg<32, plp::ModeCfg<MODE>::NPL, 3>::LDS];
+  __shared__ __attribute__((aligned(16))) char lds[lds_bytes<MODE>()];
   if ((int)blockIdx.x < n0)
     planes_body<false, true, MODE>(k0, blockIdx.x, n0, lds);
   else
@@ -73,6 +112,8 @@ PlanesKern kern_of(GemmLayout layout, const PlanesGemmArgs& a) {
   k.e = a.e;
   k.out_scale = a.out_scale;
   k.dyn_inv = a.dyn_inv;
+  static const int vec = [] { const char* e = getenv("POSELIFT_ADDEND_SCALAR"); return (e && e[0] == '1') ? 0 : 1; }();
+  k.vec_addend = vec;
   (void)layout;
   return k;
 }

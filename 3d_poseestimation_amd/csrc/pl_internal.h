@@ -139,20 +139,22 @@ int bwd_row_chunks(int B, int H);
 // part_amax (optional): [strips * RC][2] per-workgroup maxima of |dy| and |zhat| (the dz range bound, below)
 int launch_bn_bwd_reduce(const float* g, const uint64_t* bits, const float* z, const float* mean,
                          const float* rstd, float keep_scale, int B, int H, float* part_dy,
-                         float* part_dyz, hipStream_t s, int Hc = 0, float* part_amax = nullptr);
-// finalize: c = {gamma*rstd, sum_dy/B, sum_dyz/B}; dgamma, dbeta
-// (part = [world][2][RC][H]; coef uses all ranks' partials, dgamma/dbeta this rank's only)
+                         float* part_dyz, hipStream_t s, int Hc = 0, float* part_amax = nullptr, int rc = 0);
+
 // dz_scale (optional, with part_amax of n_amax workgroups): {S, 1/S}, S the power of two that maps the bound
 // max|c0| max|dy| (2 + max|zhat|) >= max|dz| to at most 2^14 (fp16 planes of dz, PL_F16X3)
 int launch_bn_bwd_finalize(const float* part, int RC, int world, int rank, int B, int H,
                            const float* gamma, const float* rstd, float* coef, float* dgamma,
                            float* dbeta, hipStream_t s, const float* part_amax = nullptr, int n_amax = 0,
-                           float* dz_scale = nullptr);
+                           float* dz_scale = nullptr, int eval_mode = 0);
+// eval-mode BatchNorm for the saved-state forward: mean := running mean, rstd := rsqrt(running var + eps), scale, shift
+int launch_bn_eval_stats(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int H,
+                         float* mean, float* rstd, float* scale, float* shift, hipStream_t s);
 // pass 2: dz = c0*(dy - c1 - zhat*c2)  (bn) or dz = dy (no bn); partial column sums of dz
 // planes: also (dz == NULL: only) write dz as GEMM operand planes
 int launch_bn_bwd_dz(const float* g, const uint64_t* bits, const float* z, const float* mean,
                      const float* rstd, const float* coef, float keep_scale, int bn, int B, int H,
-                     float* dz, float* part_db, hipStream_t s, int Hc = 0, const PlaneOut* planes = nullptr);
+                     float* dz, float* part_db, hipStream_t s, int Hc = 0, const PlaneOut* planes = nullptr, int rc = 0);
 
 // out[i] = sum_s slabs[s*n + i]
 int launch_reduce_slabs(const float* slabs, int nslab, int64_t n, float* out, hipStream_t s);

@@ -9,6 +9,7 @@ holders only: their tensors are views into flat arenas and every FLOP of forward
 backward runs in the HIP library.  There is no CPU or eager fallback.
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -34,17 +35,45 @@ class Linear(nn.Module):
         raise _lib.PoseliftError("residual blocks are evaluated by LinearModel.forward as one fused path")
 
 
-class _EvalNoBackward(torch.autograd.Function):
-    """Marks an eval-mode output so a later .backward() fails loudly instead of silently
-    producing no gradients (eval-mode backward belongs to the phase5 row)."""
+class _LifterEvalFn(torch.autograd.Function):
+    """model.eval() inside an autograd graph (phase5_loop/train_5.py:120 runs the lifter in eval mode with gradients
+    flowing through it into Model_2D): pl_lifter_fwd_eval_saved / pl_lifter_bwd_eval -- BatchNorm on the running
+    statistics, Dropout the identity, dx and every parameter gradient as torch computes them in eval mode."""
 
     @staticmethod
-    def forward(ctx, y, *anchors):
-        return y.view_as(y)
+    def forward(ctx, x2, model, ws, *params):
+        B = x2.shape[0]
+        y = torch.empty(B, model.output_size, dtype=torch.float32, device=x2.device)
+        try:
+            model._mark_wplanes()
+            _lib.check(_lib.lib().pl_lifter_fwd_eval_saved(
+                ctypes.byref(model._desc), x2.data_ptr(), y.data_ptr(), B, ws["buf"].data_ptr(), ws["bytes"],
+                _lib.current_stream_ptr()), "pl_lifter_fwd_eval_saved")
+        except BaseException:
+            model._release_workspace(ws, ws["busy"])
+            raise
+        ctx.model, ctx.ws, ctx.token = model, ws, ws["busy"]
+        ctx.ticket = _GraphTicket(model)
+        weakref.finalize(ctx, LinearModel._release_workspace, ws, ws["busy"])
+        weakref.finalize(ctx, ctx.ticket.close)
+        ctx.save_for_backward(x2)
+        ctx.need_dx = x2.requires_grad
+        model.last_workspace = ws
+        return y
 
     @staticmethod
-    def backward(ctx, g):
-        raise NotImplementedError("backward through an eval-mode LinearModel is not built yet")
+    def backward(ctx, gy):
+        (x2,) = ctx.saved_tensors
+        model, ws = ctx.model, ctx.ws
+        if not ctx.ticket.open:
+            raise _lib.PoseliftError("second backward through the same LinearModel forward (retain_graph): the saved "
+                                     "activations were released after the first one -- run the forward again")
+        try:
+            dx = model._run_bwd(x2, gy.contiguous(), ws, ctx.need_dx, last_graph=False, eval_mode=True)
+        finally:
+            ctx.ticket.close()
+            model._release_workspace(ws, ctx.token)
+        return (dx, None, None) + (None,) * len(model._param_list)
 
 
 def _overlap_ok(sync):
@@ -171,11 +200,57 @@ class LinearModel(nn.Module):
             params=flat.data_ptr(), bn_running=running.data_ptr(), bn_batches=batches.data_ptr())
         if self._sync_struct is not None:
             self._desc.sync = ctypes.pointer(self._sync_struct)
+        # GEMM operand planes of the 1024-wide weights (PL_F16X3 / PL_BF16), kept across calls: FlatAdamW refreshes them
+        # while it updates the parameters, so the forward has no weight-split pass.  _wplanes_ver = the version of the
+        # parameter arena they were derived from (any in-place torch op on a parameter bumps it: then they are stale
+        # and the next forward refreshes them itself).
+        self._wplanes, self._wplanes_ver = None, None
+        nbytes = 0
+        if flat.is_cuda and os.environ.get("POSELIFT_NO_WPLANES") != "1":     # (=1: same-box A/B of the per-call split)
+            try:
+                nbytes = _lib.lib().pl_wplanes_bytes(ctypes.byref(self._desc))
+            except _lib.PoseliftError:
+                nbytes = 0
+        if nbytes:
+            self._wplanes = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._desc.wplanes = self._wplanes.data_ptr()
+
+    def _mark_wplanes(self):
+        """Before a library call that runs a forward: tell it whether the persistent weight planes are current; the
+        call refreshes them when they are not, so afterwards they are."""
+        if self._wplanes is not None:
+            self._desc.wplanes_valid = int(self._wplanes_ver is not None and self._wplanes_ver == self._flat._version)
+            self._wplanes_ver = self._flat._version
+
+    def _ensure_wplanes(self):
+        if self._wplanes is not None and self._wplanes_ver != self._flat._version:
+            _lib.check(_lib.lib().pl_wplanes_refresh(ctypes.byref(self._desc), _lib.current_stream_ptr()), "pl_wplanes_refresh")
+            self._wplanes_ver = self._flat._version
+
+    def adamw_plane_segments(self):
+        """PLAdamWPlanes for pl_adamw_flat_planes, or None: where the weight planes of each 1024-wide Linear go."""
+        if self._wplanes is None:
+            return None
+        L = _lib.lib()
+        per = L.pl_wplanes_layer_bytes(ctypes.byref(self._desc))
+        H = self.linear_size
+        kind = 2 if self.compute_dtype == _lib.PL_F16X3 else 1
+        pl = _lib.PLAdamWPlanes(nseg=0, kind=kind, scale=L.pl_weight_plane_scale(), reserved=0)
+        n_hidden = len(self._named_holders())
+        if n_hidden - 1 > _lib.ADAMW_MAX_SEGS:
+            return None
+        for l in range(1, n_hidden):
+            s = self._slots[4 * l]
+            base = self._wplanes.data_ptr() + (l - 1) * per
+            pl.seg[l - 1] = _lib.PLAdamWSeg(offset=s.offset, numel=s.numel, h=base, l=base + 2 * H * H if kind == 2 else None)
+        pl.nseg = n_hidden - 1
+        return pl
 
     # ctypes descriptors and device workspaces are rebuilt, not copied (copy.deepcopy / torch.save(model))
     def __getstate__(self):
         st = self.__dict__.copy()
         for k in ("_desc", "_ws_pool", "_flat_grad", "_flat_grad_tmp", "_grad_sync", "last_workspace", "_inject_keep",
+                  "_wplanes", "_wplanes_ver",
                   "_sync_struct", "_gather_cb", "_sync_group", "_active_ws", "_cb_error"):
             st.pop(k, None)
         return st
@@ -358,6 +433,7 @@ class LinearModel(nn.Module):
             if tuple(inj.shape) != want or inj.element_size() != 8:
                 raise _lib.PoseliftError(f"inject_keep must be 64-bit words of shape {want}")
         self._step += 1
+        self._mark_wplanes()
         self._guarded(ws, lambda: _lib.lib().pl_lifter_fwd_train(
             ctypes.byref(self._desc), x2.data_ptr(), y.data_ptr(), B, ws["buf"].data_ptr(), ws["bytes"],
             self._seed, self._step, inj.data_ptr() if inj is not None else None,
@@ -365,7 +441,7 @@ class LinearModel(nn.Module):
         self.last_workspace = ws
         return y
 
-    def _run_bwd(self, x2, gy, ws, need_dx, last_graph=True):
+    def _run_bwd(self, x2, gy, ws, need_dx, last_graph=True, eval_mode=False):
         B = x2.shape[0]
         accumulate = any(p.grad is not None for p in self._param_list)
         sync = self._grad_sync
@@ -392,6 +468,8 @@ class LinearModel(nn.Module):
                 self._guarded(ws, lambda: _lib.lib().pl_lifter_bwd_layers(*args, hi, lo, _lib.current_stream_ptr()),
                               "pl_lifter_bwd_layers")
                 sync.launch_bucket(target[a_lo:a_hi])
+        elif eval_mode:
+            self._guarded(ws, lambda: _lib.lib().pl_lifter_bwd_eval(*args, _lib.current_stream_ptr()), "pl_lifter_bwd_eval")
         else:
             self._guarded(ws, lambda: _lib.lib().pl_lifter_bwd(*args, _lib.current_stream_ptr()), "pl_lifter_bwd")
         if accumulate:
@@ -423,6 +501,7 @@ class LinearModel(nn.Module):
             self._step += 1
             L = _lib.lib()
             self._desc.step_dev = step_dev.data_ptr() if step_dev is not None else None
+            self._mark_wplanes()
 
             def call(hi, lo):
                 self._guarded(ws, lambda: L.pl_lifter_train_fwd_bwd(
@@ -472,16 +551,17 @@ class LinearModel(nn.Module):
                 finally:
                     self._release_workspace(ws)
             ws = self._acquire_workspace(B)
+            if torch.is_grad_enabled() and (x2.requires_grad or any(p.requires_grad for p in self._param_list)):
+                return _LifterEvalFn.apply(x2, self, ws, *self._param_list)
             try:
                 y = torch.empty(B, self.output_size, dtype=torch.float32, device=x2.device)
+                self._mark_wplanes()
                 rc = _lib.lib().pl_lifter_fwd_eval(
                     ctypes.byref(self._desc), x2.data_ptr(), y.data_ptr(), B, ws["buf"].data_ptr(),
                     ws["bytes"], _lib.current_stream_ptr())
                 _lib.check(rc, "pl_lifter_fwd_eval")
             finally:
                 self._release_workspace(ws)
-            if torch.is_grad_enabled() and (x2.requires_grad or any(p.requires_grad for p in self._param_list)):
-                return _EvalNoBackward.apply(y, x2, *self._param_list)
             return y
 
 

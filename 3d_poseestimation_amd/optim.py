@@ -85,33 +85,36 @@ class FlatAdamW(torch.optim.Optimizer):
         _lib.require_device_tensor(flat, "parameters")
         g = self.param_groups[0]
         self._t += 1
-        with torch.cuda.device(flat.device):
-            for lo, hi in self._active_ranges():
-                rc = _lib.lib().pl_adamw_flat(
-                    flat.data_ptr() + 4 * lo, grads.data_ptr() + 4 * lo, self._m.data_ptr() + 4 * lo,
-                    self._v.data_ptr() + 4 * lo, hi - lo,
-                    float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                    float(g["weight_decay"]), self._t, float(grad_scale), _lib.current_stream_ptr())
-                _lib.check(rc, "pl_adamw_flat")
+        self._launch(float(g["lr"]), None, self._t, None, grad_scale)
         self._step_tensor.fill_(float(self._t))
         return loss
+
+    def _launch(self, lr, lr_dev, t, t_dev, grad_scale):
+        """One pl_adamw_flat_planes launch per run of active tensors.  With the whole arena active (the normal case)
+        the same launch refreshes the model's persistent GEMM weight planes while the new parameters are in registers."""
+        model = self._model
+        flat, grads = model.flat_params, model.flat_grads
+        g = self.param_groups[0]
+        ranges = self._active_ranges()
+        planes = model.adamw_plane_segments() if ranges == [(0, flat.numel())] else None
+        with torch.cuda.device(flat.device):
+            for lo, hi in ranges:
+                rc = _lib.lib().pl_adamw_flat_planes(
+                    flat.data_ptr() + 4 * lo, grads.data_ptr() + 4 * lo, self._m.data_ptr() + 4 * lo,
+                    self._v.data_ptr() + 4 * lo, hi - lo, float(lr), lr_dev.data_ptr() if lr_dev is not None else None,
+                    float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), int(t),
+                    t_dev.data_ptr() if t_dev is not None else None, float(grad_scale),
+                    _lib.ctypes.byref(planes) if planes is not None else None, _lib.current_stream_ptr())
+                _lib.check(rc, "pl_adamw_flat_planes")
+        # the raw-pointer write does not bump the arena's version counter: say explicitly what the planes now are
+        model._wplanes_ver = flat._version if planes is not None else None
 
     # ---- graph replay (train.GraphedTrainStep): the step with t and lr read from device memory ----------------
     def _enqueue_dev(self, lr_dev, t_base, t_dev, grad_scale=1.0):
         """Enqueue (or capture) one step whose t = t_base + *t_dev and lr = *lr_dev; host-side counters are the
         caller's business (a captured launch runs many times)."""
         self._bind()
-        model = self._model
-        flat, grads = model.flat_params, model.flat_grads
-        g = self.param_groups[0]
-        with torch.cuda.device(flat.device):
-            for lo, hi in self._active_ranges():
-                rc = _lib.lib().pl_adamw_flat_dev(
-                    flat.data_ptr() + 4 * lo, grads.data_ptr() + 4 * lo, self._m.data_ptr() + 4 * lo,
-                    self._v.data_ptr() + 4 * lo, hi - lo, lr_dev.data_ptr(),
-                    float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]),
-                    int(t_base), t_dev.data_ptr(), float(grad_scale), _lib.current_stream_ptr())
-                _lib.check(rc, "pl_adamw_flat_dev")
+        self._launch(0.0, lr_dev, t_base, t_dev, grad_scale)
 
     def _advance_host(self, n=1):
         self._t += n

@@ -163,6 +163,7 @@ class GraphedTrainStep:
                 dst.copy_(src)
             model._step, optimizer._t = step0, t0
             optimizer._step_tensor.fill_(float(t0))
+            model._ensure_wplanes()          # restoring the snapshot made the persistent weight planes stale
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
@@ -178,6 +179,7 @@ class GraphedTrainStep:
             self._lr_dev.fill_(lr)
         self._x.copy_(y1.reshape(self._x.shape))
         self._y.copy_(y2.reshape(self._y.shape))
+        self.model._ensure_wplanes()         # parameters changed behind the graph's back (load_state_dict, ...)
         self.graph.replay()
         self.model._step += 1
         self.opt._advance_host(1)

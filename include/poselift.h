@@ -104,6 +104,13 @@ typedef struct PLDesc {
    * pl_lifter_train_fwd_bwd increments it once per call, after the forward's last reader -- so a captured step draws fresh
    * dropout masks on every replay.  NULL: the `step` argument alone (the eager behaviour). */
   const uint64_t* step_dev;
+  /* Operand planes of the 1024-wide weights kept ACROSS calls (optional; caller-owned, pl_wplanes_bytes() bytes).
+   * NULL: every forward call splits the weights into its workspace first.  Set: the planes live here; with
+   * wplanes_valid != 0 the caller asserts they hold the current parameters (pl_adamw_flat_planes wrote them and nothing
+   * changed the parameters since) and the forward reads them as they are; with 0 the forward refreshes them first. */
+  void* wplanes;
+  int32_t wplanes_valid;
+  int32_t reserved2;
 } PLDesc;
 
 int pl_version(void);
@@ -147,6 +154,16 @@ int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, int64_t B,
 int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, int64_t B,
                   void* workspace, size_t workspace_bytes, float* dx,
                   float* flat_grads, void* stream);
+
+/* model.eval() with gradients flowing through it (phase5_loop/train_5.py:120 runs the lifter in eval mode inside the cycle
+ * graph): the eval forward computed so that its backward can follow -- BatchNorm on the running statistics (left
+ * untouched), Dropout = identity, pre-activations and ReLU bitmaps saved in the workspace -- and that backward: dx and
+ * the gradient of every parameter (dgamma, dbeta included, as torch computes them in eval mode).  Same numbers as
+ * pl_lifter_fwd_eval to fp32 round-off; pl_lifter_fwd_eval stays the fast path when nothing needs a gradient. */
+int pl_lifter_fwd_eval_saved(const PLDesc* d, const float* x, float* y, int64_t B,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int pl_lifter_bwd_eval(const PLDesc* d, const float* x, const float* dy, int64_t B,
+                       void* workspace, size_t workspace_bytes, float* dx, float* flat_grads, void* stream);
 
 /* The same backward restricted to a range of layers (data-parallel overlap, no reference
  * counterpart).  Layers are numbered along the chain: hidden Linears 0 .. L-1 (L = pl_num_hidden)
@@ -193,6 +210,10 @@ int pl_softargmax3d_nhwc_bwd(const float* logits, const float* stats, const floa
  * throughput mode; storage stays fp32). */
 size_t pl_conv2d_nhwc_scratch_bytes(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH,
                                     int KW, int stride, int pad);
+/* the same knowing the epilogue of the call (the 7x7 / Cin 3 stem needs no scratch unless it carries a bias, a residual
+ * or relu == 2; the plain query answers for that worst case) */
+size_t pl_conv2d_nhwc_scratch_bytes_ex(int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH,
+                                       int KW, int stride, int pad, int has_bias, int has_resid, int relu);
 int pl_conv2d_nhwc_fwd(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, const float* w,
                        int64_t Cout, int KH, int KW, int stride, int pad, const float* scale,
                        const float* shift, const float* bias, int relu, const float* resid, float* y,
@@ -331,6 +352,35 @@ int pl_adamw_flat(float* p, const float* g, float* m, float* v, int64_t n,
 int pl_adamw_flat_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev,
                       float beta1, float beta2, float eps, float weight_decay, int64_t t_base,
                       const uint64_t* t_dev, float grad_scale, void* stream);
+
+/* The step that ALSO refreshes the GEMM operand planes of the 1024-wide weight matrices (PL_F16X3: two fp16 planes,
+ * PL_BF16: the bf16 shadow) while the updated parameters are in registers: the forward of the next step then needs
+ * no weight split of its own (PLDesc.wplanes / wplanes_valid).  seg[q]: floats [offset, offset + numel) of the arena
+ * (both multiples of 4) -> plane h (and l) of numel 16-bit elements each.  lr_dev / t_dev as in pl_adamw_flat_dev, or
+ * both NULL (lr, t by value). */
+#define PL_ADAMW_MAX_SEGS 8
+typedef struct PLAdamWSeg {
+  int64_t offset, numel;
+  void* h;
+  void* l;              /* kind 2 only */
+} PLAdamWSeg;
+typedef struct PLAdamWPlanes {
+  int32_t nseg;
+  int32_t kind;         /* 1 bf16, 2 fp16 pair */
+  float scale;          /* the weight planes' power-of-two scale: pl_weight_plane_scale() */
+  int32_t reserved;
+  PLAdamWSeg seg[PL_ADAMW_MAX_SEGS];
+} PLAdamWPlanes;
+int pl_adamw_flat_planes(float* p, const float* g, float* m, float* v, int64_t n, float lr, const float* lr_dev,
+                         float beta1, float beta2, float eps, float weight_decay, int64_t t, const uint64_t* t_dev,
+                         float grad_scale, const PLAdamWPlanes* planes, void* stream);
+/* Layout of the caller-owned weight-plane buffer PLDesc.wplanes: pl_wplanes_bytes() bytes (0: this descriptor has no
+ * planes path); the planes of hidden layer l (1 <= l < n_hidden) start at byte (l - 1) * pl_wplanes_layer_bytes(d):
+ * plane h, then (PL_F16X3) plane l, hidden*hidden 16-bit elements each, row-major like the weight. */
+size_t pl_wplanes_bytes(const PLDesc* d);
+size_t pl_wplanes_layer_bytes(const PLDesc* d);
+float pl_weight_plane_scale(void);
+int pl_wplanes_refresh(const PLDesc* d, void* stream);   /* planes <- current parameters (wplanes_valid is ignored) */
 
 /* ---- building blocks exported for tests ------------------------------------------ */
 /* C[M][N] = op(A) op(B) on the fp32 MFMA path.

@@ -3,6 +3,7 @@ CPU (F.conv2d, fp32 -- the ATen arithmetic the reference's nn.Conv2d / BatchNorm
 phase4 backbone's layer shapes (phase4_joined/Resnet.py: Bottleneck conv2 3x3 with the stage's stride,
 1x1 downsample with stride 2, 1x1 conv3 with BN + residual + ReLU)."""
 import importlib
+import os
 import sys
 
 import numpy as np
@@ -344,18 +345,22 @@ def test_maxpool_backward_vs_torch(pkg, shape):
     assert rc == 0 and torch.equal(dx.cpu(), want)
 
 
-def test_model3d_train_step_vs_torch_autograd(pkg):
+@pytest.mark.parametrize("size", [64, 256])
+def test_model3d_train_step_vs_torch_autograd(pkg, size):
     """Model_3D in TRAINING mode end to end on the library's differentiable pieces (53 convolutions with dgrad and
     wgrad, 56 BatchNorms on batch statistics, max-pool, three transposed convolutions, biased 1x1, soft-argmax)
-    against the same stock modules under torch autograd on the CPU in fp64: loss and parameter gradients."""
+    against the same stock modules under torch autograd on the CPU in fp64: loss and parameter gradients.
+    size 256 = BASELINE configs[3]'s real frame size (phase4_joined/train.py:69-89 on 256 x 256 frames: 64 x 64 x 64
+    heat-map volumes, 8 x 8 layer4 maps); 64 is the quick case."""
     import copy
     torch.manual_seed(7)
     m = pkg.Model_3D().train()
     m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 51))
     with torch.no_grad():
         m.final_layer.weight.mul_(1e-3)
-    frames = pkg.synth.seeded_frames(2, 52, size=64)
+    frames = pkg.synth.seeded_frames(2, 52, size=size)
     target = torch.randn(2, 51)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     def torch_step(dtype):
         ref = copy.deepcopy(m).to(dtype)
         r = ref.preact
@@ -386,24 +391,64 @@ def test_model3d_train_step_vs_torch_autograd(pkg):
     loss = ((pred - target.to(DEV)) ** 2).mean()
     loss.backward()
     assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-4 * max(1.0, abs(float(loss_ref.detach())))
-    # Round-off is chaotic here (a ReLU at a 2x2 map flips and a tiny gradient changes discretely): judge the
-    # gradients in aggregate against the stock-fp32 floor, and each tensor only for gross errors.
-    checked, e2, f2, n2 = 0, 0.0, 0.0, 0.0
+    # Round-off is chaotic here (a ReLU at a small map flips and a tiny gradient changes discretely), so every tensor is
+    # judged against what stock fp32 does against its own fp64 -- but per tensor and in the relative L2 norm: an indexing
+    # bug in ONE layer's weight gradient gives a relative error of order 1 in that tensor, wherever its size puts it
+    # among the others, and cannot hide under a bound scaled by the tensor's largest element.
+    checked, e2, f2, n2, worst = 0, 0.0, 0.0, 0.0, (0.0, "")
     for (k, p), (_, q), (_, q32) in zip(md.named_parameters(), ref.named_parameters(), ref32.named_parameters()):
         if p.grad is None:
             continue
         gr = q.grad
-        scale = float(gr.abs().max())
-        if scale < 1e-12:
+        norm = float(gr.norm())
+        if float(gr.abs().max()) < 1e-12:
             continue
         d = p.grad.cpu().double() - gr
-        floor = float((q32.grad.double() - gr).abs().max())
-        assert float(d.abs().max()) < 30 * floor + 1e-2 * scale, (k, float(d.abs().max()), floor, scale)
+        rel = float(d.norm()) / norm
+        floor_rel = float((q32.grad.double() - gr).norm()) / norm
+        assert rel < min(max(25 * floor_rel, 5e-3), 0.5), (k, rel, floor_rel)
+        worst = max(worst, (rel, k))
+        scale = float(gr.abs().max())
         e2 += float((d / scale).pow(2).mean()); f2 += float(((q32.grad.double() - gr) / scale).pow(2).mean()); n2 += 1
         checked += 1
     assert (e2 / n2) ** 0.5 < 4 * (f2 / n2) ** 0.5 + 1e-4, ((e2 / n2) ** 0.5, (f2 / n2) ** 0.5)
     assert checked > 150
     assert float((md.preact.bn1.running_mean.cpu().double() - r.bn1.running_mean).abs().max()) < 1e-5
+
+
+def test_model3d_train_step_at_config4_size_properties(pkg):
+    """BASELINE configs[3] at its full size -- 256 x 256 frames, batch 256 -- through size-independent properties: the
+    training step (forward, loss, backward over 161 parameter tensors) is bitwise repeatable, every gradient is finite
+    and non-trivial, BatchNorm buffers move; the eval forward treats rows independently."""
+    torch.manual_seed(3)
+    m = pkg.Model_3D()
+    m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 71))
+    with torch.no_grad():
+        m.final_layer.weight.mul_(1e-3)
+    m = m.to(DEV).train()
+    B = 256
+    frames = pkg.synth.seeded_frames(B, 72, size=256).to(DEV)
+    target = torch.randn(B, 51, device=DEV) * 0.3
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    runs = []
+    for _ in range(2):
+        m.load_state_dict(sd0)
+        m.zero_grad(set_to_none=True)
+        loss = ((m(frames) - target) ** 2).mean()
+        loss.backward()
+        runs.append((loss.detach().clone(), [p.grad.clone() for p in m.parameters()]))
+    assert torch.equal(runs[0][0], runs[1][0])
+    n_nonzero = 0
+    for a, b in zip(runs[0][1], runs[1][1]):
+        assert torch.equal(a, b) and torch.isfinite(a).all()
+        n_nonzero += int(float(a.abs().max()) > 0)
+    assert n_nonzero >= len(runs[0][1]) - 2
+    assert not torch.equal(m.preact.bn1.running_mean, sd0["preact.bn1.running_mean"])
+    m.eval()
+    with torch.no_grad():
+        y_all = m(frames[:64])
+        y_sub = m(frames[8:24])
+    assert torch.allclose(y_all[8:24], y_sub, rtol=0, atol=2e-5)      # rows independent (split-K choices may differ by batch)
 
 
 def test_phase5_cycle_step_runs_and_couples_the_networks(pkg):

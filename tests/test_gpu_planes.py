@@ -220,3 +220,45 @@ def test_graphed_train_step_is_bitwise_the_eager_one(pkg, dtype, B, H):
     l1, _ = pkg.train_step(mg, og, *batches[0])
     l2, _ = pkg.train_step(me, oe, *batches[0])
     assert torch.equal(l1, l2)
+
+
+@pytest.mark.parametrize("dtype,B,H", [("fp32", 96, 128), ("f16x3", 256, 256), ("bf16x6", 160, 256)])
+def test_eval_mode_backward_vs_torch_twin(pkg, dtype, B, H):
+    """model.eval() inside an autograd graph -- phase5_loop/train_5.py:120 runs the lifter in eval mode with gradients
+    flowing through it (twice per graph) into Model_2D.  BatchNorm on non-trivial running statistics, Dropout the
+    identity: outputs, input gradient and every parameter gradient (dgamma / dbeta and the pre-BN biases included:
+    in eval mode they are ordinary affine parameters) against the stock-PyTorch twin in fp64 on the CPU; the running
+    statistics must not move."""
+    from oracle.torch_twin import TwinLifter
+    torch.manual_seed(17)
+    st = orc.init_state(34, 51, H, 2, rng=np.random.default_rng(5), nontrivial_bn=True)
+    sd = {k: torch.from_numpy(np.array(v)) for k, v in st.items()}
+    m = pkg.LinearModel(34, 51, linear_size=H, p_dropout=0.5, compute_dtype=dtype).to(DEV)
+    m.load_state_dict(sd)
+    m.eval()
+    tw = TwinLifter(34, 51, linear_size=H, p_dropout=0.5).double()
+    tw.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()})
+    tw.eval()
+    xa, xb = torch.rand(B, 34), torch.rand(B, 34)
+    ta, tb = torch.rand(B, 51) - 0.5, torch.rand(B, 51) - 0.5
+    outs = []
+    for model, dev, dt in ((m, DEV, torch.float32), (tw, "cpu", torch.float64)):
+        a = xa.clone().to(dev, dt).requires_grad_(True)
+        ya, yb = model(a), model(xb.to(dev, dt))                 # two calls in one graph, the second without dx
+        loss = ((ya - ta.to(dev, dt)) ** 2).mean() + 0.5 * ((yb - tb.to(dev, dt)) ** 2).mean()
+        loss.backward()
+        outs.append((ya.detach().cpu().double().numpy(), a.grad.cpu().double().numpy(),
+                     {k: p.grad.cpu().double().numpy() for k, p in model.named_parameters()}))
+    (yg, dxg, gg), (yc, dxc, gc) = outs
+    assert orc.mpjpe_mm(yg, yc) < 1e-3
+    with torch.no_grad():
+        assert orc.mpjpe_mm(m(xa.to(DEV)).cpu().numpy(), yg) < 1e-3     # the nothing-saved eval forward agrees
+    assert np.abs(dxg - dxc).max() <= 5e-4 * np.abs(dxc).max()
+    for k, v in gc.items():
+        rel = np.linalg.norm(gg[k] - v) / (np.linalg.norm(v) + 1e-30)
+        assert rel < 2e-4, (k, rel)
+    after = m.state_dict()
+    for k, v in sd.items():
+        if "running" in k or "num_batches" in k:
+            assert torch.equal(after[k].cpu(), v), k
+    assert m._live_graphs == 0

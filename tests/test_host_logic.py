@@ -50,6 +50,13 @@ def test_entry_points_reject_bad_arguments_before_touching_a_device(pkg):
     # scratch sizes: the stem's weight gradient needs its per-workgroup partials, a 1x1 nothing unless it is split
     assert L.pl_conv2d_nhwc_wgrad_scratch_bytes(2, 64, 64, 3, 64, 7, 7, 2, 3) == 512 * 64 * 147 * 4
     assert L.pl_conv2d_nhwc_scratch_bytes(64, 64, 64, 256, 1024, 1, 1, 1, 0) == 0       # 2048 x 8 tiles: no split
+    # the 7x7 stem: scratch-free with the epilogue its own kernel folds, im2col with a bias / residual / relu 2 -- the
+    # plain query answers for the worst case, so a caller that sized scratch through it never sees PL_EWORKSPACE
+    stem = (2, 256, 256, 3, 64, 7, 7, 2, 3)
+    im2col = (2 * 128 * 128 + 64) * 160 * 4
+    assert L.pl_conv2d_nhwc_scratch_bytes_ex(*stem, 0, 0, 1) == 0
+    assert L.pl_conv2d_nhwc_scratch_bytes_ex(*stem, 1, 0, 1) == im2col == L.pl_conv2d_nhwc_scratch_bytes_ex(*stem, 0, 0, 2)
+    assert L.pl_conv2d_nhwc_scratch_bytes(*stem) == im2col
     split = L.pl_conv2d_nhwc_scratch_bytes(4, 8, 8, 512, 512, 3, 3, 1, 1)              # layer4 conv2: 8 tiles
     assert split > 0 and split % (256 * 512 * 4) == 0
     assert L.pl_bn_train_scratch_bytes(0, 64) == 0 and L.pl_bn_train_scratch_bytes(4096, 64) > 0

@@ -1,0 +1,5 @@
+# same-box A/B of round-2 levers (bench.py headline step, ms per step)
+timeout -k 10 800 python -m pytest tests -q -m gpu > gpurun_out/t6.log 2>&1; echo rc=$?; tail -4 gpurun_out/t6.log
+for cfg in "A=0" "POSELIFT_ADDEND_SCALAR=1" "POSELIFT_NO_WPLANES=1" "A=0" "POSELIFT_ADDEND_SCALAR=1" "POSELIFT_NO_WPLANES=1" "A=0"; do
+  env $cfg timeout -k 10 120 python bench.py --steps 150 --warmup 30 --no-extras --no-cpu-baseline --no-prof 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$cfg', d['ms_per_step'], d['value'], d['batch_64']['ms_per_step'])"
+done
