@@ -135,6 +135,9 @@ struct Ws {
   std::vector<size_t> actp, wp;       // activation planes of layers 0..L-2, weight planes of layers 1..L-1
   std::vector<char> act_f32;          // is the fp32 activation of layer l materialised?
   size_t dzp, amax, dzscale;
+  // partial sums whose combine is deferred to the ONE reduce launch at the end of a backward range
+  size_t skp_out, skp_in;             // skinny weight-gradient partials of the output / input layer
+  std::vector<size_t> wslab;          // split-K slabs of the 1024-wide weight gradients, one set per layer (planes path)
 };
 
 Ws plan(const PLDesc* d, int64_t B) {
@@ -193,7 +196,11 @@ Ws plan(const PLDesc* d, int64_t B) {
   w.dyout = take((size_t)B * d->out_dim * 4);                 // d loss / d y of the fused train step
   w.mse = take(pl_mse_scratch_bytes(B * d->out_dim));
   w.dzp = w.amax = w.dzscale = 0;
+  w.skp_out = take((size_t)skinny_in_chunks((int)B) * d->out_dim * H * 4);
+  w.skp_in = take((size_t)skinny_in_chunks((int)B) * d->in_dim * H * 4);
   if (w.planes) {
+    w.wslab.push_back(0);
+    for (int l = 1; l < w.L; ++l) w.wslab.push_back(take((size_t)tn_splits(H, H, (int)B) * H * H * 4));
     for (int l = 0; l + 1 < w.L; ++l) w.actp.push_back(take(w.act_bytes));           // two fp16 planes = 4 B per element
     w.wp.push_back(0);
     for (int l = 1; l < w.L; ++l) w.wp.push_back(take((size_t)H * H * 4));
@@ -545,20 +552,23 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
   const int64_t BH = B * H;
   const int n_amax = ((H + 255) / 256) * w.RC;
   // bias gradients = column sums of partials; all of them are reduced by ONE launch at the end
-  std::vector<const float*> jpart; std::vector<float*> jout; std::vector<int> jR, jH;
+  std::vector<const float*> jpart; std::vector<float*> jout; std::vector<int> jR, jH, jkind, jtrans;
+  auto job = [&](const float* part, float* out, int R, int Hj, int kind, int transK) {
+    jpart.push_back(part); jout.push_back(out); jR.push_back(R); jH.push_back(Hj); jkind.push_back(kind); jtrans.push_back(transK);
+  };
 
   if (do_output) {
   // final Linear (LinearModel.w2): dW = dy^T h, db = sum dy, g = dy W
   const float* W5 = d->params + P.off[4 * w.L];
   const float* h_last = f32(ws, w.act[w.L - 1]);
   if (skinny_supported(O, H)) {
-    PL_TRY(launch_skinny_wide_in(dy, h_last, grads + P.off[4 * w.L], Bi, O, H, false, slabs, s));
+    PL_TRY(launch_skinny_wide_in(dy, h_last, grads + P.off[4 * w.L], Bi, O, H, false, f32(ws, w.skp_out), s, false));
+    job(f32(ws, w.skp_out), grads + P.off[4 * w.L], skinny_in_chunks(Bi), O * H, 0, 0);
   } else {
     PL_TRY(gemm_tn_reduced(dy, O, h_last, H, grads + P.off[4 * w.L], O, H, Bi, slabs, s));
   }
   PL_TRY(launch_colsum_partial(dy, Bi, O, f32(ws, w.outpart), s));
-  jpart.push_back(f32(ws, w.outpart)); jout.push_back(grads + P.off[4 * w.L + 1]);
-  jR.push_back(colsum_chunks(Bi)); jH.push_back(O);
+  job(f32(ws, w.outpart), grads + P.off[4 * w.L + 1], colsum_chunks(Bi), O, 0, 0);
   {
     GemmArgs g = {};
     g.A = dy; g.B = W5; g.C = GA; g.M = Bi; g.N = H; g.K = O; g.lda = O; g.ldb = H; g.ldc = H; g.split_k = 1;
@@ -597,7 +607,7 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
     }
     PL_TRY(launch_bn_bwd_dz(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), f32(ws, w.coef), kscale,
                             d->bn, Bi, H, pl_layer ? nullptr : DZ, f32(ws, w.dbpart[l]), s, 0, &dzo, w.RC));
-    jpart.push_back(f32(ws, w.dbpart[l])); jout.push_back(ly.gb); jR.push_back(w.RC); jH.push_back(H);
+    job(f32(ws, w.dbpart[l]), ly.gb, w.RC, H, 0, 0);
     const float* a_in = l == 0 ? x : (w.planes ? nullptr : f32(ws, w.act[l - 1]));
     if (pl_layer) {
       // dX = dz W (NN) and dW = dz^T a (TN, split-K slabs) on the planes: one launch
@@ -605,11 +615,12 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
       PlanesGemmArgs nn = planes_args(w.pkind, u16(ws, w.dzp), BH, H, wplane(d, w, ws, l), (int64_t)H * H, H,
                                       (l % 2 == 1) ? GA : GB, Bi, H, H, 1.0f / kWeightPlaneScale, dzs ? dzs + 1 : nullptr);
       if (l % 2 == 1) nn.e.addend = GA;
+      float* wsl = f32(ws, w.wslab[l]);                // this layer's own slabs: combined by the range's one reduce launch
       PlanesGemmArgs tn = planes_args(w.pkind, u16(ws, w.dzp), BH, H, u16(ws, w.actp[l - 1]), BH, H,
-                                      splits > 1 ? slabs : ly.gW, H, H, Bi, 1.0f / kActPlaneScale, dzs ? dzs + 1 : nullptr);
+                                      splits > 1 ? wsl : ly.gW, H, H, Bi, 1.0f / kActPlaneScale, dzs ? dzs + 1 : nullptr);
       tn.e.split_k = splits;
       PL_TRY(launch_gemm_planes_pair(nn, tn, s));
-      if (splits > 1) PL_TRY(launch_reduce_slabs(slabs, splits, (int64_t)H * H, ly.gW, s));
+      if (splits > 1) job(wsl, ly.gW, splits, H * H, 1, 0);
     } else if (l > 0) {
       // da_in = dz W and dW = dz^T a_in share dz and are independent: ONE launch.  A residual
       // block's first Linear also receives the skip gradient (in GA, added in the epilogue).
@@ -628,7 +639,8 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
       PL_TRY(launch_gemm_f32_pair(g, t, s));
       if (splits > 1) PL_TRY(launch_reduce_slabs(slabs, splits, (int64_t)H * H, ly.gW, s));
     } else if (skinny_supported(ly.K, H)) {
-      PL_TRY(launch_skinny_wide_in(a_in, DZ, ly.gW, Bi, ly.K, H, true, slabs, s));
+      PL_TRY(launch_skinny_wide_in(a_in, DZ, ly.gW, Bi, ly.K, H, true, f32(ws, w.skp_in), s, false));
+      job(f32(ws, w.skp_in), ly.gW, skinny_in_chunks(Bi), ly.K * H, 0, ly.K);
     } else {
       PL_TRY(gemm_tn_reduced(DZ, H, a_in, ly.K, ly.gW, H, ly.K, Bi, slabs, s));
     }
@@ -640,7 +652,8 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
     }
   }
   if (jpart.empty()) return PL_OK;
-  return launch_reduce_rows_multi(jpart.data(), jR.data(), jH.data(), jout.data(), (int)jpart.size(), s);
+  return launch_reduce_rows_multi(jpart.data(), jR.data(), jH.data(), jout.data(), (int)jpart.size(), s, jkind.data(),
+                                  jtrans.data());
 }
 
 extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, int64_t B, void* ws,

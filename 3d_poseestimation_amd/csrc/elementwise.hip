@@ -634,12 +634,31 @@ __global__ __launch_bounds__(NTHR) void colsum_partial_kernel(const float* __res
 }
 
 // several independent reduce_rows problems in one launch: blockIdx.y = job
-struct RowJobs { const float* part[8]; float* out[8]; int R[8]; int H[8]; };
+// Every fixed-order partial-sum combine of one backward range in ONE launch (blockIdx.y = job): the bias gradients
+// (many partial rows, few columns: 16 columns x 16 row-parts per workgroup, as reduce_rows_kernel), the skinny
+// layers' weight-gradient partials (transK: the transposed store of dW0), and the split-K slabs of the 1024-wide weight
+// gradients (few slabs, 1M outputs: streamed as float4, slab by slab in order -- kind 1).
+constexpr int kMaxRowJobs = 12;
+struct RowJobs { const float* part[kMaxRowJobs]; float* out[kMaxRowJobs]; int R[kMaxRowJobs]; int H[kMaxRowJobs];
+                 int kind[kMaxRowJobs]; int transK[kMaxRowJobs]; };
 __global__ __launch_bounds__(NTHR) void reduce_rows_multi_kernel(RowJobs j) {
   __shared__ float red[RPARTS][RCOLS];
   const int job = blockIdx.y;
   const int R = j.R[job], H = j.H[job];
   const float* __restrict__ part = j.part[job];
+  if (j.kind[job] == 1) {                    // H % 4 == 0, 16-byte aligned (checked on the host)
+    const int n4 = H >> 2;
+    for (int i = blockIdx.x * NTHR + threadIdx.x; i < n4; i += gridDim.x * NTHR) {
+      float4 a = ld4(part + 4 * (size_t)i);
+      for (int sl = 1; sl < R; ++sl) {
+        const float4 b = ld4(part + (size_t)sl * H + 4 * (size_t)i);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      st4(j.out[job] + 4 * (size_t)i, a);
+    }
+    return;
+  }
+  if (blockIdx.x * RCOLS >= H) return;
   const int cl = threadIdx.x & (RCOLS - 1), p = threadIdx.x / RCOLS;
   const int c = blockIdx.x * RCOLS + cl;
   float a = 0.f;
@@ -647,7 +666,15 @@ __global__ __launch_bounds__(NTHR) void reduce_rows_multi_kernel(RowJobs j) {
 #pragma unroll 8
     for (int k = p; k < R; k += RPARTS) a += part[(size_t)k * H + c];
   const float t = parts_sum(a, red, cl, p);
-  if (p == 0 && c < H) j.out[job][c] = t;
+  if (p == 0 && c < H) {
+    const int K = j.transK[job];
+    if (K > 0) {                             // c = k * (H / K) + col  ->  out[col][k]
+      const int Hc = H / K, k = c / Hc, col = c - k * Hc;
+      j.out[job][(size_t)col * K + k] = t;
+    } else {
+      j.out[job][c] = t;
+    }
+  }
 }
 
 __global__ void bn_fold_eval_kernel(const float* __restrict__ bias, const float* __restrict__ gamma,
@@ -1066,16 +1093,26 @@ int launch_reduce_slabs_bias(const float* slabs, int nslab, int rows, int cols, 
 }
 
 int launch_reduce_rows_multi(const float* const* part, const int* R, const int* H, float* const* out, int njobs,
-                             hipStream_t s) {
-  for (int base = 0; base < njobs; base += 8) {
+                             hipStream_t s, const int* kind, const int* transK) {
+  for (int base = 0; base < njobs; base += kMaxRowJobs) {
     RowJobs j = {};
-    const int n = njobs - base < 8 ? njobs - base : 8;
-    int maxH = 0;
+    const int n = njobs - base < kMaxRowJobs ? njobs - base : kMaxRowJobs;
+    int gx = 1;
     for (int k = 0; k < n; ++k) {
       j.part[k] = part[base + k]; j.out[k] = out[base + k]; j.R[k] = R[base + k]; j.H[k] = H[base + k];
-      if (H[base + k] > maxH) maxH = H[base + k];
+      j.kind[k] = kind ? kind[base + k] : 0;
+      j.transK[k] = transK ? transK[base + k] : 0;
+      int need;
+      if (j.kind[k] == 1) {
+        if ((j.H[k] & 3) || !aligned16(j.part[k]) || !aligned16(j.out[k])) PL_FAIL(PL_EINVAL, "reduce_rows_multi: slab job alignment");
+        need = ((j.H[k] >> 2) + NTHR - 1) / NTHR;
+        if (need > 1024) need = 1024;
+      } else {
+        need = (j.H[k] + RCOLS - 1) / RCOLS;
+      }
+      if (need > gx) gx = need;
     }
-    hipLaunchKernelGGL(reduce_rows_multi_kernel, dim3((maxH + RCOLS - 1) / RCOLS, n), dim3(NTHR), 0, s, j);
+    hipLaunchKernelGGL(reduce_rows_multi_kernel, dim3(gx, n), dim3(NTHR), 0, s, j);
     PL_CHECK_LAUNCH("reduce_rows_multi");
   }
   return PL_OK;

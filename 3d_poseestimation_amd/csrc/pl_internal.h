@@ -160,7 +160,7 @@ int launch_bn_bwd_dz(const float* g, const uint64_t* bits, const float* z, const
 int launch_reduce_slabs(const float* slabs, int nslab, int64_t n, float* out, hipStream_t s);
 // njobs independent out[c] = sum_r part[r][c] reductions in one launch
 int launch_reduce_rows_multi(const float* const* part, const int* R, const int* H, float* const* out, int njobs,
-                             hipStream_t s);
+                             hipStream_t s, const int* kind = nullptr, const int* transK = nullptr);
 // out[r][c] = bias[c] + sum_s slabs[s][r][c]
 int launch_reduce_slabs_bias(const float* slabs, int nslab, int rows, int cols, const float* bias,
                              float* out, hipStream_t s);
@@ -181,8 +181,11 @@ int skinny_chunks(int B);                      // row tasks (64 rows each)
 int skinny_stat_groups(int B);                 // 64-row BN statistics groups it emits
 int launch_skinny_wide_out(const float* X, const float* W, const float* bias, float* out, int B, int K,
                            int H, bool w_transposed, float* stat_sum, float* stat_m2, hipStream_t s);
+// reduce == false: only the partials are written (part: skinny_in_chunks(B) x K x H floats); the caller combines them
+// (launch_reduce_rows_multi: R = skinny_in_chunks(B), H = K*H, transK = K when out_transposed)
 int launch_skinny_wide_in(const float* X, const float* D, float* out, int B, int K, int H,
-                          bool out_transposed, float* part, hipStream_t s);
+                          bool out_transposed, float* part, hipStream_t s, bool reduce = true);
+int skinny_in_chunks(int B);
 bool skinny_narrow_out_supported(int H, int N);
 size_t skinny_narrow_out_part_floats(int B, int H);
 int launch_skinny_narrow_out(const float* h, const float* W, const float* bias, float* y, int B, int H,

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(NTHR) void skinny_narrow_out_reduce_kernel(const fl
 
 bool skinny_supported(int K, int H) { return (K == 34 || K == 51) && H % 128 == 0; }
 int skinny_chunks(int B) { return (B + RG - 1) / RG; }           // row tasks (wide_out; upper bound for wide_in)
-static int skinny_in_chunks(int B) { return (B + IN_CHUNK - 1) / IN_CHUNK; }
+int skinny_in_chunks(int B) { return (B + IN_CHUNK - 1) / IN_CHUNK; }
 int skinny_stat_groups(int B) { return (B + 63) / 64; }
 
 // forward of the input layer (+ BN statistics)  /  g = dy W5 (transposed weights, no bias)
@@ -335,13 +335,14 @@ int launch_skinny_wide_out(const float* X, const float* W, const float* bias, fl
 
 // out = X^T D, X [B][K], D [B][H]; out is [K][H] or, transposed, [H][K]; part: chunks*K*H floats
 int launch_skinny_wide_in(const float* X, const float* D, float* out, int B, int K, int H,
-                          bool out_transposed, float* part, hipStream_t s) {
+                          bool out_transposed, float* part, hipStream_t s, bool reduce) {
   if (!skinny_supported(K, H)) PL_FAIL(PL_ESHAPE, "skinny_wide_in: K=%d H=%d not specialised", K, H);
   const int nc = skinny_in_chunks(B);
   dim3 grid(nc * (H / 32)), block(NTHR);
   if (K == 34) hipLaunchKernelGGL((skinny_wide_in_kernel<34>), grid, block, 0, s, X, D, B, H, part);
   else hipLaunchKernelGGL((skinny_wide_in_kernel<51>), grid, block, 0, s, X, D, B, H, part);
   PL_CHECK_LAUNCH("skinny_wide_in");
+  if (!reduce) return PL_OK;
   const int n = K * H;
   if (out_transposed)
     hipLaunchKernelGGL((skinny_reduce_kernel<true>), dim3((n + 15) / 16), block, 0, s, part, nc, K, H, out);

@@ -159,8 +159,14 @@ def read_rooflines(pkg, L, dtype, one, traffic):
             return None
         avg_ms = ms.value / n_l.value
         ach = fl.value / n_l.value / (avg_ms * 1e-3) / 1e12
+        tr = None
+        if traffic:
+            tr = (traffic.get("per_dtype", {}).get(dtype, {}).get("dual" if "dual" in tkey else "forward", {})
+                  .get("hbm_bytes_per_launch"))
+            if tr is None and dtype == "bf16x6":
+                tr = traffic.get(tkey)                         # round-1 figures of the bf16x6 kernels
         r = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-             "frac": round(ach / peak, 4), "traffic": traffic.get(tkey) if traffic else None,
+             "frac": round(ach / peak, 4), "traffic": tr,
              "kernel": kernel, "flop_per_launch": fl.value / n_l.value,
              "avg_launch_us": round(avg_ms * 1e3, 2), "launches_timed": n_l.value,
              "sampling": f"HIP events around every {PROF_EVERY}th GEMM launch of the timed region"}

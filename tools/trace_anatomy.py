@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel anatomy of one train step from a rocprofv3 --kernel-trace database (results.db).
 
-    python tools/trace_anatomy.py gpurun_out/prof/r02_results.db [first_step] [n_steps]
+    python tools/trace_anatomy.py <results.db | *_kernel_trace.csv> [first_step] [n_steps]
 Steps are delimited by the AdamW launch; prints launches per step, GPU-busy time per step and per-kernel totals."""
 import collections
 import re
@@ -17,8 +17,14 @@ def short(n):
 
 
 def main():
-    db = sqlite3.connect(sys.argv[1])
-    rows = list(db.execute("select name, start, end from kernels order by start"))
+    if sys.argv[1].endswith(".csv"):                     # rocprofv3 --output-format csv: *_kernel_trace.csv
+        import csv
+        with open(sys.argv[1], newline="") as f:
+            rows = sorted(((r["Kernel_Name"], int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(f)),
+                          key=lambda r: r[1])
+    else:
+        db = sqlite3.connect(sys.argv[1])
+        rows = list(db.execute("select name, start, end from kernels order by start"))
     ad = [i for i, r in enumerate(rows) if "adamw" in r[0]]
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 10
     n = int(sys.argv[3]) if len(sys.argv) > 3 else 50
