@@ -75,6 +75,13 @@ inline int planes_kind(const PLDesc* d, int64_t B) {       // PlaneOut::kind of 
   if (!ok) return 0;
   return d->dtype == PL_F16X3 ? 2 : (d->dtype == PL_BF16 ? 1 : 0);
 }
+// BatchNorm-backward pass 1 of hidden layer l is folded into the epilogue of the dX GEMM of layer l+1 (which produces
+// its incoming gradient) whenever that GEMM is a planes GEMM: every hidden layer but the top one.  A pure function of
+// (descriptor, layer), so the ranges of a cut backward agree on it.  POSELIFT_BNR_UNFUSED=1: the separate pass (A/B).
+inline bool fused_reduce(const PLDesc* d, bool planes, int l, int L, bool eval_bn) {
+  static const bool off = [] { const char* e = getenv("POSELIFT_BNR_UNFUSED"); return e && e[0] == '1'; }();
+  return planes && d->bn && !eval_bn && !off && l < L - 1;
+}
 inline int arith_of(const PLDesc* d) { return d->dtype == PL_F16X3 ? (int)PL_BF16X6 : d->dtype; }
 
 struct ParamLayout {
@@ -205,7 +212,7 @@ Ws plan(const PLDesc* d, int64_t B) {
     w.wp.push_back(0);
     for (int l = 1; l < w.L; ++l) w.wp.push_back(take((size_t)H * H * 4));
     w.dzp = take(w.act_bytes);
-    w.amax = take((size_t)((H + 255) / 256) * w.RC * 2 * 4);
+    w.amax = take(std::max((size_t)((H + 255) / 256) * w.RC, (size_t)(B / 64) * (H / 64)) * 2 * 4);
     w.dzscale = take((size_t)w.L * 2 * 4);
   }
   w.total = o;
@@ -591,16 +598,22 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
     PlaneOut dzo = {nullptr, nullptr, 1.0f, dzs, 0};
     if (pl_layer) { dzo.h = u16(ws, w.dzp); dzo.l = dzo.h + BH; dzo.kind = w.pkind; }
     if (d->bn) {
-      // (pass 1 was tried inside the producing GEMM's epilogue: +17 us per GEMM for the 7.5 us
-      //  kernel it removed -- every tile finishes at once, so epilogue work is pure tail)
+      // pass 1 (column sums of dy and dy*zhat): a streaming kernel of its own, or -- round 2 -- already done by the
+      // LDS-staged epilogue of the planes GEMM that produced `gin` (round 1 tried it in the dword-per-lane epilogue of
+      // the fp32-operand GEMM: +17 us per GEMM for the 7.5 us kernel it removed)
+      const bool fr = fused_reduce(d, w.planes, l, w.L, eval_bn);
+      const int rc_l = fr ? Bi / 64 : w.RC;
+      const int n_amax_l = fr ? (Bi / 64) * (H / 64) : n_amax;
       float* stat = f32(ws, w.stat);
-      float* mine = stat + (size_t)(eval_bn ? 0 : sync_rank(d)) * 2 * w.RC * H;
-      PL_TRY(launch_bn_bwd_reduce(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), kscale, Bi, H,
-                                  mine, mine + (size_t)w.RC * H, s, 0, dzs ? f32(ws, w.amax) : nullptr, w.RC));
-      if (!eval_bn) PL_TRY(sync_gather(d, stat, (int64_t)2 * w.RC * H, s));
-      PL_TRY(launch_bn_bwd_finalize(stat, w.RC, eval_bn ? 1 : sync_world(d), eval_bn ? 0 : sync_rank(d), Bi, H, ly.gamma,
+      float* mine = stat + (size_t)((eval_bn || fr) ? 0 : sync_rank(d)) * 2 * rc_l * H;
+      if (!fr) {
+        PL_TRY(launch_bn_bwd_reduce(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), kscale, Bi, H,
+                                    mine, mine + (size_t)rc_l * H, s, 0, dzs ? f32(ws, w.amax) : nullptr, rc_l));
+        if (!eval_bn) PL_TRY(sync_gather(d, stat, (int64_t)2 * rc_l * H, s));
+      }
+      PL_TRY(launch_bn_bwd_finalize(stat, rc_l, eval_bn ? 1 : sync_world(d), eval_bn ? 0 : sync_rank(d), Bi, H, ly.gamma,
                                     f32(ws, w.rstd[l]), f32(ws, w.coef), ly.ggamma, ly.gbeta, s,
-                                    dzs ? f32(ws, w.amax) : nullptr, n_amax, dzs, eval_bn ? 1 : 0));
+                                    dzs ? f32(ws, w.amax) : nullptr, n_amax_l, dzs, eval_bn ? 1 : 0));
     } else {
       PL_TRY(launch_fill(ly.ggamma, H, 0.f, s));
       PL_TRY(launch_fill(ly.gbeta, H, 0.f, s));
@@ -615,6 +628,17 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
       PlanesGemmArgs nn = planes_args(w.pkind, u16(ws, w.dzp), BH, H, wplane(d, w, ws, l), (int64_t)H * H, H,
                                       (l % 2 == 1) ? GA : GB, Bi, H, H, 1.0f / kWeightPlaneScale, dzs ? dzs + 1 : nullptr);
       if (l % 2 == 1) nn.e.addend = GA;
+      if (fused_reduce(d, w.planes, l - 1, w.L, eval_bn)) {      // pass 1 of the layer below, on the block just produced
+        const bool lower_scaled = w.pkind == 2 && l - 1 > 0;       // its dz planes (fp16) want the range maxima too
+        nn.e.bnr_z = f32(ws, w.z[l - 1]);
+        nn.e.bnr_bits = u64(ws, w.bits[l - 1]);
+        nn.e.bnr_mean = f32(ws, w.mean[l - 1]);
+        nn.e.bnr_rstd = f32(ws, w.rstd[l - 1]);
+        nn.e.bnr_kscale = kscale;
+        nn.e.bnr_part_dy = f32(ws, w.stat);
+        nn.e.bnr_part_dyz = f32(ws, w.stat) + (size_t)(Bi / 64) * H;
+        nn.e.bnr_amax = lower_scaled ? f32(ws, w.amax) : nullptr;
+      }
       float* wsl = f32(ws, w.wslab[l]);                // this layer's own slabs: combined by the range's one reduce launch
       PlanesGemmArgs tn = planes_args(w.pkind, u16(ws, w.dzp), BH, H, u16(ws, w.actp[l - 1]), BH, H,
                                       splits > 1 ? wsl : ly.gW, H, H, Bi, 1.0f / kActPlaneScale, dzs ? dzs + 1 : nullptr);

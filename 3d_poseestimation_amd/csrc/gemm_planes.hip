@@ -45,8 +45,10 @@ __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block
   // layout that is 64 dword loads per lane on 128-byte row segments and cost +14 us per launch (rocprofv3: 68.8 / 72.6 us
   // for the two launches with an addend against 59.8 / 54.7 without).  Here: the wave's 64x64 block goes through its own
   // 16 KB of LDS (free after the main loop) and the addend / result move as 16-byte accesses on 256-byte row segments.
-  if (k.vec_addend && k.e.addend && k.e.split_k <= 1 && !k.e.bias && !k.e.stat_sum && !k.e.col_scale && !k.e.resid && !k.e.relu &&
-      (k.e.ldc & 3) == 0 && ((reinterpret_cast<uintptr_t>(C) | reinterpret_cast<uintptr_t>(k.e.addend)) & 15) == 0) {
+  const bool plain_out = k.e.split_k <= 1 && !k.e.bias && !k.e.stat_sum && !k.e.col_scale && !k.e.resid && !k.e.relu &&
+                         (k.e.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
+  if (plain_out && ((k.vec_addend && k.e.addend) || k.e.bnr_z) &&
+      (!k.e.addend || (reinterpret_cast<uintptr_t>(k.e.addend) & 15) == 0)) {
     __syncthreads();                                   // every computing wave is done reading operand tiles
     float* ldsw = reinterpret_cast<float*>(lds) + wave * 64 * 68;     // row stride 68 floats: conflict-free both ways
 #pragma unroll
@@ -57,16 +59,72 @@ __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block
         for (int r = 0; r < 16; ++r)
           ldsw[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + b * 32 + i] = acc[0][a][b][r];
     const int lr = lane >> 4, lc = (lane & 15) * 4;
-    const size_t o0 = (size_t)(m0 + wm * 64 + lr) * k.e.ldc + n0 + wn * 64 + lc;
-    float4 q[16];
+    const int row0 = m0 + wm * 64 + lr, col0 = n0 + wn * 64 + lc;
+    const size_t o0 = (size_t)row0 * k.e.ldc + col0;
+    float4 v[16];
+    if (k.e.addend) {
+      float4 q[16];
 #pragma unroll
-    for (int it = 0; it < 16; ++it) q[it] = *reinterpret_cast<const float4*>(k.e.addend + o0 + (size_t)it * 4 * k.e.ldc);
+      for (int it = 0; it < 16; ++it) q[it] = *reinterpret_cast<const float4*>(k.e.addend + o0 + (size_t)it * 4 * k.e.ldc);
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-      const float4 v = *reinterpret_cast<const float4*>(ldsw + (it * 4 + lr) * 68 + lc);
-      // (same operation order as gemm_epilogue: v += addend)
-      *reinterpret_cast<float4*>(C + o0 + (size_t)it * 4 * k.e.ldc) =
-          make_float4(v.x + q[it].x, v.y + q[it].y, v.z + q[it].z, v.w + q[it].w);
+      for (int it = 0; it < 16; ++it) {
+        const float4 t = *reinterpret_cast<const float4*>(ldsw + (it * 4 + lr) * 68 + lc);
+        v[it] = make_float4(t.x + q[it].x, t.y + q[it].y, t.z + q[it].z, t.w + q[it].w);   // (gemm_epilogue's order)
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < 16; ++it) v[it] = *reinterpret_cast<const float4*>(ldsw + (it * 4 + lr) * 68 + lc);
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) *reinterpret_cast<float4*>(C + o0 + (size_t)it * 4 * k.e.ldc) = v[it];
+    if (k.e.bnr_z) {
+      // BatchNorm-backward pass 1 of the layer below on the block just produced (GemmArgs::bnr_*): the separate pass read
+      // g (16.8 MB) back from HBM, here it is in registers.  One partial row per 64-row block, in a fixed order.
+      const int N = k.e.N;
+      const int wpr = ((N + 255) >> 8) * 4;
+      const int strip = col0 >> 8, bit = (col0 & 255) >> 2;
+      const float4 mu = *reinterpret_cast<const float4*>(k.e.bnr_mean + col0);
+      const float4 rs = *reinterpret_cast<const float4*>(k.e.bnr_rstd + col0);
+      const float ks = k.e.bnr_kscale;
+      float4 zz[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) zz[it] = *reinterpret_cast<const float4*>(k.e.bnr_z + o0 + (size_t)it * 4 * k.e.ldc);
+      float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+      float mxd = 0.f, mxz = 0.f;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const uint64_t* bw = k.e.bnr_bits + (size_t)(row0 + 4 * it) * wpr + strip * 4;
+        const ulonglong2 w01 = *reinterpret_cast<const ulonglong2*>(bw), w23 = *reinterpret_cast<const ulonglong2*>(bw + 2);
+        const float d0 = ((w01.x >> bit) & 1ull) ? v[it].x * ks : 0.f;
+        const float d1 = ((w01.y >> bit) & 1ull) ? v[it].y * ks : 0.f;
+        const float d2 = ((w23.x >> bit) & 1ull) ? v[it].z * ks : 0.f;
+        const float d3 = ((w23.y >> bit) & 1ull) ? v[it].w * ks : 0.f;
+        const float z0 = (zz[it].x - mu.x) * rs.x, z1 = (zz[it].y - mu.y) * rs.y;
+        const float z2 = (zz[it].z - mu.z) * rs.z, z3 = (zz[it].w - mu.w) * rs.w;
+        s1.x += d0; s1.y += d1; s1.z += d2; s1.w += d3;
+        s2.x = fmaf(d0, z0, s2.x); s2.y = fmaf(d1, z1, s2.y); s2.z = fmaf(d2, z2, s2.z); s2.w = fmaf(d3, z3, s2.w);
+        mxd = fmaxf(fmaxf(mxd, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
+        mxz = fmaxf(fmaxf(mxz, fmaxf(fabsf(z0), fabsf(z1))), fmaxf(fabsf(z2), fabsf(z3)));
+      }
+      // lanes l, l^16, l^32, l^48 hold the same four columns (rows lr = 0..3 mod 4): fixed-order butterfly
+#pragma unroll
+      for (int o = 16; o <= 32; o <<= 1) {
+        s1.x += __shfl_xor(s1.x, o); s1.y += __shfl_xor(s1.y, o); s1.z += __shfl_xor(s1.z, o); s1.w += __shfl_xor(s1.w, o);
+        s2.x += __shfl_xor(s2.x, o); s2.y += __shfl_xor(s2.y, o); s2.z += __shfl_xor(s2.z, o); s2.w += __shfl_xor(s2.w, o);
+      }
+      const int rg = (m0 >> 6) + wm;                   // 64-row block of the whole matrix
+      if (lr == 0) {
+        *reinterpret_cast<float4*>(k.e.bnr_part_dy + (size_t)rg * N + col0) = s1;
+        *reinterpret_cast<float4*>(k.e.bnr_part_dyz + (size_t)rg * N + col0) = s2;
+      }
+      if (k.e.bnr_amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mxd = fmaxf(mxd, __shfl_xor(mxd, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o)); }
+        if (lane == 0) {
+          float* q = k.e.bnr_amax + ((size_t)rg * (N >> 6) + (n0 >> 6) + wn) * 2;
+          q[0] = mxd; q[1] = mxz;
+        }
+      }
     }
     return;
   }

@@ -60,6 +60,18 @@ struct GemmArgs {
   // NHWC input x [B][H][W][Cin]; row m = (b, oh, ow), k = (kh*KW + kw)*Cin + ci, element
   // x[b][oh*stride - pad + kh][ow*stride - pad + kw][ci] or 0 outside the image.  B = weights [N][K] (OHWI).
   int conv_cin, conv_h, conv_w, conv_ho, conv_wo, conv_kw, conv_stride, conv_pad_h, conv_pad_w;
+  // BatchNorm-backward pass 1 of the layer BELOW, folded into the epilogue of the dX GEMM that produces its incoming
+  // gradient (planes GEMM only; bnr_z == NULL otherwise): C is g = d(act of that layer); with its saved z, ReLU/dropout
+  // bitmap, batch mean and rstd the epilogue also emits, per 64-row block and column, sum dy and sum dy*zhat
+  // (dy = g * bit * bnr_kscale) -- [M/64][N] each -- and per (64-row block, 64-column block) max |dy| and max |zhat|.
+  const float* bnr_z;
+  const uint64_t* bnr_bits;
+  const float* bnr_mean;
+  const float* bnr_rstd;
+  float bnr_kscale;
+  float* bnr_part_dy;       // [M/64][N]
+  float* bnr_part_dyz;      // [M/64][N]
+  float* bnr_amax;          // [(M/64) * (N/64)][2] or NULL
 };
 
 // y = conv2d(x, w) as an implicit GEMM on the PL_BF16X6 planes pipeline; a.A = x, a.B = w [Cout][KH*KW*Cin],
