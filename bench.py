@@ -228,6 +228,26 @@ def side_measurements(pkg, a, dev, x_eval, y_oracle):
                                         "roofline_forward": rl[1] and {k: rl[1][k] for k in ("achieved", "peak", "frac", "avg_launch_us")}}
         del m, opt
 
+    # the headline step captured once as a hipGraph and replayed (train.GraphedTrainStep; bitwise the eager step)
+    torch.manual_seed(0)
+    mg = pkg.LinearModel(34, 51, compute_dtype=a.dtype).to(dev).train()
+    og = pkg.FlatAdamW(mg, lr=1e-4)
+    gstep = pkg.GraphedTrainStep(mg, og, xb, yb)
+    res["this_library_%s_hipgraph_replay" % a.dtype] = {"poses_per_s": round(timed(lambda: gstep(xb, yb)), 1)}
+    x64, y64 = pkg.synth.synthetic_batch(64, 98, dev)
+    torch.manual_seed(0)
+    m64 = pkg.LinearModel(34, 51, compute_dtype=a.dtype).to(dev).train()
+    g64 = pkg.GraphedTrainStep(m64, pkg.FlatAdamW(m64, lr=1e-4), x64, y64)
+    for _ in range(20):
+        g64(x64, y64)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        g64(x64, y64)
+    torch.cuda.synchronize()
+    res["batch_64_hipgraph_replay"] = {"ms_per_step": round(1e3 * (time.perf_counter() - t0) / 200, 4)}
+    del mg, og, gstep, m64, g64
+
     for name, autocast in (("pytorch_rocm_eager_fp32", False), ("pytorch_rocm_eager_bf16_autocast", True)):
         torch.manual_seed(0)
         tw = TwinLifter(34, 51).to(dev).train()
