@@ -326,7 +326,9 @@ __global__ __launch_bounds__(NTHR) void mask_by_bits_kernel(const float* __restr
 // (Round 2 tried folding the statistics finalize into this kernel -- every workgroup re-deriving mean / rstd of its
 //  256-column strip from the 64 partials -- to drop the 6.6 us finalize launch per layer; likewise for the backward
 //  pass.  Same-box A/B, B = 4096: 0.7095 ms per step unfused against 0.80 (64 rows per workgroup), 0.80 (32), 0.92
-//  (128), 0.90 (16): the 128 KB prologue per workgroup costs more than the launch it removes.  Not kept.)
+//  (128), 0.90 (16): the 128 KB prologue per workgroup costs more than the launch it removes.  Not kept.
+//  Also tried: two rows per trip with both rows' loads issued first (here and in bn_bwd_dz_rows): 0.6543 / 0.6524 ms
+//  against 0.6446 / 0.6446 for one row per trip, same box -- eight short waves per CU already overlap their round trips.)
 __device__ __forceinline__ void bn_apply_rows(
     const float* __restrict__ z, const float4 sc, const float4 sh, const float* resid, float* act,
     uint64_t* __restrict__ bits, int B, int H, int mode, bool norelu, uint32_t thr, float kscale, uint32_t k0,
