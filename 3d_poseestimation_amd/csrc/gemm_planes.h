@@ -147,6 +147,18 @@ __device__ __forceinline__ f32x16 mfma16(const s16x8 a, const s16x8 b, const f32
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// timing-only (ABL 4 / 5): the FLOPs of one 32x32x16 MFMA issued as two 16x16x32 ones on quarters of the accumulator --
+// garbage arithmetic, the question is only which shape the chip clocks higher under this loop's load (guide: DVFS item 7)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x16 mfma16_as_two_16x16x32(const s16x8 a, const s16x8 b, f32x16 c) {
+  f32x4 lo = __builtin_shufflevector(c, c, 0, 1, 2, 3), hi = __builtin_shufflevector(c, c, 4, 5, 6, 7);
+  lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), lo, 0, 0, 0);
+  hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), hi, 0, 0, 0);
+  c[0] = lo[0]; c[1] = lo[1]; c[2] = lo[2]; c[3] = lo[3];
+  c[4] = hi[0]; c[5] = hi[1]; c[6] = hi[2]; c[7] = hi[3];
+  return c;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -177,7 +189,7 @@ __device__ __forceinline__ void sched_half() {
 //          a lone wave per SIMD issues in order, so with NLW = 0 every DMA issue is matrix-pipe idle time (measured:
 //          1.26 us per 32-k tile against 0.81 us of MFMA time).  Waves w and w+4 share a SIMD: the loader's stall
 //          costs the computing wave nothing.  acc is meaningful in waves 0-3 only (`return false` for loaders).
-// ABL (timing-only builds of the microbenchmark): 1 no MFMAs, 2 no DMA, 3 DMA only.
+// ABL (timing-only builds of the microbenchmark): 1 no MFMAs, 2 no DMA, 3 DMA only, 4 the MFMAs as 16x16x32, 5 = 2 + 4.
 template <bool A_KS, bool B_KS, int BKX, int MODE, int NLW = 0, int ABL = 0, int NST = 3>
 __device__ __forceinline__ bool planes_mainloop(const PlanesArgs& p, const int block_id, const int nwork,
                                                 char* __restrict__ lds, f32x16 (&acc)[ModeCfg<MODE>::NACC][2][2],
@@ -238,7 +250,7 @@ __device__ __forceinline__ bool planes_mainloop(const PlanesArgs& p, const int b
     ob[j] = (int)glds_lane_off<B_KS, BKX>(lw + 4 * j, lane, p.ldb);
   }
   auto issue = [&](const int kt, const int stage_off) {
-    if (ABL == 2) return;
+    if (ABL == 2 || ABL == 5) return;
     const int sa = kt * ga_step, sb = kt * gb_step;
     char* d = lds + stage_off + lw * 1024;
 #pragma unroll
@@ -307,6 +319,7 @@ __device__ __forceinline__ bool planes_mainloop(const PlanesArgs& p, const int b
     if (ABL == 0 || ABL == 2)                                                                            \
       acc[c][aa][bb] = mfma16<MODE>(fa[set][aa][ia], fb[set][bb][ib], acc[c][aa][bb]);                    \
     else if (ABL == 1) asm volatile("" ::"v"(fa[set][aa][ia]), "v"(fb[set][bb][ib]));                    \
+    else if (ABL == 4 || ABL == 5) acc[c][aa][bb] = mfma16_as_two_16x16x32(fa[set][aa][ia], fb[set][bb][ib], acc[c][aa][bb]); \
   } while (0)
   // products of one 32x32 output tile and one 16-deep k step (bf16x6: smallest terms first, the round-1 order)
 #define PLP_MFS(set, aa, bb)                                                                     \
@@ -345,7 +358,7 @@ __device__ __forceinline__ bool planes_mainloop(const PlanesArgs& p, const int b
     // steady state, first half: the fragment reads two per MFMA shadow, then one DMA issue per MFMA shadow
     if (STEADY && ABL == 0) sched_half<KSTEPS == 2 ? NDS : 0, NVM, NMF>();
     __builtin_amdgcn_sched_barrier(0);
-    if (NLW == 0 && ABL != 2) {
+    if (NLW == 0 && ABL != 2 && ABL != 5) {
       if (do_issue) wait_vmcnt<Cf::NDMA>(); else wait_vmcnt<0>();   // tile kt+1 (issued a whole tile ago) has landed
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this tile's fragment reads have left LDS (WAR on the stage)
@@ -365,7 +378,7 @@ __device__ __forceinline__ bool planes_mainloop(const PlanesArgs& p, const int b
   if (NLW == 0) {
     issue(0, st[0]);
     if (nk > 1) issue(1, st[1]);
-    if (ABL != 2) { if (nk > 1) wait_vmcnt<Cf::NDMA>(); else wait_vmcnt<0>(); }
+    if (ABL != 2 && ABL != 5) { if (nk > 1) wait_vmcnt<Cf::NDMA>(); else wait_vmcnt<0>(); }
   }
   barrier();
   PLP_FRAGS(0, st[0], 0);

@@ -1,0 +1,247 @@
+// The planes GEMM main loop on v_mfma_f32_16x16x32 (gemm_planes.h has the 32x32x16 form and everything shared).
+//
+// Why a second shape: under this loop's load the chip holds a higher matrix clock on the 16x16x32 shape (the guide's
+// DVFS note; measured here with a timing-only build that issues each 32x32x16 MFMA as two 16x16x32 ones on the same
+// registers: 30.0 -> 27.4 us per 4096x1024x1024 f16x3 GEMM, MFMA-only 23.9 -> 22.5 us).  Same tile (128x128, BK 32,
+// three LDS stages, four computing + four loader wavefronts), same DMA, same planes; what changes is the fragment
+// geometry, the accumulator layout (and with it the epilogue, which is LDS-staged throughout: gemm_planes.hip).
+//
+//   v_mfma_f32_16x16x32_{f16,bf16}: lane l holds A[row l&15][k = 8 (l>>4) + j], B[k = 8 (l>>4) + j][col l&15], j < 8;
+//   D: col l&15, row 4 (l>>4) + reg, reg < 4.  A wave's 64x64 block = 4x4 such tiles: acc[4][4] of 4 floats.
+//   One BK-32 tile is ONE k step: per plane 4 A fragments + 4 B fragments (one ds_read_b128, or two transposing
+//   ds_read_b64_tr_b16, each) feed 16 MFMAs per product.
+// Registers (256 per wave with eight waves per workgroup): 2 x 64 accumulators (f16x3) leave room for one A fragment
+// set and two B sets, so the prefetch is staggered: A[2,3] of tile kt is read under the MFMAs of A[0,1], and after the
+// mid-step barrier A[0,1] and B of tile kt+1 are read under the MFMAs of A[2,3].
+#pragma once
+#include "gemm_planes.h"
+
+namespace plp {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// k-contiguous image [128 rows][64 B]: the DMA writes it linearly, the 16-byte chunk a lane FETCHES is XORed with
+// f(row) = (-(row >> 2)) & 3 -- for the 16x16x32 read pattern (16 consecutive rows x the 4 chunks per wave instruction)
+// every 16-lane group of ds_read_b128 then covers the 16 slots of the 256-byte bank row exactly once.
+__device__ __forceinline__ int kc16_swz(int row) { return (0 - (row >> 2)) & 3; }
+
+template <bool KS>
+__device__ __forceinline__ uint32_t glds_lane_off16(int rb, int lane, int ld) {
+  if (!KS) {   // 16 rows x 64 B per instruction
+    const int row = rb * 16 + (lane >> 2);
+    const int ch = (lane & 3) ^ kc16_swz(row);
+    return (uint32_t)(row * ld * 2 + ch * 16);
+  }
+  return glds_lane_off<true, 32>(rb, lane, ld);   // k-strided image: as the 32x32x16 loop (the guide's layout (b))
+}
+
+// per-lane LDS byte offsets of the fragment reads inside one plane of one operand tile
+template <bool KS>
+struct FragAddr16 {
+  uint32_t b[KS ? 8 : 1];
+  __device__ __forceinline__ void init(int wq, int lane) {
+    const int r = lane & 15, q = lane >> 4;
+    if (!KS) {
+      // row wq*64 + t*16 + r (t adds 1024 bytes: (16 rows >> 2) & 3 == 0, the swizzle does not depend on t), chunk q
+      const int row = wq * 64 + r;
+      b[0] = (uint32_t)(row * 64 + ((q ^ kc16_swz(row)) << 4));
+    } else {
+      // group g = lane >> 4 reads k rows 8g + 4u .. +3 (u = 0, 1) of the tile's 16 columns c0 .. c0+15; lane 4qq+pp of the
+      // group supplies row qq, columns 4pp .. 4pp+3 and receives column (lane & 15)
+      const int qq = r >> 2, pp = r & 3;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int row = 8 * q + 4 * u + qq;
+          const int ch = wq * 8 + t * 2 + (pp >> 1);
+          const int x = ((row & 3) << 2) | ((row >> 2) & 3);
+          b[t * 2 + u] = (uint32_t)(256 * row + 16 * (ch ^ x) + 8 * (pp & 1));
+        }
+    }
+  }
+};
+
+template <bool KS>
+__device__ __forceinline__ s16x8 read_frag16(const char* op, const FragAddr16<KS>& fa, int t) {
+  if (!KS) return *reinterpret_cast<const s16x8*>(op + fa.b[0] + t * 1024);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(op + fa.b[t * 2 + 0]));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(op + fa.b[t * 2 + 1]));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int MODE>
+__device__ __forceinline__ f32x4v mfma16x16(const s16x8 a, const s16x8 b, const f32x4v c) {
+  if constexpr (MODE == kF16x3)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// acc[c][rt][ct][reg]: row = m0 + wm*64 + rt*16 + 4*(lane>>4) + reg, col = n0 + wn*64 + ct*16 + (lane&15)
+// Whole tiles only (as planes_mainloop); 512 threads; returns false in the loader waves.
+template <bool A_KS, bool B_KS, int MODE>
+__device__ __forceinline__ bool planes_mainloop16(const PlanesArgs& p, const int block_id, const int nwork,
+                                                  char* __restrict__ lds, f32x4v (&acc)[ModeCfg<MODE>::NACC][4][4],
+                                                  int& m0, int& n0, int& slice) {
+  static_assert(MODE == kF16x3 || MODE == kBf16, "two fp16 planes or one bf16 plane");
+  constexpr int NPL = ModeCfg<MODE>::NPL, NACC = ModeCfg<MODE>::NACC;
+  using Cf = PlanesCfg<32, NPL, 3>;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= 4;
+  const int lw = wave & 3;
+  const int wm = (wave & 3) >> 1, wn = wave & 1;
+
+  const int tiles_n = p.N / 128;
+  const int splits = p.split_k > 1 ? p.split_k : 1;
+  const int ntiles = nwork / splits;
+  int w = block_id;
+  if ((nwork & 7) == 0) w = (w & 7) * (nwork >> 3) + (w >> 3);   // XCD-aware: blocks b and b+8 share an L2
+  slice = w / ntiles;
+  const int t = w - slice * ntiles;
+  m0 = (t / tiles_n) * 128;
+  n0 = (t % tiles_n) * 128;
+  int kbeg = 0, kend = p.K;
+  if (splits > 1) {
+    const int per = ((p.K / 32 + splits - 1) / splits) * 32;
+    kbeg = min(slice * per, p.K);
+    kend = min(kbeg + per, p.K);
+  }
+  const int nk = (kend - kbeg) / 32;
+
+#pragma unroll
+  for (int c = 0; c < NACC; ++c)
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[c][a][b][r] = 0.f;
+  if (nk <= 0) return !loader;
+
+  const __bf16* ta = A_KS ? p.A + (size_t)kbeg * p.lda + m0 : p.A + (size_t)m0 * p.lda + kbeg;
+  const __bf16* tb = B_KS ? p.B + (size_t)kbeg * p.ldb + n0 : p.B + (size_t)n0 * p.ldb + kbeg;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(ta), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(tb), 0, 0x7fffffff, 0x00020000);
+  const int ga_step = A_KS ? 32 * p.lda * 2 : 64;
+  const int gb_step = B_KS ? 32 * p.ldb * 2 : 64;
+  const int apl = (int)(p.a_plane * 2), bpl = (int)(p.b_plane * 2);
+  auto barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int st[3] = {0, Cf::STAGE, 2 * Cf::STAGE};      // st[q] = stage of tile kt + q
+  auto rotate = [&]() { const int o = st[0]; st[0] = st[1]; st[1] = st[2]; st[2] = o; };
+
+  if (loader) {
+    int oa[2], ob[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      oa[j] = (int)glds_lane_off16<A_KS>(lw + 4 * j, lane, p.lda);
+      ob[j] = (int)glds_lane_off16<B_KS>(lw + 4 * j, lane, p.ldb);
+    }
+    auto issue = [&](const int kt, const int stage_off) {
+      const int sa = kt * ga_step, sb = kt * gb_step;
+      char* d = lds + stage_off + lw * 1024;
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          PLP_BLDS16(ra, d + pl * Cf::OPP + j * 4096, oa[j], sa + pl * apl);
+          PLP_BLDS16(rb, d + (NPL + pl) * Cf::OPP + j * 4096, ob[j], sb + pl * bpl);
+        }
+    };
+    issue(0, st[0]);
+    if (nk > 1) { issue(1, st[1]); wait_vmcnt<Cf::NDMA>(); } else { wait_vmcnt<0>(); }
+    barrier();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 2 < nk) { issue(kt + 2, st[2]); wait_vmcnt<Cf::NDMA>(); } else { wait_vmcnt<0>(); }
+      barrier();
+      rotate();
+    }
+    return false;
+  }
+
+  FragAddr16<A_KS> fra;
+  FragAddr16<B_KS> frb;
+  fra.init(wm, lane);
+  frb.init(wn, lane);
+  s16x8 fa[4][NPL];          // A fragments of the tile in flight (row tiles 0..3)
+  s16x8 fb[2][4][NPL];       // B fragments: set P of tile kt, set 1-P of tile kt+1
+
+#define PLP16_READ_A(stage_off, t0, t1)                                                      \
+  do {                                                                                       \
+    const char* q_ = lds + (stage_off);                                                      \
+    _Pragma("unroll") for (int t2 = (t0); t2 < (t1); ++t2)                                   \
+    _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                       \
+      fa[t2][pl] = read_frag16<A_KS>(q_ + pl * Cf::OPP, fra, t2);                            \
+  } while (0)
+#define PLP16_READ_B(set, stage_off)                                                         \
+  do {                                                                                       \
+    const char* q_ = lds + (stage_off) + NPL * Cf::OPP;                                      \
+    _Pragma("unroll") for (int t2 = 0; t2 < 4; ++t2)                                         \
+    _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                       \
+      fb[set][t2][pl] = read_frag16<B_KS>(q_ + pl * Cf::OPP, frb, t2);                       \
+  } while (0)
+  // one 16x16 output tile, one 32-deep k step: f16x3 = main product on accumulator 0, the two cross terms on 1
+#define PLP16_MFS(set, rt, ct)                                                                         \
+  do {                                                                                                 \
+    if constexpr (MODE == kF16x3) {                                                                    \
+      acc[1][rt][ct] = mfma16x16<MODE>(fa[rt][0], fb[set][ct][1], acc[1][rt][ct]);                      \
+      acc[1][rt][ct] = mfma16x16<MODE>(fa[rt][1], fb[set][ct][0], acc[1][rt][ct]);                      \
+    }                                                                                                  \
+    acc[0][rt][ct] = mfma16x16<MODE>(fa[rt][0], fb[set][ct][0], acc[0][rt][ct]);                        \
+  } while (0)
+#define PLP16_ROWS(set, r0, r1)                                                              \
+  do {                                                                                       \
+    _Pragma("unroll") for (int rt = (r0); rt < (r1); ++rt)                                   \
+    _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) PLP16_MFS(set, rt, ct);                 \
+  } while (0)
+
+  constexpr int RA = NPL * (A_KS ? 2 : 1), RB = NPL * (B_KS ? 2 : 1);     // ds_reads per fragment tile
+  constexpr int NMF = 8 * ModeCfg<MODE>::NPROD;                           // MFMAs per half step
+  auto step = [&](const int kt, auto par, auto steady) {
+    constexpr int P = decltype(par)::value;
+    constexpr bool STEADY = decltype(steady)::value;
+    const bool has_next = STEADY || kt + 1 < nk;
+    PLP16_READ_A(st[0], 2, 4);                 // this tile's lower row tiles, under the MFMAs of the upper ones
+    PLP16_ROWS(P, 0, 2);
+    if (STEADY) sched_half<2 * RA, 0, NMF>();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this tile's fragment reads have left LDS (WAR on the stage)
+    barrier();
+    if (has_next) {
+      PLP16_READ_A(st[1], 0, 2);
+      PLP16_READ_B(1 - P, st[1]);
+    }
+    PLP16_ROWS(P, 2, 4);
+    if (STEADY) sched_half<2 * RA + 4 * RB, 0, NMF>();
+    __builtin_amdgcn_sched_barrier(0);
+    rotate();
+  };
+
+  barrier();
+  PLP16_READ_A(st[0], 0, 2);
+  PLP16_READ_B(0, st[0]);
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  int kt = 0;
+  for (; kt + 3 < nk; kt += 2) {
+    step(kt, P0{}, std::true_type{});
+    step(kt + 1, P1{}, std::true_type{});
+  }
+  for (; kt < nk; kt += 2) {
+    step(kt, P0{}, std::false_type{});
+    if (kt + 1 < nk) step(kt + 1, P1{}, std::false_type{});
+  }
+#undef PLP16_READ_A
+#undef PLP16_READ_B
+#undef PLP16_MFS
+#undef PLP16_ROWS
+  return true;
+}
+
+}  // namespace plp

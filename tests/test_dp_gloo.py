@@ -56,6 +56,27 @@ def _worker(rank, world, port, bucket_bytes, out):
         if s.name in full:
             got = (flat[s.offset:s.offset + s.numel] * scale).numpy()
             np.testing.assert_allclose(got, full[s.name].reshape(-1), rtol=1e-4, atol=1e-7)
+    # ---- the overlapped form's protocol (what LinearModel's backward drives on the GPU) ----------------------
+    sync = pkg.dp.GradSync()
+    assert sync.overlap_enabled() and not sync.has_pending()
+    local = torch.arange(8, dtype=torch.float32) + 100 * rank
+    buf = local.clone()
+    sync.launch_bucket(buf[4:])                               # the arena's tail first, as backward finishes it
+    sync.launch_bucket(buf[:4])
+    assert sync.has_pending()
+    assert sync(model) == 1.0 / world and not sync.has_pending()     # buckets in flight: wait, do not reduce again
+    want = sum(torch.arange(8, dtype=torch.float32) + 100 * r for r in range(world))
+    assert torch.equal(buf, want)
+    with sync.no_sync():                                      # accumulation micro-batch: backward launches nothing
+        assert not sync.overlap_enabled()
+        with sync.no_sync():
+            assert not sync.overlap_enabled()
+        assert not sync.overlap_enabled()
+    assert sync.overlap_enabled()
+    assert not pkg.dp.GradSync(overlap=False).overlap_enabled()
+    sync.launch_bucket(buf)                                   # buckets whose result must not be used ...
+    sync.abandon()                                            # ... are waited for and forgotten (collective stays matched)
+    assert not sync.has_pending()
     # every rank holds the same parameters after the broadcast
     gathered = [torch.zeros_like(model.flat_params) for _ in range(world)]
     dist.all_gather(gathered, model.flat_params)

@@ -160,6 +160,16 @@ static void run(const char* name, int M, int N, int K, int splits, bool check, f
 
 int main(int argc, char** argv) {
   const bool check = argc < 2 || atoi(argv[1]) != 0;
+  if (argc > 2 && atoi(argv[2]) == 1) {
+    // MFMA shape question only (timing builds): 32x32x16 vs the same FLOPs as 16x16x32, with and without the DMA
+    for (int rep = 0; rep < 2; ++rep) {
+      run<false, false, kF16x3, 4, 0, 3>("NT", 4096, 1024, 1024, 1, false);
+      run<false, false, kF16x3, 4, 4, 3>("NT", 4096, 1024, 1024, 1, false);
+      run<false, false, kF16x3, 4, 2, 3>("NT", 4096, 1024, 1024, 1, false);
+      run<false, false, kF16x3, 4, 5, 3>("NT", 4096, 1024, 1024, 1, false);
+    }
+    return 0;
+  }
   // small shapes first (a wrong kernel should fail here, quickly)
   run<false, false, kF16x3>("NT", 256, 256, 128, 1, check);
   run<false, true, kF16x3>("NN", 256, 256, 128, 1, check);
