@@ -8,7 +8,7 @@
 #include <stdlib.h>
 
 #include "gemm_epilogue.h"
-#include "gemm_planes.h"
+#include "gemm_planes16.h"
 #include "pl_internal.h"
 
 namespace pl {
@@ -22,113 +22,202 @@ struct PlanesKern {
   int vec_addend;          // POSELIFT_ADDEND_SCALAR=1 (same-box A/B): the addend through gemm_epilogue's dword loads
 };
 
-template <bool A_KS, bool B_KS, int MODE>
-__device__ __forceinline__ void planes_body(const PlanesKern& k, const int block_id, const int nwork, char* lds) {
-  f32x16 acc[plp::ModeCfg<MODE>::NACC][2][2];
-  int m0, n0, slice;
-  if (!plp::planes_mainloop<A_KS, B_KS, 32, MODE, 4, 0, 3>(k.p, block_id, nwork, lds, acc, m0, n0, slice)) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;       // waves 0-3 only
-  const int i = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
-  if constexpr (MODE == plp::kF16x3) {
-    // main + low / 2048, then back from the operands' power-of-two scales (exact unless the result under/overflows)
-    const float os = k.dyn_inv ? k.out_scale * k.dyn_inv[0] : k.out_scale;
+// ---- the epilogue on the wave's 64x64 block staged in its own 17 KB of LDS (row stride 68 floats: conflict-free both
+// ways), everything as 16-byte accesses on 256-byte row segments.  Lane (lr = lane >> 4, lc = 4 (lane & 15)) owns columns
+// col0 .. col0+3 of rows lr, lr+4, ..., lr+60.  Same operation order per element as gemm_epilogue (bias, skip-gradient
+// addend, eval-BN fold, ReLU, residual, ReLU); statistics and the BatchNorm-backward sums per 64-row block in a fixed order.
+__device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __restrict__ C, const float* __restrict__ ldsw,
+                                                const int m0, const int n0, const int wm, const int wn, const int lane) {
+  const GemmArgs& e = k.e;
+  const int lr = lane >> 4, lc = (lane & 15) * 4;
+  const int row0 = m0 + wm * 64 + lr, col0 = n0 + wn * 64 + lc;
+  const size_t o0 = (size_t)row0 * e.ldc + col0;
+  const bool plain = e.split_k > 1;              // split-K slab: the bare partial product
+  float4 v[16];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+  for (int it = 0; it < 16; ++it) v[it] = *reinterpret_cast<const float4*>(ldsw + (it * 4 + lr) * 68 + lc);
+  if (!plain) {
+    if (e.bias) {
+      const float4 b = *reinterpret_cast<const float4*>(e.bias + col0);
 #pragma unroll
-      for (int b = 0; b < 2; ++b)
+      for (int it = 0; it < 16; ++it) { v[it].x += b.x; v[it].y += b.y; v[it].z += b.z; v[it].w += b.w; }
+    }
+    if (e.addend) {
+      float4 q[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          acc[0][a][b][r] = fmaf(acc[1][a][b][r], 1.0f / plp::kF16LoScale, acc[0][a][b][r]) * os;
+      for (int it = 0; it < 16; ++it) q[it] = *reinterpret_cast<const float4*>(e.addend + o0 + (size_t)it * 4 * e.ldc);
+#pragma unroll
+      for (int it = 0; it < 16; ++it) { v[it].x += q[it].x; v[it].y += q[it].y; v[it].z += q[it].z; v[it].w += q[it].w; }
+    }
+    if (e.col_scale) {
+      const float4 sc = *reinterpret_cast<const float4*>(e.col_scale + col0);
+      const float4 sh = *reinterpret_cast<const float4*>(e.col_shift + col0);
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        v[it].x = fmaf(v[it].x, sc.x, sh.x); v[it].y = fmaf(v[it].y, sc.y, sh.y);
+        v[it].z = fmaf(v[it].z, sc.z, sh.z); v[it].w = fmaf(v[it].w, sc.w, sh.w);
+      }
+    }
+    if (e.relu == 1) {
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        v[it].x = fmaxf(v[it].x, 0.f); v[it].y = fmaxf(v[it].y, 0.f); v[it].z = fmaxf(v[it].z, 0.f); v[it].w = fmaxf(v[it].w, 0.f);
+      }
+    }
+    if (e.resid) {
+      float4 q[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) q[it] = *reinterpret_cast<const float4*>(e.resid + o0 + (size_t)it * 4 * e.ldc);
+#pragma unroll
+      for (int it = 0; it < 16; ++it) { v[it].x += q[it].x; v[it].y += q[it].y; v[it].z += q[it].z; v[it].w += q[it].w; }
+    }
+    if (e.relu == 2) {
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        v[it].x = fmaxf(v[it].x, 0.f); v[it].y = fmaxf(v[it].y, 0.f); v[it].z = fmaxf(v[it].z, 0.f); v[it].w = fmaxf(v[it].w, 0.f);
+      }
+    }
   }
-  float* C = k.e.C + (k.e.split_k > 1 ? (size_t)slice * k.e.M * k.e.ldc : 0);
-  // dX of a residual block's first Linear adds the skip gradient (addend): read through gemm_epilogue's accumulator
-  // layout that is 64 dword loads per lane on 128-byte row segments and cost +14 us per launch (rocprofv3: 68.8 / 72.6 us
-  // for the two launches with an addend against 59.8 / 54.7 without).  Here: the wave's 64x64 block goes through its own
-  // 16 KB of LDS (free after the main loop) and the addend / result move as 16-byte accesses on 256-byte row segments.
-  const bool plain_out = k.e.split_k <= 1 && !k.e.bias && !k.e.stat_sum && !k.e.col_scale && !k.e.resid && !k.e.relu &&
-                         (k.e.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(C) & 15) == 0;
-  if (plain_out && ((k.vec_addend && k.e.addend) || k.e.bnr_z) &&
-      (!k.e.addend || (reinterpret_cast<uintptr_t>(k.e.addend) & 15) == 0)) {
-    __syncthreads();                                   // every computing wave is done reading operand tiles
-    float* ldsw = reinterpret_cast<float*>(lds) + wave * 64 * 68;     // row stride 68 floats: conflict-free both ways
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+  for (int it = 0; it < 16; ++it) *reinterpret_cast<float4*>(C + o0 + (size_t)it * 4 * e.ldc) = v[it];
+  if (plain) return;
+  if (e.stat_sum) {
+    // training-mode BatchNorm partial statistics of this 64-row block (sum and M2 about the block's own mean); lanes l,
+    // l^16, l^32, l^48 hold the same four columns: fixed-order butterfly
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) { s.x += v[it].x; s.y += v[it].y; s.z += v[it].z; s.w += v[it].w; }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      s.x += __shfl_xor(s.x, o); s.y += __shfl_xor(s.y, o); s.z += __shfl_xor(s.z, o); s.w += __shfl_xor(s.w, o);
+    }
+    const float4 mean = make_float4(s.x * (1.f / 64.f), s.y * (1.f / 64.f), s.z * (1.f / 64.f), s.w * (1.f / 64.f));
+    float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const float dx = v[it].x - mean.x, dy = v[it].y - mean.y, dz = v[it].z - mean.z, dw = v[it].w - mean.w;
+      m2.x = fmaf(dx, dx, m2.x); m2.y = fmaf(dy, dy, m2.y); m2.z = fmaf(dz, dz, m2.z); m2.w = fmaf(dw, dw, m2.w);
+    }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      m2.x += __shfl_xor(m2.x, o); m2.y += __shfl_xor(m2.y, o); m2.z += __shfl_xor(m2.z, o); m2.w += __shfl_xor(m2.w, o);
+    }
+    if (lr == 0) {
+      const size_t o = (size_t)((m0 >> 6) + wm) * e.N + col0;
+      *reinterpret_cast<float4*>(e.stat_sum + o) = s;
+      *reinterpret_cast<float4*>(e.stat_m2 + o) = m2;
+    }
+  }
+  if (e.bnr_z) {
+    // BatchNorm-backward pass 1 of the layer below on the block just produced (GemmArgs::bnr_*): the separate pass read
+    // g (16.8 MB) back from HBM, here it is in registers.  One partial row per 64-row block, in a fixed order.
+    const int N = e.N;
+    const int wpr = ((N + 255) >> 8) * 4;
+    const int strip = col0 >> 8, bit = (col0 & 255) >> 2;
+    const float4 mu = *reinterpret_cast<const float4*>(e.bnr_mean + col0);
+    const float4 rs = *reinterpret_cast<const float4*>(e.bnr_rstd + col0);
+    const float ks = e.bnr_kscale;
+    float4 zz[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) zz[it] = *reinterpret_cast<const float4*>(e.bnr_z + o0 + (size_t)it * 4 * e.ldc);
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    float mxd = 0.f, mxz = 0.f;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const uint64_t* bw = e.bnr_bits + (size_t)(row0 + 4 * it) * wpr + strip * 4;
+      const ulonglong2 w01 = *reinterpret_cast<const ulonglong2*>(bw), w23 = *reinterpret_cast<const ulonglong2*>(bw + 2);
+      const float d0 = ((w01.x >> bit) & 1ull) ? v[it].x * ks : 0.f;
+      const float d1 = ((w01.y >> bit) & 1ull) ? v[it].y * ks : 0.f;
+      const float d2 = ((w23.x >> bit) & 1ull) ? v[it].z * ks : 0.f;
+      const float d3 = ((w23.y >> bit) & 1ull) ? v[it].w * ks : 0.f;
+      const float z0 = (zz[it].x - mu.x) * rs.x, z1 = (zz[it].y - mu.y) * rs.y;
+      const float z2 = (zz[it].z - mu.z) * rs.z, z3 = (zz[it].w - mu.w) * rs.w;
+      s1.x += d0; s1.y += d1; s1.z += d2; s1.w += d3;
+      s2.x = fmaf(d0, z0, s2.x); s2.y = fmaf(d1, z1, s2.y); s2.z = fmaf(d2, z2, s2.z); s2.w = fmaf(d3, z3, s2.w);
+      mxd = fmaxf(fmaxf(mxd, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
+      mxz = fmaxf(fmaxf(mxz, fmaxf(fabsf(z0), fabsf(z1))), fmaxf(fabsf(z2), fabsf(z3)));
+    }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      s1.x += __shfl_xor(s1.x, o); s1.y += __shfl_xor(s1.y, o); s1.z += __shfl_xor(s1.z, o); s1.w += __shfl_xor(s1.w, o);
+      s2.x += __shfl_xor(s2.x, o); s2.y += __shfl_xor(s2.y, o); s2.z += __shfl_xor(s2.z, o); s2.w += __shfl_xor(s2.w, o);
+    }
+    const int rg = (m0 >> 6) + wm;                   // 64-row block of the whole matrix
+    if (lr == 0) {
+      *reinterpret_cast<float4*>(e.bnr_part_dy + (size_t)rg * N + col0) = s1;
+      *reinterpret_cast<float4*>(e.bnr_part_dyz + (size_t)rg * N + col0) = s2;
+    }
+    if (e.bnr_amax) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { mxd = fmaxf(mxd, __shfl_xor(mxd, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o)); }
+      if (lane == 0) {
+        float* q = e.bnr_amax + ((size_t)rg * (N >> 6) + (n0 >> 6) + wn) * 2;
+        q[0] = mxd; q[1] = mxz;
+      }
+    }
+  }
+}
+
+// S16 = true (default): the 16x16x32 main loop (gemm_planes16.h) -- the chip holds a higher matrix clock on that shape
+// under this loop's load -- and the staged epilogue for everything.  S16 = false (POSELIFT_MFMA32=1, same-box A/B): the
+// 32x32x16 loop; its accumulator layout is gemm_epilogue's, so only the addend / BatchNorm-backward cases are staged.
+template <bool A_KS, bool B_KS, int MODE, bool S16>
+__device__ __forceinline__ void planes_body(const PlanesKern& k, const int block_id, const int nwork, char* lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave & 3) >> 1, wn = wave & 1;
+  // main + low / 2048, then back from the operands' power-of-two scales (exact unless the result under/overflows)
+  const float os = MODE == plp::kF16x3 ? (k.dyn_inv ? k.out_scale * k.dyn_inv[0] : k.out_scale) : 1.f;
+  float* ldsw = reinterpret_cast<float*>(lds) + (wave & 3) * 64 * 68;
+  int m0, n0, slice;
+  if constexpr (S16) {
+    plp::f32x4v acc[plp::ModeCfg<MODE>::NACC][4][4];
+    if (!plp::planes_mainloop16<A_KS, B_KS, MODE>(k.p, block_id, nwork, lds, acc, m0, n0, slice)) return;
+    __syncthreads();                                   // every computing wave is done reading operand tiles
+    const int q = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = acc[0][rt][ct][r];
+          if constexpr (MODE == plp::kF16x3) v = fmaf(acc[1][rt][ct][r], 1.0f / plp::kF16LoScale, v) * os;
+          ldsw[(rt * 16 + 4 * q + r) * 68 + ct * 16 + c] = v;
+        }
+    float* C = k.e.C + (k.e.split_k > 1 ? (size_t)slice * k.e.M * k.e.ldc : 0);
+    staged_epilogue(k, C, ldsw, m0, n0, wm, wn, lane);
+  } else {
+    f32x16 acc[plp::ModeCfg<MODE>::NACC][2][2];
+    if (!plp::planes_mainloop<A_KS, B_KS, 32, MODE, 4, 0, 3>(k.p, block_id, nwork, lds, acc, m0, n0, slice)) return;
+    const int i = lane & 31, h = lane >> 5;
+    if constexpr (MODE == plp::kF16x3) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          ldsw[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + b * 32 + i] = acc[0][a][b][r];
-    const int lr = lane >> 4, lc = (lane & 15) * 4;
-    const int row0 = m0 + wm * 64 + lr, col0 = n0 + wn * 64 + lc;
-    const size_t o0 = (size_t)row0 * k.e.ldc + col0;
-    float4 v[16];
-    if (k.e.addend) {
-      float4 q[16];
+        for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int it = 0; it < 16; ++it) q[it] = *reinterpret_cast<const float4*>(k.e.addend + o0 + (size_t)it * 4 * k.e.ldc);
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const float4 t = *reinterpret_cast<const float4*>(ldsw + (it * 4 + lr) * 68 + lc);
-        v[it] = make_float4(t.x + q[it].x, t.y + q[it].y, t.z + q[it].z, t.w + q[it].w);   // (gemm_epilogue's order)
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < 16; ++it) v[it] = *reinterpret_cast<const float4*>(ldsw + (it * 4 + lr) * 68 + lc);
+          for (int r = 0; r < 16; ++r)
+            acc[0][a][b][r] = fmaf(acc[1][a][b][r], 1.0f / plp::kF16LoScale, acc[0][a][b][r]) * os;
     }
+    float* C = k.e.C + (k.e.split_k > 1 ? (size_t)slice * k.e.M * k.e.ldc : 0);
+    // dX of a residual block's first Linear adds the skip gradient (addend): through gemm_epilogue's accumulator layout
+    // that is 64 dword loads per lane on 128-byte row segments and cost +14 us per launch (rocprofv3: 68.8 / 72.6 us for the
+    // two launches with an addend against 59.8 / 54.7 without); staged, the addend moves as 16-byte accesses.
+    const bool plain_out = k.e.split_k <= 1 && !k.e.bias && !k.e.stat_sum && !k.e.col_scale && !k.e.resid && !k.e.relu;
+    if (plain_out && ((k.vec_addend && k.e.addend) || k.e.bnr_z)) {
+      __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 16; ++it) *reinterpret_cast<float4*>(C + o0 + (size_t)it * 4 * k.e.ldc) = v[it];
-    if (k.e.bnr_z) {
-      // BatchNorm-backward pass 1 of the layer below on the block just produced (GemmArgs::bnr_*): the separate pass read
-      // g (16.8 MB) back from HBM, here it is in registers.  One partial row per 64-row block, in a fixed order.
-      const int N = k.e.N;
-      const int wpr = ((N + 255) >> 8) * 4;
-      const int strip = col0 >> 8, bit = (col0 & 255) >> 2;
-      const float4 mu = *reinterpret_cast<const float4*>(k.e.bnr_mean + col0);
-      const float4 rs = *reinterpret_cast<const float4*>(k.e.bnr_rstd + col0);
-      const float ks = k.e.bnr_kscale;
-      float4 zz[16];
+      for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int it = 0; it < 16; ++it) zz[it] = *reinterpret_cast<const float4*>(k.e.bnr_z + o0 + (size_t)it * 4 * k.e.ldc);
-      float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-      float mxd = 0.f, mxz = 0.f;
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const uint64_t* bw = k.e.bnr_bits + (size_t)(row0 + 4 * it) * wpr + strip * 4;
-        const ulonglong2 w01 = *reinterpret_cast<const ulonglong2*>(bw), w23 = *reinterpret_cast<const ulonglong2*>(bw + 2);
-        const float d0 = ((w01.x >> bit) & 1ull) ? v[it].x * ks : 0.f;
-        const float d1 = ((w01.y >> bit) & 1ull) ? v[it].y * ks : 0.f;
-        const float d2 = ((w23.x >> bit) & 1ull) ? v[it].z * ks : 0.f;
-        const float d3 = ((w23.y >> bit) & 1ull) ? v[it].w * ks : 0.f;
-        const float z0 = (zz[it].x - mu.x) * rs.x, z1 = (zz[it].y - mu.y) * rs.y;
-        const float z2 = (zz[it].z - mu.z) * rs.z, z3 = (zz[it].w - mu.w) * rs.w;
-        s1.x += d0; s1.y += d1; s1.z += d2; s1.w += d3;
-        s2.x = fmaf(d0, z0, s2.x); s2.y = fmaf(d1, z1, s2.y); s2.z = fmaf(d2, z2, s2.z); s2.w = fmaf(d3, z3, s2.w);
-        mxd = fmaxf(fmaxf(mxd, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
-        mxz = fmaxf(fmaxf(mxz, fmaxf(fabsf(z0), fabsf(z1))), fmaxf(fabsf(z2), fabsf(z3)));
-      }
-      // lanes l, l^16, l^32, l^48 hold the same four columns (rows lr = 0..3 mod 4): fixed-order butterfly
-#pragma unroll
-      for (int o = 16; o <= 32; o <<= 1) {
-        s1.x += __shfl_xor(s1.x, o); s1.y += __shfl_xor(s1.y, o); s1.z += __shfl_xor(s1.z, o); s1.w += __shfl_xor(s1.w, o);
-        s2.x += __shfl_xor(s2.x, o); s2.y += __shfl_xor(s2.y, o); s2.z += __shfl_xor(s2.z, o); s2.w += __shfl_xor(s2.w, o);
-      }
-      const int rg = (m0 >> 6) + wm;                   // 64-row block of the whole matrix
-      if (lr == 0) {
-        *reinterpret_cast<float4*>(k.e.bnr_part_dy + (size_t)rg * N + col0) = s1;
-        *reinterpret_cast<float4*>(k.e.bnr_part_dyz + (size_t)rg * N + col0) = s2;
-      }
-      if (k.e.bnr_amax) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { mxd = fmaxf(mxd, __shfl_xor(mxd, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o)); }
-        if (lane == 0) {
-          float* q = k.e.bnr_amax + ((size_t)rg * (N >> 6) + (n0 >> 6) + wn) * 2;
-          q[0] = mxd; q[1] = mxz;
-        }
-      }
+          for (int r = 0; r < 16; ++r)
+            ldsw[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + b * 32 + i] = acc[0][a][b][r];
+      staged_epilogue(k, C, ldsw, m0, n0, wm, wn, lane);
+      return;
     }
-    return;
+    gemm_epilogue<false, 2>(k.e, C, acc[0], m0, n0, wm, wn, i, h);
   }
-  gemm_epilogue<false, 2>(k.e, C, acc[0], m0, n0, wm, wn, i, h);
 }
 
 // LDS: three operand stages, and never less than the 4 x 17 KB the addend epilogue stages the output block in
@@ -138,22 +227,27 @@ constexpr int lds_bytes() {
   return stages > 4 * 64 * 68 * 4 ? stages : 4 * 64 * 68 * 4;
 }
 
-template <bool A_KS, bool B_KS, int MODE>
+template <bool A_KS, bool B_KS, int MODE, bool S16>
 __global__ __launch_bounds__(512) void planes_gemm_kernel(PlanesKern k) {
   __shared__ __attribute__((aligned(16))) char lds[lds_bytes<MODE>()];
-  planes_body<A_KS, B_KS, MODE>(k, blockIdx.x, gridDim.x, lds);
+  planes_body<A_KS, B_KS, MODE, S16>(k, blockIdx.x, gridDim.x, lds);
 }
 
 // backward pair of one layer in one launch: workgroups [0, n0) run dX = dz W (NN), the rest dW = dz^T a (TN, split-K
 // slabs).  One workgroup per CU at a time (96 KB of LDS each): what the single launch saves is the launch boundary
 // and the tail of the first problem, which the second one's workgroups fill.
-template <int MODE>
+template <int MODE, bool S16>
 __global__ __launch_bounds__(512) void planes_gemm_dual_kernel(PlanesKern k0, PlanesKern k1, int n0) {
   __shared__ __attribute__((aligned(16))) char lds[lds_bytes<MODE>()];
   if ((int)blockIdx.x < n0)
-    planes_body<false, true, MODE>(k0, blockIdx.x, n0, lds);
+    planes_body<false, true, MODE, S16>(k0, blockIdx.x, n0, lds);
   else
-    planes_body<true, true, MODE>(k1, blockIdx.x - n0, gridDim.x - n0, lds);
+    planes_body<true, true, MODE, S16>(k1, blockIdx.x - n0, gridDim.x - n0, lds);
+}
+
+bool mfma16_shape() {
+  static const bool s16 = [] { const char* e = getenv("POSELIFT_MFMA32"); return !(e && e[0] == '1'); }();
+  return s16;
 }
 
 int npl_of(int mode) { return mode == plp::kF16x3 ? 2 : (mode == plp::kBf16x6 ? 3 : 1); }
@@ -199,6 +293,16 @@ bool planes_gemm_ok(GemmLayout layout, const PlanesGemmArgs& a) {
   const int64_t b_ext = (int64_t)(npl - 1) * a.b_plane * 2 + (b_ks ? (int64_t)e.K * a.ldb * 2 : (int64_t)128 * a.ldb * 2 + (int64_t)e.K * 2);
   if (a_ext >= (1ll << 31) || b_ext >= (1ll << 31)) return false;
   if ((e.stat_sum != nullptr) != (e.stat_m2 != nullptr)) return false;
+  if ((e.col_scale != nullptr) != (e.col_shift != nullptr)) return false;
+  // the staged epilogue moves everything as 16-byte accesses
+  if (e.ldc & 3) return false;
+  const uintptr_t al = reinterpret_cast<uintptr_t>(e.C) | reinterpret_cast<uintptr_t>(e.bias) | reinterpret_cast<uintptr_t>(e.addend) |
+                       reinterpret_cast<uintptr_t>(e.resid) | reinterpret_cast<uintptr_t>(e.col_scale) |
+                       reinterpret_cast<uintptr_t>(e.col_shift) | reinterpret_cast<uintptr_t>(e.stat_sum) |
+                       reinterpret_cast<uintptr_t>(e.stat_m2) | reinterpret_cast<uintptr_t>(e.bnr_z) |
+                       reinterpret_cast<uintptr_t>(e.bnr_mean) | reinterpret_cast<uintptr_t>(e.bnr_rstd) |
+                       reinterpret_cast<uintptr_t>(e.bnr_part_dy) | reinterpret_cast<uintptr_t>(e.bnr_part_dyz);
+  if (al & 15) return false;
   return true;
 }
 
@@ -207,14 +311,18 @@ int launch_gemm_planes(GemmLayout layout, const PlanesGemmArgs& a, hipStream_t s
   const PlanesKern k = kern_of(layout, a);
   const dim3 grid(grid_of(a)), block(512);
   void* prof = prof_begin_flops(2.0 * a.e.M * a.e.N * a.e.K, s);
-#define PL_PLANES_LAUNCH(MODE)                                                                                   \
+#define PL_PLANES_LAUNCH(MODE, S16)                                                                              \
   switch (layout) {                                                                                              \
-    case kNT: hipLaunchKernelGGL((planes_gemm_kernel<false, false, MODE>), grid, block, 0, s, k); break;         \
-    case kNN: hipLaunchKernelGGL((planes_gemm_kernel<false, true, MODE>), grid, block, 0, s, k); break;          \
-    case kTN: hipLaunchKernelGGL((planes_gemm_kernel<true, true, MODE>), grid, block, 0, s, k); break;           \
+    case kNT: hipLaunchKernelGGL((planes_gemm_kernel<false, false, MODE, S16>), grid, block, 0, s, k); break;    \
+    case kNN: hipLaunchKernelGGL((planes_gemm_kernel<false, true, MODE, S16>), grid, block, 0, s, k); break;     \
+    case kTN: hipLaunchKernelGGL((planes_gemm_kernel<true, true, MODE, S16>), grid, block, 0, s, k); break;      \
     default: PL_FAIL(PL_EINVAL, "gemm_planes: bad layout %d", (int)layout);                                     \
   }
-  if (a.mode == plp::kF16x3) { PL_PLANES_LAUNCH(plp::kF16x3) } else { PL_PLANES_LAUNCH(plp::kBf16) }
+  if (mfma16_shape()) {
+    if (a.mode == plp::kF16x3) { PL_PLANES_LAUNCH(plp::kF16x3, true) } else { PL_PLANES_LAUNCH(plp::kBf16, true) }
+  } else {
+    if (a.mode == plp::kF16x3) { PL_PLANES_LAUNCH(plp::kF16x3, false) } else { PL_PLANES_LAUNCH(plp::kBf16, false) }
+  }
 #undef PL_PLANES_LAUNCH
   prof_end(prof, s);
   PL_CHECK_LAUNCH("gemm_planes");
@@ -227,10 +335,14 @@ int launch_gemm_planes_pair(const PlanesGemmArgs& nn, const PlanesGemmArgs& tn, 
   const PlanesKern k0 = kern_of(kNN, nn), k1 = kern_of(kTN, tn);
   const int g0 = grid_of(nn), g1 = grid_of(tn);
   void* prof = prof_begin_flops(2.0 * nn.e.M * nn.e.N * nn.e.K + 2.0 * tn.e.M * tn.e.N * tn.e.K, s);
-  if (nn.mode == plp::kF16x3)
-    hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kF16x3>), dim3(g0 + g1), dim3(512), 0, s, k0, k1, g0);
-  else
-    hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kBf16>), dim3(g0 + g1), dim3(512), 0, s, k0, k1, g0);
+  const dim3 grid(g0 + g1), block(512);
+  if (mfma16_shape()) {
+    if (nn.mode == plp::kF16x3) hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kF16x3, true>), grid, block, 0, s, k0, k1, g0);
+    else hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kBf16, true>), grid, block, 0, s, k0, k1, g0);
+  } else {
+    if (nn.mode == plp::kF16x3) hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kF16x3, false>), grid, block, 0, s, k0, k1, g0);
+    else hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kBf16, false>), grid, block, 0, s, k0, k1, g0);
+  }
   prof_end(prof, s);
   PL_CHECK_LAUNCH("gemm_planes_dual");
   return PL_OK;

@@ -13,7 +13,7 @@
 
 #include <vector>
 
-#include "../../3d_poseestimation_amd/csrc/gemm_planes.h"
+#include "../../3d_poseestimation_amd/csrc/gemm_planes16.h"
 
 #define CK(x)                                                                          \
   do {                                                                                 \
@@ -44,6 +44,31 @@ __global__ __launch_bounds__(256 + 64 * NLW) void planes_gemm_kernel(PlanesArgs 
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         const int col = n0 + wn * 64 + b * 32 + i;
+        float v = acc[0][a][b][r];
+        if constexpr (MODE == kF16x3) v = fmaf(acc[1][a][b][r], 1.0f / kF16LoScale, v) * out_scale;
+        C[(size_t)row * p.ldc + col] = v;
+      }
+}
+
+// the 16x16x32 main loop (gemm_planes16.h), plain register stores
+template <bool A_KS, bool B_KS, int MODE>
+__global__ __launch_bounds__(512) void planes_gemm16_kernel(PlanesArgs p, float out_scale) {
+  constexpr int NPL = ModeCfg<MODE>::NPL;
+  __shared__ __attribute__((aligned(16))) char lds[PlanesCfg<32, NPL, 3>::LDS];
+  f32x4v acc[ModeCfg<MODE>::NACC][4][4];
+  int m0, n0, slice;
+  if (!planes_mainloop16<A_KS, B_KS, MODE>(p, blockIdx.x, gridDim.x, lds, acc, m0, n0, slice)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  float* C = p.C + (size_t)slice * p.M * p.ldc;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 64 + a * 16 + 4 * (lane >> 4) + r;
+        const int col = n0 + wn * 64 + b * 16 + (lane & 15);
         float v = acc[0][a][b][r];
         if constexpr (MODE == kF16x3) v = fmaf(acc[1][a][b][r], 1.0f / kF16LoScale, v) * out_scale;
         C[(size_t)row * p.ldc + col] = v;
@@ -89,7 +114,7 @@ __global__ void ref_kernel(const float* A, const float* B, int mode, bool a_ks, 
   C[(size_t)m * N + n] = s;
 }
 
-template <bool A_KS, bool B_KS, int MODE, int NLW = 4, int ABL = 0, int NST = 3>
+template <bool A_KS, bool B_KS, int MODE, int NLW = 4, int ABL = 0, int NST = 3, bool S16 = false>
 static void run(const char* name, int M, int N, int K, int splits, bool check, float amag = 1.f, float bmag = 0.03f) {
   if (ABL) check = false;
   constexpr int NPL = ModeCfg<MODE>::NPL;
@@ -117,7 +142,11 @@ static void run(const char* name, int M, int N, int K, int splits, bool check, f
   const float out_scale = 1.f / (sa * sb);
   const int grid = (M / 128) * (N / 128) * splits;
   CK(hipMemset(dc, 0xff, nc * 4 * splits));
-  planes_gemm_kernel<A_KS, B_KS, MODE, NLW, ABL, NST><<<grid, nthr>>>(p, out_scale);
+  auto launch = [&]() {
+    if constexpr (S16) planes_gemm16_kernel<A_KS, B_KS, MODE><<<grid, 512>>>(p, out_scale);
+    else planes_gemm_kernel<A_KS, B_KS, MODE, NLW, ABL, NST><<<grid, nthr>>>(p, out_scale);
+  };
+  launch();
   CK(hipGetLastError());
   CK(hipDeviceSynchronize());
   const char* mname = MODE == kBf16 ? "bf16  " : MODE == kBf16x6 ? "bf16x6" : "f16x3 ";
@@ -138,22 +167,23 @@ static void run(const char* name, int M, int N, int K, int splits, bool check, f
       if (!(e <= maxerr)) { maxerr = e; worst = i; }
       if (!(e == e)) ++bad;
     }
-    printf("%-2s %s lw%d st%d %dx%dx%d s%d mag %g/%g: max|ref|=%.4g max err=%.3g (rel %.3g) rms rel %.3g nan=%zu %s\n", name, mname,
-           NLW, NST, M, N, K, splits, amag, bmag, maxref, maxerr, maxerr / maxref, sqrt(sq / sqr), bad,
+    printf("%-2s %s %s lw%d st%d %dx%dx%d s%d mag %g/%g: max|ref|=%.4g max err=%.3g (rel %.3g) rms rel %.3g nan=%zu %s\n", name, mname,
+           S16 ? "16x16x32" : "32x32x16", NLW, NST, M, N, K, splits, amag, bmag, maxref, maxerr, maxerr / maxref, sqrt(sq / sqr), bad,
            (bad == 0 && maxerr / maxref < 3e-6) ? "OK" : "FAIL");
   }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int it = 0; it < 5; ++it) planes_gemm_kernel<A_KS, B_KS, MODE, NLW, ABL, NST><<<grid, nthr>>>(p, out_scale);
+  for (int it = 0; it < 5; ++it) launch();
   const int iters = 50;
   CK(hipEventRecord(e0));
-  for (int it = 0; it < iters; ++it) planes_gemm_kernel<A_KS, B_KS, MODE, NLW, ABL, NST><<<grid, nthr>>>(p, out_scale);
+  for (int it = 0; it < iters; ++it) launch();
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
   CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / iters;
-  printf("%-2s %s lw%d st%d abl%d %dx%dx%d s%d grid=%d: %.2f us  %.1f TF algorithmic (%.1f TF issued)\n", name, mname, NLW, NST,
+  printf("%-2s %s %s lw%d st%d abl%d %dx%dx%d s%d grid=%d: %.2f us  %.1f TF algorithmic (%.1f TF issued)\n", name, mname,
+         S16 ? "16x16x32" : "32x32x16", NLW, NST,
          ABL, M, N, K, splits, grid, us, 2.0 * M * N * K / us * 1e-6, 2.0 * M * N * K / us * 1e-6 * ModeCfg<MODE>::NPROD);
   CK(hipFree(da)); CK(hipFree(db)); CK(hipFree(dc)); CK(hipFree(pa)); CK(hipFree(pb)); CK(hipFree(dref));
 }
@@ -167,6 +197,29 @@ int main(int argc, char** argv) {
       run<false, false, kF16x3, 4, 4, 3>("NT", 4096, 1024, 1024, 1, false);
       run<false, false, kF16x3, 4, 2, 3>("NT", 4096, 1024, 1024, 1, false);
       run<false, false, kF16x3, 4, 5, 3>("NT", 4096, 1024, 1024, 1, false);
+    }
+    return 0;
+  }
+  if (argc > 2 && atoi(argv[2]) == 2) {
+    // the 16x16x32 main loop: every layout against fp64 (small first), then the lifter's shapes beside the 32x32x16 loop
+    run<false, false, kF16x3, 4, 0, 3, true>("NT", 128, 128, 32, 1, check);
+    run<false, false, kF16x3, 4, 0, 3, true>("NT", 128, 128, 64, 1, check);
+    run<false, false, kF16x3, 4, 0, 3, true>("NT", 128, 128, 96, 1, check);
+    run<false, false, kF16x3, 4, 0, 3, true>("NT", 256, 256, 128, 1, check);
+    run<false, true, kF16x3, 4, 0, 3, true>("NN", 256, 256, 128, 1, check);
+    run<true, true, kF16x3, 4, 0, 3, true>("TN", 256, 256, 256, 2, check);
+    run<false, false, kBf16, 4, 0, 3, true>("NT", 256, 256, 128, 1, check);
+    run<false, true, kBf16, 4, 0, 3, true>("NN", 256, 256, 128, 1, check);
+    run<true, true, kBf16, 4, 0, 3, true>("TN", 256, 256, 256, 2, check);
+    for (int rep = 0; rep < 2; ++rep) {
+      run<false, false, kF16x3, 4, 0, 3>("NT", 4096, 1024, 1024, 1, false);
+      run<false, false, kF16x3, 4, 0, 3, true>("NT", 4096, 1024, 1024, 1, check && rep == 0);
+      run<false, true, kF16x3, 4, 0, 3>("NN", 4096, 1024, 1024, 1, false);
+      run<false, true, kF16x3, 4, 0, 3, true>("NN", 4096, 1024, 1024, 1, check && rep == 0);
+      run<true, true, kF16x3, 4, 0, 3>("TN", 1024, 1024, 4096, 4, false);
+      run<true, true, kF16x3, 4, 0, 3, true>("TN", 1024, 1024, 4096, 4, check && rep == 0);
+      run<false, false, kBf16, 4, 0, 3>("NT", 4096, 1024, 1024, 1, false);
+      run<false, false, kBf16, 4, 0, 3, true>("NT", 4096, 1024, 1024, 1, check && rep == 0);
     }
     return 0;
   }
