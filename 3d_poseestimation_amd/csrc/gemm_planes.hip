@@ -236,6 +236,8 @@ __global__ __launch_bounds__(512) void planes_gemm_kernel(PlanesKern k) {
 // backward pair of one layer in one launch: workgroups [0, n0) run dX = dz W (NN), the rest dW = dz^T a (TN, split-K
 // slabs).  One workgroup per CU at a time (96 KB of LDS each): what the single launch saves is the launch boundary
 // and the tail of the first problem, which the second one's workgroups fill.
+// (Tried: alternating the two problems in groups of 8 workgroups, so that half the CUs run dX's heavy epilogues beside the
+//  other half's main loops -- same-box A/B 0.688 vs 0.629 ms per step: two working sets per XCD L2 cost far more.)
 template <int MODE, bool S16>
 __global__ __launch_bounds__(512) void planes_gemm_dual_kernel(PlanesKern k0, PlanesKern k1, int n0) {
   __shared__ __attribute__((aligned(16))) char lds[lds_bytes<MODE>()];
