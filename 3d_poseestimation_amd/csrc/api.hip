@@ -136,6 +136,7 @@ struct Ws {
   std::vector<size_t> z, act, bits, mean, rstd, dbpart;
   size_t stat, scale, shift, coef, ga, gb, dz, slabs, outpart, dyout, mse, total;
   size_t act_bytes, bits_bytes;
+  size_t slab_floats;                 // size of the `slabs` region (also the thin GEMMs' split-K scratch)
   // PL_F16X3 planes path
   bool planes;
   int pkind;                          // PlaneOut::kind: 2 fp16 pair (PL_F16X3), 1 bf16 (PL_BF16)
@@ -197,7 +198,9 @@ Ws plan(const PLDesc* d, int64_t B) {
     // partials of the skinny-layer kernels (skinny.hip)
     slab = std::max(slab, (size_t)skinny_chunks((int)B) * std::max(d->in_dim, d->out_dim) * H * 4);
     slab = std::max(slab, skinny_narrow_out_part_floats((int)B, H) * 4);
+    if (B <= thin_gemm_max_m() && B % 128) slab = std::max(slab, thin_gemm_scratch_floats((int)B, H, H) * 4);
   }
+  w.slab_floats = slab / 4;
   w.slabs = take(slab);
   w.outpart = take((size_t)colsum_chunks((int)B) * d->out_dim * 4);
   w.dyout = take((size_t)B * d->out_dim * 4);                 // d loss / d y of the fused train step
@@ -427,6 +430,7 @@ extern "C" int pl_lifter_fwd_eval(const PLDesc* d, const float* x, float* y, int
     g.col_shift = f32(ws, w.shift) + (size_t)l * H;
     g.relu = 1;
     if (l >= 2 && (l % 2) == 0) g.resid = f32(ws, w.act[l - 2]);
+    g.thin_scratch = f32(ws, w.slabs); g.thin_scratch_floats = w.slab_floats;
     if (w.planes && l > 0) {
       PlanesGemmArgs pg = planes_args(w.pkind, u16(ws, w.actp[l - 1]), BH, H, wplane(d, w, ws, l), (int64_t)H * H, H, out, (int)B, H, H,
                                       1.0f / (kActPlaneScale * kWeightPlaneScale), nullptr);
@@ -487,6 +491,7 @@ static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, 
     g.A = a_in; g.B = ly.W; g.C = f32(ws, w.z[l]); g.bias = ly.b;
     g.M = (int)B; g.N = H; g.K = ly.K; g.lda = ly.K; g.ldb = ly.K; g.ldc = H; g.split_k = 1;
     g.arith = arith_of(d);
+    g.thin_scratch = f32(ws, w.slabs); g.thin_scratch_floats = w.slab_floats;
     const bool skinny = l == 0 && skinny_supported(ly.K, H);
     const int groups = skinny ? skinny_stat_groups((int)B) : w.G;
     float* stat = f32(ws, w.stat);
@@ -655,6 +660,7 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
       g.A = DZ; g.B = ly.W; g.M = Bi; g.N = H; g.K = H; g.lda = H; g.ldb = H; g.ldc = H; g.split_k = 1;
       if (l % 2 == 1) { g.C = GA; g.addend = GA; } else { g.C = GB; }
       g.arith = arith_of(d);
+      g.thin_scratch = slabs; g.thin_scratch_floats = w.slab_floats;   // (the pair runs as two launches off the tile grid)
       GemmArgs t = {};
       t.arith = g.arith;
       t.A = DZ; t.B = a_in; t.M = H; t.N = H; t.K = Bi; t.lda = H; t.ldb = H; t.ldc = H;

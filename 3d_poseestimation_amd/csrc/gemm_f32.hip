@@ -1189,6 +1189,11 @@ int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s) {
   const int splits = a.split_k > 1 ? a.split_k : 1;
   dim3 grid(tiles * splits), block(NTHR);
   const size_t lds_bytes = 0;   // LDS is static
+  // small batch: a handful of tiles for 256 CUs -- the contraction split over the chip instead (gemm_thin.hip)
+  // (only off the tile grid: whole-tile batches keep one arithmetic whatever their size -- SyncBN shards of 128 rows are
+  //  bitwise the single-process batch, tests/test_gpu_dp.py)
+  if (a.thin_scratch && !whole_tiles(a) && a.M <= thin_gemm_max_m() && thin_gemm_ok(layout, a))
+    return launch_gemm_thin(layout, a, a.thin_scratch, a.thin_scratch_floats, s);
   ProfRec* prof = prof_begin(a, s);
   const bool whole = whole_tiles(a);
 #ifdef PL_ABLATE   /* timing-only variants of the bf16x6 loop (wrong results by construction) */

@@ -72,6 +72,9 @@ struct GemmArgs {
   float* bnr_part_dy;       // [M/64][N]
   float* bnr_part_dyz;      // [M/64][N]
   float* bnr_amax;          // [(M/64) * (N/64)][2] or NULL
+  // host side only: scratch for the small-batch split-K path (gemm_thin.hip); NULL = never take it
+  float* thin_scratch;
+  size_t thin_scratch_floats;
 };
 
 // y = conv2d(x, w) as an implicit GEMM on the PL_BF16X6 planes pipeline; a.A = x, a.B = w [Cout][KH*KW*Cin],
@@ -117,6 +120,12 @@ int launch_gemm_planes_pair(const PlanesGemmArgs& nn, const PlanesGemmArgs& tn, 
 int launch_split_planes(const float* x, int64_t n, const PlaneOut& out, hipStream_t s);
 
 int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s);
+// M <= thin_gemm_max_m() rows (NT, NN): the contraction split over the chip, exact fp32 MFMA, slabs + one reduce/epilogue
+// launch (gemm_thin.hip); launch_gemm_f32 takes it for problems that are not whole tiles when a.thin_scratch is set
+int thin_gemm_max_m();
+bool thin_gemm_ok(GemmLayout layout, const GemmArgs& a);
+size_t thin_gemm_scratch_floats(int M, int N, int K);
+int launch_gemm_thin(GemmLayout layout, const GemmArgs& a, float* scratch, size_t scratch_floats, hipStream_t s);
 int launch_gemm_f32_pair(const GemmArgs& nn, const GemmArgs& tn, hipStream_t s);
 int gemm_stat_groups(int M);  // number of 64-row groups the stats epilogue emits
 int prof_enable(int on);
