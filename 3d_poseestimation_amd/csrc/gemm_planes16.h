@@ -13,6 +13,9 @@
 // Registers (256 per wave with eight waves per workgroup): 2 x 64 accumulators (f16x3) leave room for one A fragment
 // set and two B sets, so the prefetch is staggered: A[2,3] of tile kt is read under the MFMAs of A[0,1], and after the
 // mid-step barrier A[0,1] and B of tile kt+1 are read under the MFMAs of A[2,3].
+// (Tried: the loader waves, idle after their last DMA issue, touching every line the dX epilogue will load -- skip
+//  gradient, saved z, bitmap -- two K tiles ahead, as the youngest loads of their queue: 0.6175 / 0.6156 ms per step
+//  against 0.6104 / 0.6197 without, same box.  The epilogue is not waiting on HBM latency; not kept.)
 #pragma once
 #include "gemm_planes.h"
 
