@@ -10,7 +10,11 @@
 // operand whose 32 lanes run along its contiguous (column) dimension, so its loads and stores
 // are 128-byte segments; the narrow operand is small enough to live in L1/L2.
 // (Two earlier VALU designs -- narrow operand through scalar loads, then through broadcast LDS
-// reads -- ran 26-67 us per call: one wave per SIMD with 34-52-long dependent FMA chains.)
+// reads -- ran 26-67 us per call: one wave per SIMD with 34-52-long dependent FMA chains.
+// Round 2 tried wide_out with 128 x 128 workgroup tiles, both operands staged in LDS and the columns dealt
+// round-robin over four MFMA tiles so that a lane stores 16 bytes on 512-byte row segments: 15.9 / 15.6 us against
+// 13.9 / 11.1 us for this form -- these kernels are bound by the ~3 us of fp32 MFMA issue per wave plus un-overlapped
+// load and store latency at one wave per SIMD, not by the store pattern.  Not kept.)
 #include "pl_internal.h"
 
 namespace pl {
