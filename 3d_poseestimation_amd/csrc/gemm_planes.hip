@@ -26,6 +26,7 @@ struct PlanesKern {
 // ways), everything as 16-byte accesses on 256-byte row segments.  Lane (lr = lane >> 4, lc = 4 (lane & 15)) owns columns
 // col0 .. col0+3 of rows lr, lr+4, ..., lr+60.  Same operation order per element as gemm_epilogue (bias, skip-gradient
 // addend, eval-BN fold, ReLU, residual, ReLU); statistics and the BatchNorm-backward sums per 64-row block in a fixed order.
+template <bool EDGE>
 __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __restrict__ C, const float* __restrict__ ldsw,
                                                 const int m0, const int n0, const int wm, const int wn, const int lane) {
   const GemmArgs& e = k.e;
@@ -33,25 +34,30 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
   const int row0 = m0 + wm * 64 + lr, col0 = n0 + wn * 64 + lc;
   const size_t o0 = (size_t)row0 * e.ldc + col0;
   const bool plain = e.split_k > 1;              // split-K slab: the bare partial product
+  // EDGE: rows >= M / columns >= N of an overhanging tile hold garbage: never loaded for, never stored, never counted
+  const int nrows = EDGE ? e.M - (m0 + wm * 64) : 64;          // valid rows of this wave's block (may be <= 0)
+  const bool cok = !EDGE || col0 < e.N;
+  auto ok = [&](int it) { return !EDGE || (cok && lr + 4 * it < nrows); };
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 v[16];
 #pragma unroll
   for (int it = 0; it < 16; ++it) v[it] = *reinterpret_cast<const float4*>(ldsw + (it * 4 + lr) * 68 + lc);
   if (!plain) {
     if (e.bias) {
-      const float4 b = *reinterpret_cast<const float4*>(e.bias + col0);
+      const float4 b = cok ? *reinterpret_cast<const float4*>(e.bias + col0) : zero4;
 #pragma unroll
       for (int it = 0; it < 16; ++it) { v[it].x += b.x; v[it].y += b.y; v[it].z += b.z; v[it].w += b.w; }
     }
     if (e.addend) {
       float4 q[16];
 #pragma unroll
-      for (int it = 0; it < 16; ++it) q[it] = *reinterpret_cast<const float4*>(e.addend + o0 + (size_t)it * 4 * e.ldc);
+      for (int it = 0; it < 16; ++it) q[it] = ok(it) ? *reinterpret_cast<const float4*>(e.addend + o0 + (size_t)it * 4 * e.ldc) : zero4;
 #pragma unroll
       for (int it = 0; it < 16; ++it) { v[it].x += q[it].x; v[it].y += q[it].y; v[it].z += q[it].z; v[it].w += q[it].w; }
     }
     if (e.col_scale) {
-      const float4 sc = *reinterpret_cast<const float4*>(e.col_scale + col0);
-      const float4 sh = *reinterpret_cast<const float4*>(e.col_shift + col0);
+      const float4 sc = cok ? *reinterpret_cast<const float4*>(e.col_scale + col0) : zero4;
+      const float4 sh = cok ? *reinterpret_cast<const float4*>(e.col_shift + col0) : zero4;
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
         v[it].x = fmaf(v[it].x, sc.x, sh.x); v[it].y = fmaf(v[it].y, sc.y, sh.y);
@@ -67,7 +73,7 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
     if (e.resid) {
       float4 q[16];
 #pragma unroll
-      for (int it = 0; it < 16; ++it) q[it] = *reinterpret_cast<const float4*>(e.resid + o0 + (size_t)it * 4 * e.ldc);
+      for (int it = 0; it < 16; ++it) q[it] = ok(it) ? *reinterpret_cast<const float4*>(e.resid + o0 + (size_t)it * 4 * e.ldc) : zero4;
 #pragma unroll
       for (int it = 0; it < 16; ++it) { v[it].x += q[it].x; v[it].y += q[it].y; v[it].z += q[it].z; v[it].w += q[it].w; }
     }
@@ -79,11 +85,17 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
     }
   }
 #pragma unroll
-  for (int it = 0; it < 16; ++it) *reinterpret_cast<float4*>(C + o0 + (size_t)it * 4 * e.ldc) = v[it];
+  for (int it = 0; it < 16; ++it)
+    if (ok(it)) *reinterpret_cast<float4*>(C + o0 + (size_t)it * 4 * e.ldc) = v[it];
   if (plain) return;
   if (e.stat_sum) {
     // training-mode BatchNorm partial statistics of this 64-row block (sum and M2 about the block's own mean); lanes l,
     // l^16, l^32, l^48 hold the same four columns: fixed-order butterfly
+    if (EDGE) {
+#pragma unroll
+      for (int it = 0; it < 16; ++it)
+        if (!ok(it)) v[it] = zero4;
+    }
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int it = 0; it < 16; ++it) { s.x += v[it].x; s.y += v[it].y; s.z += v[it].z; s.w += v[it].w; }
@@ -91,10 +103,13 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
     for (int o = 16; o <= 32; o <<= 1) {
       s.x += __shfl_xor(s.x, o); s.y += __shfl_xor(s.y, o); s.z += __shfl_xor(s.z, o); s.w += __shfl_xor(s.w, o);
     }
-    const float4 mean = make_float4(s.x * (1.f / 64.f), s.y * (1.f / 64.f), s.z * (1.f / 64.f), s.w * (1.f / 64.f));
+    const int cnt = EDGE ? max(0, min(64, nrows)) : 64;
+    const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+    const float4 mean = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
     float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
+      if (EDGE && !ok(it)) continue;
       const float dx = v[it].x - mean.x, dy = v[it].y - mean.y, dz = v[it].z - mean.z, dw = v[it].w - mean.w;
       m2.x = fmaf(dx, dx, m2.x); m2.y = fmaf(dy, dy, m2.y); m2.z = fmaf(dz, dz, m2.z); m2.w = fmaf(dw, dw, m2.w);
     }
@@ -102,7 +117,7 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
     for (int o = 16; o <= 32; o <<= 1) {
       m2.x += __shfl_xor(m2.x, o); m2.y += __shfl_xor(m2.y, o); m2.z += __shfl_xor(m2.z, o); m2.w += __shfl_xor(m2.w, o);
     }
-    if (lr == 0) {
+    if (lr == 0 && cok) {
       const size_t o = (size_t)((m0 >> 6) + wm) * e.N + col0;
       *reinterpret_cast<float4*>(e.stat_sum + o) = s;
       *reinterpret_cast<float4*>(e.stat_m2 + o) = m2;
@@ -161,7 +176,8 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
 // S16 = true (default): the 16x16x32 main loop (gemm_planes16.h) -- the chip holds a higher matrix clock on that shape
 // under this loop's load -- and the staged epilogue for everything.  S16 = false (POSELIFT_MFMA32=1, same-box A/B): the
 // 32x32x16 loop; its accumulator layout is gemm_epilogue's, so only the addend / BatchNorm-backward cases are staged.
-template <bool A_KS, bool B_KS, int MODE, bool S16>
+// EDGE (16x16x32 loop only): M / N need not be multiples of 128 -- the conv path's 64-wide layers and ragged pixel counts
+template <bool A_KS, bool B_KS, int MODE, bool S16, bool EDGE = false>
 __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block_id, const int nwork, char* lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave & 3) >> 1, wn = wave & 1;
@@ -171,7 +187,7 @@ __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block
   int m0, n0, slice;
   if constexpr (S16) {
     plp::f32x4v acc[plp::ModeCfg<MODE>::NACC][4][4];
-    if (!plp::planes_mainloop16<A_KS, B_KS, MODE>(k.p, block_id, nwork, lds, acc, m0, n0, slice)) return;
+    if (!plp::planes_mainloop16<A_KS, B_KS, MODE, EDGE>(k.p, block_id, nwork, lds, acc, m0, n0, slice)) return;
     __syncthreads();                                   // every computing wave is done reading operand tiles
     const int q = lane >> 4, c = lane & 15;
 #pragma unroll
@@ -185,7 +201,7 @@ __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block
           ldsw[(rt * 16 + 4 * q + r) * 68 + ct * 16 + c] = v;
         }
     float* C = k.e.C + (k.e.split_k > 1 ? (size_t)slice * k.e.M * k.e.ldc : 0);
-    staged_epilogue(k, C, ldsw, m0, n0, wm, wn, lane);
+    staged_epilogue<EDGE>(k, C, ldsw, m0, n0, wm, wn, lane);
   } else {
     f32x16 acc[plp::ModeCfg<MODE>::NACC][2][2];
     if (!plp::planes_mainloop<A_KS, B_KS, 32, MODE, 4, 0, 3>(k.p, block_id, nwork, lds, acc, m0, n0, slice)) return;
@@ -213,7 +229,7 @@ __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             ldsw[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + b * 32 + i] = acc[0][a][b][r];
-      staged_epilogue(k, C, ldsw, m0, n0, wm, wn, lane);
+      staged_epilogue<false>(k, C, ldsw, m0, n0, wm, wn, lane);
       return;
     }
     gemm_epilogue<false, 2>(k.e, C, acc[0], m0, n0, wm, wn, i, h);
@@ -227,10 +243,10 @@ constexpr int lds_bytes() {
   return stages > 4 * 64 * 68 * 4 ? stages : 4 * 64 * 68 * 4;
 }
 
-template <bool A_KS, bool B_KS, int MODE, bool S16>
+template <bool A_KS, bool B_KS, int MODE, bool S16, bool EDGE = false>
 __global__ __launch_bounds__(512) void planes_gemm_kernel(PlanesKern k) {
   __shared__ __attribute__((aligned(16))) char lds[lds_bytes<MODE>()];
-  planes_body<A_KS, B_KS, MODE, S16>(k, blockIdx.x, gridDim.x, lds);
+  planes_body<A_KS, B_KS, MODE, S16, EDGE>(k, blockIdx.x, gridDim.x, lds);
 }
 
 // backward pair of one layer in one launch: workgroups [0, n0) run dX = dz W (NN), the rest dW = dz^T a (TN, split-K
@@ -273,8 +289,9 @@ PlanesKern kern_of(GemmLayout layout, const PlanesGemmArgs& a) {
 }
 
 int grid_of(const PlanesGemmArgs& a) {
-  return (a.e.M / 128) * (a.e.N / 128) * (a.e.split_k > 1 ? a.e.split_k : 1);
+  return ((a.e.M + 127) / 128) * ((a.e.N + 127) / 128) * (a.e.split_k > 1 ? a.e.split_k : 1);
 }
+bool is_edge(const PlanesGemmArgs& a) { return (a.e.M % 128) != 0 || (a.e.N % 128) != 0; }
 
 }  // namespace
 
@@ -285,7 +302,12 @@ bool planes_gemm_ok(GemmLayout layout, const PlanesGemmArgs& a) {
   if (a.mode != plp::kBf16 && a.mode != plp::kF16x3) return false;
   if (!a.A || !a.B || !e.C || e.M <= 0 || e.N <= 0 || e.K <= 0) return false;
   const int splits = e.split_k > 1 ? e.split_k : 1;
-  if (e.M % 128 || e.N % 128 || e.K % (32 * splits)) return false;
+  if (e.K % (32 * splits)) return false;
+  if (e.M % 128 || e.N % 128) {
+    // overhanging tiles (16x16x32 loop, guarded epilogue): the source of an overhanging lane is clamped to the last valid
+    // row / 8-column chunk, so a k-strided operand's extent must be a multiple of 8; no BatchNorm-backward epilogue there
+    if (!mfma16_shape() || (e.N & 7) || (layout == kTN && (e.M & 7)) || e.bnr_z) return false;
+  }
   if ((a.lda & 7) || (a.ldb & 7)) return false;
   if ((reinterpret_cast<uintptr_t>(a.A) | reinterpret_cast<uintptr_t>(a.B)) & 15) return false;
   if (((a.a_plane | a.b_plane) & 7) != 0) return false;
@@ -320,7 +342,17 @@ int launch_gemm_planes(GemmLayout layout, const PlanesGemmArgs& a, hipStream_t s
     case kTN: hipLaunchKernelGGL((planes_gemm_kernel<true, true, MODE, S16>), grid, block, 0, s, k); break;      \
     default: PL_FAIL(PL_EINVAL, "gemm_planes: bad layout %d", (int)layout);                                     \
   }
-  if (mfma16_shape()) {
+  if (is_edge(a)) {
+#define PL_PLANES_LAUNCH_EDGE(MODE)                                                                                    \
+  switch (layout) {                                                                                                    \
+    case kNT: hipLaunchKernelGGL((planes_gemm_kernel<false, false, MODE, true, true>), grid, block, 0, s, k); break;   \
+    case kNN: hipLaunchKernelGGL((planes_gemm_kernel<false, true, MODE, true, true>), grid, block, 0, s, k); break;    \
+    case kTN: hipLaunchKernelGGL((planes_gemm_kernel<true, true, MODE, true, true>), grid, block, 0, s, k); break;     \
+    default: PL_FAIL(PL_EINVAL, "gemm_planes: bad layout %d", (int)layout);                                           \
+  }
+    if (a.mode == plp::kF16x3) { PL_PLANES_LAUNCH_EDGE(plp::kF16x3) } else { PL_PLANES_LAUNCH_EDGE(plp::kBf16) }
+#undef PL_PLANES_LAUNCH_EDGE
+  } else if (mfma16_shape()) {
     if (a.mode == plp::kF16x3) { PL_PLANES_LAUNCH(plp::kF16x3, true) } else { PL_PLANES_LAUNCH(plp::kBf16, true) }
   } else {
     if (a.mode == plp::kF16x3) { PL_PLANES_LAUNCH(plp::kF16x3, false) } else { PL_PLANES_LAUNCH(plp::kBf16, false) }
@@ -332,7 +364,7 @@ int launch_gemm_planes(GemmLayout layout, const PlanesGemmArgs& a, hipStream_t s
 }
 
 int launch_gemm_planes_pair(const PlanesGemmArgs& nn, const PlanesGemmArgs& tn, hipStream_t s) {
-  if (!planes_gemm_ok(kNN, nn) || !planes_gemm_ok(kTN, tn) || nn.mode != tn.mode)
+  if (!planes_gemm_ok(kNN, nn) || !planes_gemm_ok(kTN, tn) || nn.mode != tn.mode || is_edge(nn) || is_edge(tn))
     PL_FAIL(PL_ESHAPE, "gemm_planes_pair: unsupported problems");
   const PlanesKern k0 = kern_of(kNN, nn), k1 = kern_of(kTN, tn);
   const int g0 = grid_of(nn), g1 = grid_of(tn);

@@ -28,14 +28,20 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // every 16-lane group of ds_read_b128 then covers the 16 slots of the 256-byte bank row exactly once.
 __device__ __forceinline__ int kc16_swz(int row) { return (0 - (row >> 2)) & 3; }
 
+// `left`: rows (k-contiguous image) / columns (k-strided image) of the matrix from the tile origin on.  A tile that hangs
+// over the edge of its matrix re-reads the last valid row / 8-column chunk in the overhang (the LDS slot a lane fills is
+// fixed by its lane id; only the SOURCE is clamped): the MFMAs compute values the guarded epilogue never stores.
 template <bool KS>
-__device__ __forceinline__ uint32_t glds_lane_off16(int rb, int lane, int ld) {
+__device__ __forceinline__ uint32_t glds_lane_off16(int rb, int lane, int ld, int left = 0x7fffffff) {
   if (!KS) {   // 16 rows x 64 B per instruction
     const int row = rb * 16 + (lane >> 2);
     const int ch = (lane & 3) ^ kc16_swz(row);
-    return (uint32_t)(row * ld * 2 + ch * 16);
+    return (uint32_t)(min(row, left - 1) * ld * 2 + ch * 16);
   }
-  return glds_lane_off<true, 32>(rb, lane, ld);   // k-strided image: as the 32x32x16 loop (the guide's layout (b))
+  // k-strided image: as the 32x32x16 loop (the guide's layout (b)): 4 k-rows x 256 B per instruction
+  const int krow = rb * 4 + (lane >> 4);
+  const int ch = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (rb & 3));
+  return (uint32_t)(krow * ld * 2 + min(ch, (left >> 3) - 1) * 16);
 }
 
 // per-lane LDS byte offsets of the fragment reads inside one plane of one operand tile
@@ -83,7 +89,9 @@ __device__ __forceinline__ f32x4v mfma16x16(const s16x8 a, const s16x8 b, const 
 
 // acc[c][rt][ct][reg]: row = m0 + wm*64 + rt*16 + 4*(lane>>4) + reg, col = n0 + wn*64 + ct*16 + (lane&15)
 // Whole tiles only (as planes_mainloop); 512 threads; returns false in the loader waves.
-template <bool A_KS, bool B_KS, int MODE>
+// EDGE: M and N need not be multiples of 128 (M: any for a k-contiguous A, % 8 for a k-strided one; N % 8): see
+// glds_lane_off16.  K stays a whole number of 32-k tiles per slice.
+template <bool A_KS, bool B_KS, int MODE, bool EDGE = false>
 __device__ __forceinline__ bool planes_mainloop16(const PlanesArgs& p, const int block_id, const int nwork,
                                                   char* __restrict__ lds, f32x4v (&acc)[ModeCfg<MODE>::NACC][4][4],
                                                   int& m0, int& n0, int& slice) {
@@ -97,7 +105,7 @@ __device__ __forceinline__ bool planes_mainloop16(const PlanesArgs& p, const int
   const int lw = wave & 3;
   const int wm = (wave & 3) >> 1, wn = wave & 1;
 
-  const int tiles_n = p.N / 128;
+  const int tiles_n = EDGE ? (p.N + 127) / 128 : p.N / 128;
   const int splits = p.split_k > 1 ? p.split_k : 1;
   const int ntiles = nwork / splits;
   int w = block_id;
@@ -143,8 +151,8 @@ __device__ __forceinline__ bool planes_mainloop16(const PlanesArgs& p, const int
     int oa[2], ob[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      oa[j] = (int)glds_lane_off16<A_KS>(lw + 4 * j, lane, p.lda);
-      ob[j] = (int)glds_lane_off16<B_KS>(lw + 4 * j, lane, p.ldb);
+      oa[j] = (int)glds_lane_off16<A_KS>(lw + 4 * j, lane, p.lda, EDGE ? p.M - m0 : 0x7fffffff);
+      ob[j] = (int)glds_lane_off16<B_KS>(lw + 4 * j, lane, p.ldb, EDGE ? p.N - n0 : 0x7fffffff);
     }
     auto issue = [&](const int kt, const int stage_off) {
       const int sa = kt * ga_step, sb = kt * gb_step;

@@ -46,7 +46,11 @@ def _planes_gemm(pkg, layout, mode, a, b, bias=None, sa=1.0, sb=1.0):
 @pytest.mark.parametrize("mode,tol", [(PL_F16X3, 2e-6), (PL_BF16, 2e-2)])
 @pytest.mark.parametrize("layout,M,N,K", [(0, 4096, 1024, 1024), (1, 4096, 1024, 1024), (2, 1024, 1024, 4096),
                                           (0, 128, 128, 32), (0, 256, 128, 96), (1, 128, 384, 64), (2, 128, 256, 512),
-                                          (2, 256, 128, 160)])
+                                          (2, 256, 128, 160),
+                                          # tiles that hang over the matrix edge (the conv path's 64-wide layers, ragged
+                                          # pixel counts): clamped sources, guarded epilogue
+                                          (0, 200, 192, 64), (0, 1000, 64, 256), (0, 1, 8, 32), (1, 130, 64, 128),
+                                          (1, 300, 320, 96), (2, 64, 256, 512), (2, 200, 72, 256)])
 def test_planes_gemm_vs_fp64(pkg, mode, tol, layout, M, N, K):
     """Every layout (k-contiguous rows through ds_read_b128, k-strided through the transposing LDS read), K from one
     tile to 128 tiles (prologue / steady state / tail of the DMA pipeline), with a bias in the epilogue.  f16x3 must
@@ -91,11 +95,12 @@ def test_f16x3_tensor_scale_keeps_small_and_large_operands_fp32_grade(pkg, mag, 
 
 def test_planes_gemm_rejects_what_it_cannot_tile(pkg):
     L = pkg.lib()
-    one = torch.zeros(130 * 64, device=DEV)
+    one = torch.zeros(130 * 68, device=DEV)
     scratch = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
-    rc = L.pl_gemm_planes(0, PL_F16X3, one.data_ptr(), one.data_ptr(), one.data_ptr(), 130, 64, 32, None, 1.0, 1.0,
-                          scratch.data_ptr(), None)
-    assert rc != 0 and b"unsupported" in L.pl_last_error()
+    for M, N, K in ((130, 64, 40), (130, 68, 32)):            # K not whole 32-k tiles; N not a multiple of 8
+        rc = L.pl_gemm_planes(0, PL_F16X3, one.data_ptr(), one.data_ptr(), one.data_ptr(), M, N, K, None, 1.0, 1.0,
+                              scratch.data_ptr(), None)
+        assert rc != 0 and b"unsupported" in L.pl_last_error()
     assert L.pl_gemm_planes(0, 2, one.data_ptr(), one.data_ptr(), one.data_ptr(), 128, 128, 32, None, 1.0, 1.0,
                             scratch.data_ptr(), None) != 0                     # PL_BF16X6 has no planes form
 
