@@ -117,6 +117,12 @@ SIGNATURES = {
     "pl_bn_train_bwd": (_c.c_int, [_P, _P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _P, _P, _P, _P, _P]),
     "pl_add_relu_fwd": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P, _P]),
     "pl_mask_by_bits": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P]),
+    "pl_planes_split": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_float, _P, _P]),
+    "pl_bn_train_fwd_ex": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _c.c_float, _c.c_float, _P, _P, _P, _c.c_int,
+                                      _P, _P, _P, _P, _P, _P, _c.c_int, _P]),
+    "pl_bn_train_bwd_ex": (_c.c_int, [_P, _P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _P, _P, _P, _P, _P, _c.c_int, _P, _P]),
+    "pl_add_relu_fwd_ex": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_int, _P]),
+    "pl_mask_add_by_bits": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _P, _P]),
     "pl_maxpool3x3s2_nhwc": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P]),
     "pl_maxpool3x3s2_nhwc_bwd": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P]),
     "pl_maxpool3x3s2_nhwc_idx": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _P]),
@@ -141,6 +147,9 @@ SIGNATURES = {
     "pl_gemm_planes_scratch_bytes": (_c.c_size_t, [_c.c_int64, _c.c_int64, _c.c_int64]),
     "pl_gemm_planes": (_c.c_int, [_c.c_int, _c.c_int, _P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P,
                                   _c.c_float, _c.c_float, _P, _P]),
+    "pl_gemm_planes_splits": (_c.c_int, [_c.c_int64, _c.c_int64, _c.c_int64]),
+    "pl_gemm_planes_raw": (_c.c_int, [_c.c_int, _c.c_int, _P, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int64, _P,
+                                      _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_float, _P, _P, _P]),
     "pl_prof_enable": (_c.c_int, [_c.c_int]),
     "pl_prof_read": (_c.c_int, [_c.c_double, _c.c_double, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64),
                                 _c.POINTER(_c.c_double)]),

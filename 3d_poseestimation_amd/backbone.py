@@ -44,7 +44,7 @@ class ResNet(nn.Module):
 
     def __init__(self, architecture="resnet50", compute_dtype="bf16x6"):
         super().__init__()
-        self.compute_dtype = compute_dtype          # eval-mode arithmetic: "bf16x6" (fp32-grade) or "bf16"
+        self.compute_dtype = compute_dtype          # "bf16x6" (fp32-grade), "bf16", or "f16x3" (fp32-grade; training: 1x1 convolutions on the planes GEMM)
         if architecture not in self.LAYERS:
             raise ValueError(f"{architecture}: only the Bottleneck ResNets are built (the reference uses resnet50)")
         self.inplanes = 64
@@ -95,6 +95,8 @@ class ResNet(nn.Module):
             return conv.conv2d_nhwc_autograd(inp, w(m), stride, padding, ar)
         x = bnr(cv(x.float(), self.conv1, 2, 3), self.bn1, True)
         x = conv.maxpool3x3s2_nhwc_autograd(x)
+        if self.compute_dtype == "f16x3":
+            return self._blocks_train_planes(x, cv, bnr)
         for li in (1, 2, 3, 4):
             for blk in getattr(self, f"layer{li}"):
                 identity = x
@@ -104,6 +106,44 @@ class ResNet(nn.Module):
                 out = bnr(cv(out, blk.conv2, blk.stride, 1), blk.bn2, True)
                 out = bnr(cv(out, blk.conv3, 1, 0), blk.bn3, False)
                 x = conv.add_relu(out, identity)
+        return x
+
+    def _blocks_train_planes(self, x, cv, bnr):
+        """The Bottleneck stack of a training step with the 1x1 convolutions on the planes GEMM (conv.py, bottom):
+        conv1, conv3 and the stride-1 downsample read operand planes written by the kernel that produced their input
+        (residual join / BatchNorm apply) and their backward reads dz planes written by the BatchNorm backward; the 3x3
+        convolutions and the stride-2 downsamples (a row gather, not a GEMM on contiguous rows) keep the bf16x6 kernels.
+        Same arithmetic class throughout (fp32-grade products, fp32 accumulation).  Resnet.py:65-93, :139-142."""
+        bnp = conv.batchnorm_relu_train_planes
+        xp = conv.to_planes(x)
+        for li in (1, 2, 3, 4):
+            for blk in getattr(self, f"layer{li}"):
+                B, H, W, cin = x.shape
+                mid, cout = blk.conv1.out_channels, blk.conv3.out_channels
+                ho, wo = (H - 1) // blk.stride + 1, (W - 1) // blk.stride + 1
+                ok = conv.planes_conv_supported(B * H * W, cin, mid) and conv.planes_conv_supported(B * ho * wo, mid, cout)
+                if not ok:                     # (tiny maps / odd widths: the plain path, block by block)
+                    identity = x
+                    if blk.downsample is not None:
+                        identity = bnr(cv(x, blk.downsample[0], blk.stride, 0), blk.downsample[1], False)
+                    out = bnr(cv(x, blk.conv1, 1, 0), blk.bn1, True)
+                    out = bnr(cv(out, blk.conv2, blk.stride, 1), blk.bn2, True)
+                    out = bnr(cv(out, blk.conv3, 1, 0), blk.bn3, False)
+                    x, xp = conv.add_relu_planes(out, identity)
+                    continue
+                identity = x
+                if blk.downsample is not None:
+                    if blk.stride == 1 and conv.planes_conv_supported(B * H * W, cin, cout):
+                        lk = conv.PlaneLink()
+                        identity = bnp(conv.conv1x1_planes(xp, blk.downsample[0].weight, lk), blk.downsample[1], False,
+                                       False, lk)
+                    else:
+                        identity = bnr(cv(x, blk.downsample[0], blk.stride, 0), blk.downsample[1], False)
+                l1, l3 = conv.PlaneLink(), conv.PlaneLink()
+                out = bnp(conv.conv1x1_planes(xp, blk.conv1.weight, l1), blk.bn1, True, False, l1)      # fp32: conv2 reads it
+                out = bnp(cv(out, blk.conv2, blk.stride, 1), blk.bn2, True, True, None)                # planes only: conv3
+                out = bnp(conv.conv1x1_planes(out, blk.conv3.weight, l3), blk.bn3, False, False, l3)
+                x, xp = conv.add_relu_planes(out, identity)
         return x
 
     def forward(self, x_nhwc):

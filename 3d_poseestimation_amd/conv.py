@@ -55,7 +55,9 @@ def _opt(t, name, n):
     return t
 
 
-ARITH = {"bf16x6": _lib.PL_BF16X6, "bf16": _lib.PL_BF16}
+# "f16x3": the 1x1 convolutions of a TRAINING step run on the planes GEMM (bottom of this file); everything else -- the
+# 3x3 / 7x7 / transposed convolutions, eval mode -- keeps the fp32-grade bf16x6 kernels
+ARITH = {"bf16x6": _lib.PL_BF16X6, "bf16": _lib.PL_BF16, "f16x3": _lib.PL_BF16X6}
 
 
 def conv2d_nhwc(x, w_ohwi, stride=1, padding=0, scale=None, shift=None, bias=None, relu=0, resid=None,
@@ -416,3 +418,219 @@ class _ToNCHWFn(torch.autograd.Function):
 
 def nhwc_to_nchw_autograd(x):
     return _ToNCHWFn.apply(x)
+
+
+# ---------------------------------------------------------------------------------------------
+# 1x1 convolutions on the planes GEMM (compute_dtype "f16x3"): the lifter's round-2 design on the conv path.
+#
+# A 1x1 convolution over an NHWC map IS the GEMM [pixels][Cin] x [Cout][Cin]^T.  Its operands travel as 16-bit operand
+# planes written by the kernel that produces the tensor (BatchNorm apply, the residual join, BatchNorm backward), and the
+# GEMM stages them by LDS-DMA (csrc/gemm_planes16.h): three fp16 MFMAs per product instead of six bf16 ones and no split
+# work in the loop.  Between autograd nodes a tensor that exists ONLY as planes travels in a float32-typed "carrier" of
+# the logical shape: two fp16 planes are exactly four bytes per element, so the carrier has the size autograd expects of
+# the tensor (or of its gradient) while its bytes are [2][n] fp16.  Carriers are only ever handed to the functions below
+# (ResNet._forward_train wires producer to consumer directly); every gradient that reaches torch code is real fp32.
+#   reference: phase4_joined/Resnet.py:56-63, 65-93 (the Bottleneck's conv1 / conv3 / downsample and their autograd)
+# ---------------------------------------------------------------------------------------------
+ACT_PLANE_SCALE = 1.0        # csrc/pl_internal.h kActPlaneScale
+WEIGHT_PLANE_SCALE = 16.0    # kWeightPlaneScale
+
+
+class PlaneLink:
+    """Connects the BatchNorm behind a planes convolution to that convolution's backward: the BatchNorm backward writes
+    dz as planes (fp16, scaled by a power of two chosen on the device) and leaves {S, 1/S} here for the two GEMMs."""
+    __slots__ = ("dz_scale",)
+
+    def __init__(self):
+        self.dz_scale = None
+
+
+def _planes_of(t, scale):
+    """fp32 tensor -> carrier holding its PL_F16X3 planes (weights: once per step and direction, they are small)."""
+    t = t.contiguous()
+    out = torch.empty_like(t)
+    with torch.cuda.device(t.device):
+        rc = _lib.lib().pl_planes_split(t.data_ptr(), t.numel(), _lib.PL_F16X3, float(scale), out.data_ptr(),
+                                        _lib.current_stream_ptr())
+    _lib.check(rc, "pl_planes_split")
+    return out
+
+
+def _gemm_planes_raw(layout, a, a_rows_cols, b, b_rows_cols, M, N, K, out_scale, dyn_inv=None):
+    """C [M][N] fp32 from two carriers (planes of row-major matrices a_rows_cols / b_rows_cols)."""
+    L = _lib.lib()
+    dev = a.device
+    C = torch.empty(M, N, device=dev)
+    splits = L.pl_gemm_planes_splits(M, N, K)
+    slabs = torch.empty(splits * M * N, device=dev) if splits > 1 else None
+    with torch.cuda.device(dev):
+        rc = L.pl_gemm_planes_raw(layout, _lib.PL_F16X3, a.data_ptr(), a_rows_cols[0] * a_rows_cols[1], a_rows_cols[1],
+                                  b.data_ptr(), b_rows_cols[0] * b_rows_cols[1], b_rows_cols[1], C.data_ptr(), M, N, K,
+                                  None, float(out_scale), dyn_inv.data_ptr() if dyn_inv is not None else None,
+                                  slabs.data_ptr() if slabs is not None else None, _lib.current_stream_ptr())
+    _lib.check(rc, "pl_gemm_planes_raw")
+    return C
+
+
+def planes_conv_supported(rows, cin, cout):
+    """Shapes the planes GEMMs of a 1x1 convolution take: whole 32-k tiles in every contraction (Cin forward, Cout for
+    the data gradient, pixels for the weight gradient), 8-element rows, 32-bit byte offsets inside one operand."""
+    return cin % 32 == 0 and cout % 32 == 0 and rows % 32 == 0 and rows * max(cin, cout) * 4 < (1 << 31)
+
+
+class _Conv1x1PlanesFn(torch.autograd.Function):
+    """z = x W^T for a 1x1 convolution: xp = carrier of x's planes [rows][Cin], w [Cout][Cin] fp32 -> z [rows][Cout] fp32.
+    backward takes dz as a carrier (written by the BatchNorm behind this convolution, see PlaneLink)."""
+
+    @staticmethod
+    def forward(ctx, xp, w, link):
+        rows, cin = xp.shape
+        cout = w.shape[0]
+        wp = _planes_of(w, WEIGHT_PLANE_SCALE)
+        z = _gemm_planes_raw(0, xp, (rows, cin), wp, (cout, cin), rows, cout, cin,
+                             1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE))
+        ctx.save_for_backward(xp, w)
+        ctx.link = link
+        return z
+
+    @staticmethod
+    def backward(ctx, dzp):
+        xp, w = ctx.saved_tensors
+        rows, cin = xp.shape
+        cout = w.shape[0]
+        dzp = dzp.contiguous()
+        inv = ctx.link.dz_scale[1:]                      # 1 / S of the dz planes (device scalar)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wtp = _planes_of(w.t(), WEIGHT_PLANE_SCALE)  # [Cin][Cout]: the data gradient is NT on W^T
+            dx = _gemm_planes_raw(0, dzp, (rows, cout), wtp, (cin, cout), rows, cin, cout, 1.0 / WEIGHT_PLANE_SCALE, inv)
+        if ctx.needs_input_grad[1]:
+            dw = _gemm_planes_raw(2, dzp, (rows, cout), xp, (rows, cin), cout, cin, rows, 1.0 / ACT_PLANE_SCALE, inv)
+        return dx, dw, None
+
+
+def conv1x1_planes(xp, weight_oihw, link):
+    """xp: carrier [B, H, W, Cin] of the input's planes; weight: the nn.Conv2d parameter [Cout][Cin][1][1]."""
+    shape = xp.shape
+    cout, cin = weight_oihw.shape[0], weight_oihw.shape[1]
+    z = _Conv1x1PlanesFn.apply(xp.reshape(-1, cin), weight_oihw.float().reshape(cout, cin), link)
+    return z.reshape(*shape[:-1], cout)
+
+
+class _BNPlanesFn(torch.autograd.Function):
+    """_BNReLUFn with the output as fp32 (out_planes False) or ONLY as a carrier of its planes (True: the next op is a
+    planes convolution), and -- link given: the convolution that produced z is a planes convolution -- dz returned as a
+    carrier of its planes, range-scaled on the device (link.dz_scale)."""
+
+    @staticmethod
+    def forward(ctx, z, gamma, beta, running_mean, running_var, batches, eps, momentum, relu, out_planes, link):
+        shape = z.shape
+        C = shape[-1]
+        z2 = z.contiguous().reshape(-1, C)
+        rows = z2.shape[0]
+        for name, t in (("z", z2), ("gamma", gamma), ("beta", beta), ("running_mean", running_mean),
+                        ("running_var", running_var)):
+            _lib.require_device_tensor(t, name)
+        _lib.require_device_tensor(batches, "num_batches_tracked", torch.int64)
+        dev, L = z2.device, _lib.lib()
+        y = torch.empty_like(z2)                      # fp32 values, or the carrier
+        bits = torch.empty(rows, 4 * ((C + 255) // 256), dtype=torch.int64, device=dev)
+        mean, rstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        scratch = torch.empty(L.pl_bn_train_scratch_bytes(rows, C), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.pl_bn_train_fwd_ex(z2.data_ptr(), rows, C, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
+                                      running_mean.data_ptr(), running_var.data_ptr(), batches.data_ptr(), int(relu),
+                                      None if out_planes else y.data_ptr(), bits.data_ptr(), mean.data_ptr(),
+                                      rstd.data_ptr(), scratch.data_ptr(), y.data_ptr() if out_planes else None,
+                                      _lib.PL_F16X3, _lib.current_stream_ptr())
+        _lib.check(rc, "pl_bn_train_fwd_ex")
+        ctx.save_for_backward(z2, bits, mean, rstd, gamma)
+        ctx.shape, ctx.link = shape, link
+        return y.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        z2, bits, mean, rstd, gamma = ctx.saved_tensors
+        rows, C = z2.shape
+        dy2 = dy.contiguous().reshape(rows, C)
+        dev, L = z2.device, _lib.lib()
+        dz, dgamma, dbeta = torch.empty_like(z2), torch.empty(C, device=dev), torch.empty(C, device=dev)
+        scratch = torch.empty(L.pl_bn_train_scratch_bytes(rows, C), dtype=torch.uint8, device=dev)
+        link = ctx.link
+        if link is not None:
+            link.dz_scale = torch.empty(2, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.pl_bn_train_bwd_ex(dy2.data_ptr(), bits.data_ptr(), z2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                      gamma.data_ptr(), rows, C, None if link is not None else dz.data_ptr(),
+                                      dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(),
+                                      dz.data_ptr() if link is not None else None, _lib.PL_F16X3,
+                                      link.dz_scale.data_ptr() if link is not None else None, _lib.current_stream_ptr())
+        _lib.check(rc, "pl_bn_train_bwd_ex")
+        return dz.reshape(ctx.shape), dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def batchnorm_relu_train_planes(z, bn, relu=True, out_planes=False, link=None):
+    if bn.momentum is None:
+        raise NotImplementedError("cumulative moving average (momentum=None)")
+    return _BNPlanesFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                             float(bn.eps), float(bn.momentum), bool(relu), bool(out_planes), link)
+
+
+class _AddReLUPlanesFn(torch.autograd.Function):
+    """relu(a + b) as fp32 (the next join's identity) AND as a carrier of its planes (the next block's 1x1
+    convolutions); backward: one masked pass over the SUM of the two gradients (no separate add)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        if a.shape != b.shape:
+            raise ValueError("add_relu: shapes differ")
+        C = a.shape[-1]
+        a2, b2 = a.contiguous().reshape(-1, C), b.contiguous().reshape(-1, C)
+        _lib.require_device_tensor(a2, "a")
+        _lib.require_device_tensor(b2, "b")
+        rows = a2.shape[0]
+        out, outp = torch.empty_like(a2), torch.empty_like(a2)
+        bits = torch.empty(rows, 4 * ((C + 255) // 256), dtype=torch.int64, device=a2.device)
+        with torch.cuda.device(a2.device):
+            rc = _lib.lib().pl_add_relu_fwd_ex(a2.data_ptr(), b2.data_ptr(), rows, C, out.data_ptr(), bits.data_ptr(),
+                                               outp.data_ptr(), _lib.PL_F16X3, _lib.current_stream_ptr())
+        _lib.check(rc, "pl_add_relu_fwd_ex")
+        ctx.save_for_backward(bits)
+        ctx.shape = a.shape
+        return out.reshape(a.shape), outp.reshape(a.shape)
+
+    @staticmethod
+    def backward(ctx, g, gp):
+        (bits,) = ctx.saved_tensors
+        C = ctx.shape[-1]
+        if g is None:
+            g, gp = gp, None
+        g2 = g.contiguous().reshape(-1, C)
+        gp2 = gp.contiguous().reshape(-1, C) if gp is not None else None
+        dx = torch.empty_like(g2)
+        with torch.cuda.device(g2.device):
+            rc = _lib.lib().pl_mask_add_by_bits(g2.data_ptr(), gp2.data_ptr() if gp2 is not None else None, bits.data_ptr(),
+                                                g2.shape[0], C, dx.data_ptr(), _lib.current_stream_ptr())
+        _lib.check(rc, "pl_mask_add_by_bits")
+        dx = dx.reshape(ctx.shape)
+        return dx, dx
+
+
+def add_relu_planes(a, b):
+    return _AddReLUPlanesFn.apply(a, b)
+
+
+class _ToPlanesFn(torch.autograd.Function):
+    """fp32 tensor -> carrier of its planes (the stem's max-pool output, read by layer1's first 1x1 convolutions)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _planes_of(x, ACT_PLANE_SCALE)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def to_planes(x):
+    return _ToPlanesFn.apply(x)

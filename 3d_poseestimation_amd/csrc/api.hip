@@ -779,6 +779,44 @@ extern "C" int pl_gemm_planes(int layout, int mode, const float* A, const float*
   return launch_gemm_planes((GemmLayout)layout, g, s);
 }
 
+// K slices of a planes GEMM with few output tiles (the conv weight gradients: K = pixels): enough workgroups for every
+// CU twice, slices of whole 32-k tiles, at most 64 slabs
+extern "C" int pl_gemm_planes_splits(int64_t M, int64_t N, int64_t K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 1;
+  const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int s = 1;
+  while (s < 64 && tiles * s < 512 && K % (32 * 2 * s) == 0 && K / (2 * s) >= 256) s *= 2;
+  return s;
+}
+
+extern "C" int pl_gemm_planes_raw(int layout, int mode, const void* A, int64_t a_plane, int64_t lda, const void* Bm,
+                                  int64_t b_plane, int64_t ldb, float* C, int64_t M, int64_t N, int64_t K, const float* bias,
+                                  float out_scale, const float* dyn_inv, float* slabs, void* stream) {
+  if (layout < 0 || layout > 2) PL_FAIL(PL_EINVAL, "pl_gemm_planes_raw: layout %d", layout);
+  if (mode != PL_F16X3 && mode != PL_BF16) PL_FAIL(PL_EDTYPE, "pl_gemm_planes_raw: mode %d", mode);
+  if (!A || !Bm || !C) PL_FAIL(PL_EINVAL, "pl_gemm_planes_raw: null pointer");
+  if (M <= 0 || N <= 0 || K <= 0 || M > INT32_MAX || N > INT32_MAX || K > INT32_MAX || lda > INT32_MAX || ldb > INT32_MAX)
+    PL_FAIL(PL_ESHAPE, "pl_gemm_planes_raw: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  PlanesGemmArgs g = {};
+  g.A = static_cast<const unsigned short*>(A); g.B = static_cast<const unsigned short*>(Bm);
+  g.a_plane = a_plane; g.b_plane = b_plane; g.lda = (int)lda; g.ldb = (int)ldb;
+  g.mode = mode == PL_F16X3 ? 2 : 0;
+  g.out_scale = mode == PL_F16X3 ? out_scale : 1.0f;
+  g.dyn_inv = mode == PL_F16X3 ? dyn_inv : nullptr;
+  g.e.M = (int)M; g.e.N = (int)N; g.e.K = (int)K; g.e.ldc = (int)N;
+  const int splits = pl_gemm_planes_splits(M, N, K);
+  if (splits > 1) {
+    if (!slabs) PL_FAIL(PL_EWORKSPACE, "pl_gemm_planes_raw: %d K slices need slabs", splits);
+    if (bias) PL_FAIL(PL_EINVAL, "pl_gemm_planes_raw: no bias on a split-K problem");
+    g.e.C = slabs; g.e.split_k = splits;
+    PL_TRY(launch_gemm_planes((GemmLayout)layout, g, s));
+    return launch_reduce_slabs(slabs, splits, M * N, C, s);
+  }
+  g.e.C = C; g.e.split_k = 1; g.e.bias = bias;
+  return launch_gemm_planes((GemmLayout)layout, g, s);
+}
+
 // ---------------------------------------------------------------------------------------
 // measurement hook (bench.py): per-launch GEMM durations from HIP events on the launch stream
 // ---------------------------------------------------------------------------------------

@@ -272,7 +272,8 @@ __global__ __launch_bounds__(NTHR) void bn_colstats_kernel(const float* __restri
 // out = relu(a + b), bitmap of (out > 0): the residual join of a Bottleneck (Resnet.py:90-91) in training mode
 __global__ __launch_bounds__(NTHR) void add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                         float* __restrict__ out, uint64_t* __restrict__ bits, int B,
-                                                        int H) {
+                                                        int H, PlaneOut po) {
+  const PlaneDst pd = plane_dst(po);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int strip = blockIdx.x;
   const int c = strip * 256 + lane * 4;
@@ -293,20 +294,25 @@ __global__ __launch_bounds__(NTHR) void add_relu_kernel(const float* __restrict_
       if (lane == j) word = m;
     }
     if (lane < 4) bits[(size_t)r * wpr + strip * 4 + lane] = word;
-    if (active) st4(out + (size_t)r * H + c, make_float4(o[0], o[1], o[2], o[3]));
+    if (active) {
+      const float4 v = make_float4(o[0], o[1], o[2], o[3]);
+      st4(out + (size_t)r * H + c, v);
+      if (pd.kind) store_planes4(pd, (size_t)r * H + c, v);
+    }
   }
 }
 
 // dx = g where the bitmap says the forward output was positive, else 0 (backward of add_relu: both inputs get it)
 __global__ __launch_bounds__(NTHR) void mask_by_bits_kernel(const float* __restrict__ g, const uint64_t* __restrict__ bits,
-                                                            float* __restrict__ dx, int B, int H) {
+                                                            float* __restrict__ dx, int B, int H, const float* __restrict__ g2) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int strip = blockIdx.x;
   const int c = strip * 256 + lane * 4;
   if (c >= H) return;
   const int wpr = ((H + 255) >> 8) * 4;
   for (int r = blockIdx.y * 4 + wave; r < B; r += gridDim.y * 4) {
-    const float4 v = ld4(g + (size_t)r * H + c);
+    float4 v = ld4(g + (size_t)r * H + c);
+    if (g2) { const float4 u = ld4(g2 + (size_t)r * H + c); v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
     const uint64_t* bw = bits + (size_t)r * wpr + strip * 4;
     float4 d;
     d.x = ((bw[0] >> lane) & 1ull) ? v.x : 0.f;
@@ -1412,14 +1418,46 @@ extern "C" size_t pl_bn_train_scratch_bytes(int64_t rows, int64_t C) {
   const int64_t rv = rows / R;                      // rows of the reshaped view
   const size_t fwd = ((size_t)2 * R * bn_groups(rv) * C + 2 * (size_t)C) * sizeof(float);
   const int rc = bwd_row_chunks((int)rv, (int)C * R);
-  const size_t bwd = ((size_t)2 * R * rc * C + 3 * (size_t)C + (size_t)rc * R * C) * sizeof(float);
+  const size_t bwd = ((size_t)2 * R * rc * C + 3 * (size_t)C + (size_t)rc * R * C +
+                      (size_t)2 * ((C * R + 255) / 256) * rc + 16) * sizeof(float);     // ... + the dz range maxima
   return fwd > bwd ? fwd : bwd;
+}
+
+// operand planes of a [n]-element tensor for the planes GEMM: mode PL_F16X3 -> [2][n] fp16 (h, l), PL_BF16 -> [n] bf16
+static int plane_out_of(int mode, void* planes, int64_t n, float scale, const float* dyn, PlaneOut* po, const char* who) {
+  *po = PlaneOut{nullptr, nullptr, scale, dyn, 0};
+  if (!planes) return PL_OK;
+  if (mode != PL_F16X3 && mode != PL_BF16) PL_FAIL(PL_EDTYPE, "%s: planes want PL_F16X3 or PL_BF16 (mode %d)", who, mode);
+  if ((reinterpret_cast<uintptr_t>(planes) & 15) || (n & 7)) PL_FAIL(PL_EINVAL, "%s: planes misaligned", who);
+  po->h = static_cast<unsigned short*>(planes);
+  po->l = po->h + n;
+  po->kind = mode == PL_F16X3 ? 2 : 1;
+  return PL_OK;
+}
+
+extern "C" int pl_planes_split(const float* x, int64_t n, int mode, float scale, void* planes, void* stream) {
+  if (!x || !planes || n <= 0 || !(scale > 0.f)) PL_FAIL(PL_EINVAL, "pl_planes_split: bad arguments");
+  PlaneOut po;
+  PL_TRY(plane_out_of(mode, planes, n, scale, nullptr, &po, "pl_planes_split"));
+  return launch_split_planes(x, n, po, (hipStream_t)stream);
 }
 
 extern "C" int pl_bn_train_fwd(const float* z, int64_t rows, int64_t C, const float* gamma, const float* beta, float eps,
                                float momentum, float* running_mean, float* running_var, int64_t* batches, int relu,
                                float* y, uint64_t* bits, float* mean, float* rstd, void* scratch, void* stream) {
-  if (!z || !gamma || !beta || !y || !bits || !mean || !rstd || !scratch) PL_FAIL(PL_EINVAL, "pl_bn_train_fwd: null pointer");
+  if (!y) PL_FAIL(PL_EINVAL, "pl_bn_train_fwd: null pointer");
+  return pl_bn_train_fwd_ex(z, rows, C, gamma, beta, eps, momentum, running_mean, running_var, batches, relu, y, bits, mean,
+                            rstd, scratch, nullptr, 0, stream);
+}
+
+// + y_planes (optional): the output also / only (y == NULL) as operand planes of the next 1x1 convolution's planes GEMM
+extern "C" int pl_bn_train_fwd_ex(const float* z, int64_t rows, int64_t C, const float* gamma, const float* beta, float eps,
+                                  float momentum, float* running_mean, float* running_var, int64_t* batches, int relu,
+                                  float* y, uint64_t* bits, float* mean, float* rstd, void* scratch, void* y_planes,
+                                  int planes_mode, void* stream) {
+  if (!z || !gamma || !beta || (!y && !y_planes) || !bits || !mean || !rstd || !scratch) PL_FAIL(PL_EINVAL, "pl_bn_train_fwd: null pointer");
+  PlaneOut ypo;
+  PL_TRY(plane_out_of(planes_mode, y_planes, rows * C, kActPlaneScale, nullptr, &ypo, "pl_bn_train_fwd_ex"));
   if (rows < 2 || rows > INT32_MAX || C <= 0 || (C & 3)) PL_FAIL(rows < 2 ? PL_EBATCH : PL_ESHAPE, "pl_bn_train_fwd: rows=%lld C=%lld (C %% 4 == 0, rows >= 2)", (long long)rows, (long long)C);
   hipStream_t s = (hipStream_t)stream;
   const int R = bn_replicas(rows, C);
@@ -1435,8 +1473,7 @@ extern "C" int pl_bn_train_fwd(const float* z, int64_t rows, int64_t C, const fl
   const int strips = (H + 255) / 256;
   dim3 grid(strips, stream_rows_grid(B, strips));
   hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NTHR), 0, s, z, scale, shift, (const float*)nullptr, y, bits, B, H,
-                     relu ? 0 : 8, 0u, 1.0f, 0u, 0u, 0u, 0u, (const uint64_t*)nullptr, Hc,
-                     PlaneOut{nullptr, nullptr, 1.f, nullptr, 0}, (const uint64_t*)nullptr, 0u);
+                     relu ? 0 : 8, 0u, 1.0f, 0u, 0u, 0u, 0u, (const uint64_t*)nullptr, Hc, ypo, (const uint64_t*)nullptr, 0u);
   PL_CHECK_LAUNCH("bn_apply");
   return PL_OK;
 }
@@ -1444,37 +1481,69 @@ extern "C" int pl_bn_train_fwd(const float* z, int64_t rows, int64_t C, const fl
 extern "C" int pl_bn_train_bwd(const float* dy, const uint64_t* bits, const float* z, const float* mean, const float* rstd,
                                const float* gamma, int64_t rows, int64_t C, float* dz, float* dgamma, float* dbeta,
                                void* scratch, void* stream) {
-  if (!dy || !bits || !z || !mean || !rstd || !gamma || !dz || !dgamma || !dbeta || !scratch)
+  if (!dz) PL_FAIL(PL_EINVAL, "pl_bn_train_bwd: null pointer");
+  return pl_bn_train_bwd_ex(dy, bits, z, mean, rstd, gamma, rows, C, dz, dgamma, dbeta, scratch, nullptr, 0, nullptr, stream);
+}
+
+// + dz_planes (optional): dz also / only (dz == NULL) as operand planes of the 1x1 convolution's dgrad / wgrad planes GEMMs.
+// PL_F16X3: the fp16 planes hold S * dz with S the power of two from the range bound of the lifter's layers
+// (bn_bwd_finalize_kernel); dz_scale (device, 2 floats) receives {S, 1/S} -- the GEMMs take &dz_scale[1] as dyn_inv.
+extern "C" int pl_bn_train_bwd_ex(const float* dy, const uint64_t* bits, const float* z, const float* mean, const float* rstd,
+                                  const float* gamma, int64_t rows, int64_t C, float* dz, float* dgamma, float* dbeta,
+                                  void* scratch, void* dz_planes, int planes_mode, float* dz_scale, void* stream) {
+  if (!dy || !bits || !z || !mean || !rstd || !gamma || (!dz && !dz_planes) || !dgamma || !dbeta || !scratch)
     PL_FAIL(PL_EINVAL, "pl_bn_train_bwd: null pointer");
   if (rows < 2 || rows > INT32_MAX || C <= 0 || (C & 3)) PL_FAIL(PL_ESHAPE, "pl_bn_train_bwd: rows=%lld C=%lld", (long long)rows, (long long)C);
+  const bool scaled = dz_planes && planes_mode == PL_F16X3;
+  if (scaled && !dz_scale) PL_FAIL(PL_EINVAL, "pl_bn_train_bwd_ex: fp16 planes of dz need dz_scale");
+  PlaneOut po;
+  PL_TRY(plane_out_of(planes_mode, dz_planes, rows * C, 1.0f, scaled ? dz_scale : nullptr, &po, "pl_bn_train_bwd_ex"));
   hipStream_t s = (hipStream_t)stream;
   const int R = bn_replicas(rows, C);
   const int B = (int)(rows / R), H = (int)C * R, Hc = (int)C, RC = bwd_row_chunks(B, H);
   float* part = static_cast<float*>(scratch);
   float* coef = part + (size_t)2 * R * RC * Hc;
   float* part_db = coef + 3 * (size_t)Hc;
-  PL_TRY(launch_bn_bwd_reduce(dy, bits, z, mean, rstd, 1.0f, B, H, part, part + (size_t)RC * Hc, s, Hc));
-  PL_TRY(launch_bn_bwd_finalize(part, RC, R, R > 1 ? -1 : 0, B, Hc, gamma, rstd, coef, dgamma, dbeta, s));
-  return launch_bn_bwd_dz(dy, bits, z, mean, rstd, coef, 1.0f, 1, B, H, dz, part_db, s, Hc);
+  float* amax = part_db + (size_t)RC * R * Hc;                      // [strips * RC][2] (pl_bn_train_scratch_bytes)
+  const int n_amax = ((H + 255) / 256) * RC;
+  PL_TRY(launch_bn_bwd_reduce(dy, bits, z, mean, rstd, 1.0f, B, H, part, part + (size_t)RC * Hc, s, Hc, scaled ? amax : nullptr));
+  PL_TRY(launch_bn_bwd_finalize(part, RC, R, R > 1 ? -1 : 0, B, Hc, gamma, rstd, coef, dgamma, dbeta, s,
+                                scaled ? amax : nullptr, n_amax, scaled ? dz_scale : nullptr));
+  return launch_bn_bwd_dz(dy, bits, z, mean, rstd, coef, 1.0f, 1, B, H, dz, part_db, s, Hc, dz_planes ? &po : nullptr);
 }
 
 extern "C" int pl_add_relu_fwd(const float* a, const float* b, int64_t rows, int64_t C, float* out, uint64_t* bits,
                                void* stream) {
+  return pl_add_relu_fwd_ex(a, b, rows, C, out, bits, nullptr, 0, stream);
+}
+
+// + out_planes (optional): the block output also as operand planes (the next block's 1x1 convolutions read those)
+extern "C" int pl_add_relu_fwd_ex(const float* a, const float* b, int64_t rows, int64_t C, float* out, uint64_t* bits,
+                                  void* out_planes, int planes_mode, void* stream) {
   if (!a || !b || !out || !bits) PL_FAIL(PL_EINVAL, "pl_add_relu_fwd: null pointer");
   if (rows <= 0 || rows > INT32_MAX || C <= 0 || (C & 3)) PL_FAIL(PL_ESHAPE, "pl_add_relu_fwd: rows=%lld C=%lld", (long long)rows, (long long)C);
+  PlaneOut po;
+  PL_TRY(plane_out_of(planes_mode, out_planes, rows * C, kActPlaneScale, nullptr, &po, "pl_add_relu_fwd_ex"));
   const int strips = ((int)C + 255) / 256;
   dim3 grid(strips, stream_rows_grid((int)rows, strips));
-  hipLaunchKernelGGL(add_relu_kernel, grid, dim3(NTHR), 0, (hipStream_t)stream, a, b, out, bits, (int)rows, (int)C);
+  hipLaunchKernelGGL(add_relu_kernel, grid, dim3(NTHR), 0, (hipStream_t)stream, a, b, out, bits, (int)rows, (int)C, po);
   PL_CHECK_LAUNCH("add_relu");
   return PL_OK;
 }
 
 extern "C" int pl_mask_by_bits(const float* g, const uint64_t* bits, int64_t rows, int64_t C, float* dx, void* stream) {
+  return pl_mask_add_by_bits(g, nullptr, bits, rows, C, dx, stream);
+}
+
+// dx = (g + g2) where the bitmap is set, else 0: the residual join's backward with the sum of the two gradients that
+// reach the block output (through the next join and through the next block's convolutions) folded in (g2 may be NULL)
+extern "C" int pl_mask_add_by_bits(const float* g, const float* g2, const uint64_t* bits, int64_t rows, int64_t C, float* dx,
+                                   void* stream) {
   if (!g || !bits || !dx) PL_FAIL(PL_EINVAL, "pl_mask_by_bits: null pointer");
   if (rows <= 0 || rows > INT32_MAX || C <= 0 || (C & 3)) PL_FAIL(PL_ESHAPE, "pl_mask_by_bits: rows=%lld C=%lld", (long long)rows, (long long)C);
   const int strips = ((int)C + 255) / 256;
   dim3 grid(strips, stream_rows_grid((int)rows, strips));
-  hipLaunchKernelGGL(mask_by_bits_kernel, grid, dim3(NTHR), 0, (hipStream_t)stream, g, bits, dx, (int)rows, (int)C);
+  hipLaunchKernelGGL(mask_by_bits_kernel, grid, dim3(NTHR), 0, (hipStream_t)stream, g, bits, dx, (int)rows, (int)C, g2);
   PL_CHECK_LAUNCH("mask_by_bits");
   return PL_OK;
 }

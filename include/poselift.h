@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PL_VERSION 101 /* 0.1.1: PLDesc.step_dev, PL_F16X3, pl_adamw_flat_dev, pl_gemm_planes */
+#define PL_VERSION 102 /* 0.1.2: operand-plane outputs of the BatchNorm / join kernels, pl_gemm_planes_raw */
 
 typedef enum PLStatus {
   PL_OK = 0,
@@ -252,6 +252,29 @@ int pl_bn_train_bwd(const float* dy, const uint64_t* bits, const float* z, const
 int pl_add_relu_fwd(const float* a, const float* b, int64_t rows, int64_t C, float* out, uint64_t* bits, void* stream);
 int pl_mask_by_bits(const float* g, const uint64_t* bits, int64_t rows, int64_t C, float* dx, void* stream);
 
+/* The same building blocks writing GEMM OPERAND PLANES (the conv path's 1x1 convolutions on the planes GEMM, as the
+ * lifter's 1024-wide Linears: the kernel that produces a tensor also writes it as 16-bit planes, the GEMM stages them by
+ * LDS-DMA).  planes of an n-element tensor: planes_mode PL_F16X3 -> [2][n] fp16 (h = fp16(S x), l = fp16((S x - h) 2048)),
+ * PL_BF16 -> [n] bf16; 16-byte aligned, n % 8 == 0; NULL = none.  Replaces the same reference code as the plain forms.
+ *   pl_planes_split     : planes of an fp32 tensor with the static scale S (weights: 16; activations: 1)
+ *   pl_bn_train_fwd_ex  : y may be NULL when only the planes are wanted (S = 1)
+ *   pl_bn_train_bwd_ex  : dz may be NULL; PL_F16X3 planes hold S dz with S a power of two chosen on the device from a range
+ *                         bound of dz; dz_scale (device, 2 floats) receives {S, 1/S} -- pass dz_scale + 1 as dyn_inv below
+ *   pl_add_relu_fwd_ex  : out (fp32, the next join reads it) AND its planes (S = 1)
+ *   pl_mask_add_by_bits : dx = (g + g2) masked (g2 may be NULL): the join's backward with the gradient sum folded in */
+int pl_planes_split(const float* x, int64_t n, int planes_mode, float scale, void* planes, void* stream);
+int pl_bn_train_fwd_ex(const float* z, int64_t rows, int64_t C, const float* gamma, const float* beta, float eps,
+                       float momentum, float* running_mean, float* running_var, int64_t* batches, int relu,
+                       float* y, uint64_t* bits, float* mean, float* rstd, void* scratch, void* y_planes,
+                       int planes_mode, void* stream);
+int pl_bn_train_bwd_ex(const float* dy, const uint64_t* bits, const float* z, const float* mean, const float* rstd,
+                       const float* gamma, int64_t rows, int64_t C, float* dz, float* dgamma, float* dbeta,
+                       void* scratch, void* dz_planes, int planes_mode, float* dz_scale, void* stream);
+int pl_add_relu_fwd_ex(const float* a, const float* b, int64_t rows, int64_t C, float* out, uint64_t* bits,
+                       void* out_planes, int planes_mode, void* stream);
+int pl_mask_add_by_bits(const float* g, const float* g2, const uint64_t* bits, int64_t rows, int64_t C, float* dx,
+                        void* stream);
+
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1)  phase4_joined/Resnet.py:119.  x [B][H][W][C], C % 4 == 0;
  * y [B][(H-1)/2+1][(W-1)/2+1][C]. */
 int pl_maxpool3x3s2_nhwc(const float* x, int64_t B, int64_t H, int64_t W, int64_t C, float* y, void* stream);
@@ -405,6 +428,17 @@ int pl_gemm_arith(int layout, int arith, const float* A, const float* B, float* 
 size_t pl_gemm_planes_scratch_bytes(int64_t M, int64_t N, int64_t K);
 int pl_gemm_planes(int layout, int mode, const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t K,
                    const float* bias, float scale_a, float scale_b, void* scratch, void* stream);
+/* The planes GEMM on operands that already ARE planes (1x1 convolutions of the conv path: forward NT on
+ * [pixels][Cin] x [Cout][Cin], data gradient NT on dz [pixels][Cout] x W^T [Cin][Cout], weight gradient TN over the
+ * pixels; reference phase4_joined/Resnet.py:56-63 and their autograd).  Layout as pl_gemm_f32 (0 NT, 1 NN, 2 TN);
+ * a_plane / b_plane: elements between the two fp16 planes of an operand (unused for PL_BF16); lda / ldb: row strides
+ * of the plane matrices in elements (% 8 == 0).  C = out_scale * [dyn_inv[0] *] (A B) (+ bias): out_scale = 1 / (S_A S_B),
+ * dyn_inv a device scalar or NULL.  Any M; N % 8 == 0 (TN: M % 8 == 0 too); K % (32 * splits) == 0.  splits =
+ * pl_gemm_planes_splits(M, N, K) > 1 needs slabs of splits * M * N floats (K slices summed in order into C). */
+int pl_gemm_planes_splits(int64_t M, int64_t N, int64_t K);
+int pl_gemm_planes_raw(int layout, int mode, const void* A, int64_t a_plane, int64_t lda, const void* B, int64_t b_plane,
+                       int64_t ldb, float* C, int64_t M, int64_t N, int64_t K, const float* bias, float out_scale,
+                       const float* dyn_inv, float* slabs, void* stream);
 
 /* ---- next row N1: fused softmax + integral soft-argmax ----------------------------------- */
 /* Tail of Model_3D.forward  phase4_joined/Model.py:94-133 (ncoord 3, centred 1: (E/dim - 0.5)*2)

@@ -345,16 +345,18 @@ def test_maxpool_backward_vs_torch(pkg, shape):
     assert rc == 0 and torch.equal(dx.cpu(), want)
 
 
-@pytest.mark.parametrize("size", [64, 256])
-def test_model3d_train_step_vs_torch_autograd(pkg, size):
+@pytest.mark.parametrize("size,dtype", [(64, "bf16x6"), (256, "bf16x6"), (64, "f16x3"), (256, "f16x3")])
+def test_model3d_train_step_vs_torch_autograd(pkg, size, dtype):
     """Model_3D in TRAINING mode end to end on the library's differentiable pieces (53 convolutions with dgrad and
     wgrad, 56 BatchNorms on batch statistics, max-pool, three transposed convolutions, biased 1x1, soft-argmax)
     against the same stock modules under torch autograd on the CPU in fp64: loss and parameter gradients.
     size 256 = BASELINE configs[3]'s real frame size (phase4_joined/train.py:69-89 on 256 x 256 frames: 64 x 64 x 64
-    heat-map volumes, 8 x 8 layer4 maps); 64 is the quick case."""
+    heat-map volumes, 8 x 8 layer4 maps); 64 is the quick case.  dtype "f16x3": the Bottlenecks' 1x1 convolutions (forward,
+    data and weight gradients) on the planes GEMM with operand planes written by the BatchNorm / join kernels
+    (conv.py, bottom) -- at 256 every block qualifies, at 64 layer3 / layer4 fall back block by block."""
     import copy
     torch.manual_seed(7)
-    m = pkg.Model_3D().train()
+    m = pkg.Model_3D(compute_dtype=dtype).train()
     m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 51))
     with torch.no_grad():
         m.final_layer.weight.mul_(1e-3)

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/poselift.h but not exported"
     assert declared == set(pkg._lib.SIGNATURES), "ctypes signature table out of sync with the header"
-    assert pkg.lib().pl_version() == 101
+    assert pkg.lib().pl_version() == 102
 
 
 def test_entry_points_reject_bad_arguments_before_touching_a_device(pkg):
