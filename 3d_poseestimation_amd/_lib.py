@@ -150,6 +150,11 @@ SIGNATURES = {
     "pl_gemm_planes_splits": (_c.c_int, [_c.c_int64, _c.c_int64, _c.c_int64]),
     "pl_gemm_planes_raw": (_c.c_int, [_c.c_int, _c.c_int, _P, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int64, _P,
                                       _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_float, _P, _P, _P]),
+    "pl_conv2d_planes_fwd": (_c.c_int, [_c.c_int, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P,
+                                        _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_float, _P, _P]),
+    "pl_conv2d_planes_wgrad": (_c.c_int, [_c.c_int, _P, _c.c_int64, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64,
+                                          _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_float,
+                                          _P, _P, _P]),
     "pl_prof_enable": (_c.c_int, [_c.c_int]),
     "pl_prof_read": (_c.c_int, [_c.c_double, _c.c_double, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64),
                                 _c.POINTER(_c.c_double)]),

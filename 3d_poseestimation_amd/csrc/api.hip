@@ -817,6 +817,64 @@ extern "C" int pl_gemm_planes_raw(int layout, int mode, const void* A, int64_t a
   return launch_gemm_planes((GemmLayout)layout, g, s);
 }
 
+// KxK convolutions on the planes GEMM with the input gathered by the loader waves (implicit GEMM, gemm_planes16.h)
+static int conv_planes_geom(GemmArgs& e, int64_t B, int64_t H, int64_t W, int64_t Cin, int KH, int KW, int stride, int pad,
+                            int64_t* Ho, int64_t* Wo, const char* who) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
+    PL_FAIL(PL_ESHAPE, "%s: bad geometry", who);
+  *Ho = (H + 2 * pad - KH) / stride + 1;
+  *Wo = (W + 2 * pad - KW) / stride + 1;
+  if (*Ho <= 0 || *Wo <= 0 || B * *Ho * *Wo > INT32_MAX) PL_FAIL(PL_ESHAPE, "%s: bad geometry", who);
+  e.conv_cin = (int)Cin; e.conv_h = (int)H; e.conv_w = (int)W; e.conv_ho = (int)*Ho; e.conv_wo = (int)*Wo;
+  e.conv_kw = KW; e.conv_stride = stride; e.conv_pad_h = pad; e.conv_pad_w = pad;
+  return PL_OK;
+}
+
+extern "C" int pl_conv2d_planes_fwd(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W, int64_t Cin,
+                                    const void* w_planes, int64_t w_plane, int64_t Cout, int KH, int KW, int stride, int pad,
+                                    float* y, float out_scale, const float* dyn_inv, void* stream) {
+  if (mode != PL_F16X3 && mode != PL_BF16) PL_FAIL(PL_EDTYPE, "pl_conv2d_planes_fwd: mode %d", mode);
+  if (!x_planes || !w_planes || !y || Cout <= 0) PL_FAIL(PL_EINVAL, "pl_conv2d_planes_fwd: null pointer");
+  PlanesGemmArgs g = {};
+  int64_t Ho, Wo;
+  PL_TRY(conv_planes_geom(g.e, B, H, W, Cin, KH, KW, stride, pad, &Ho, &Wo, "pl_conv2d_planes_fwd"));
+  const int64_t K = (int64_t)KH * KW * Cin;
+  g.A = static_cast<const unsigned short*>(x_planes); g.B = static_cast<const unsigned short*>(w_planes);
+  g.a_plane = x_plane; g.b_plane = w_plane; g.lda = 0; g.ldb = (int)K;
+  g.mode = mode == PL_F16X3 ? 2 : 0;
+  g.out_scale = mode == PL_F16X3 ? out_scale : 1.0f;
+  g.dyn_inv = mode == PL_F16X3 ? dyn_inv : nullptr;
+  g.e.C = y; g.e.M = (int)(B * Ho * Wo); g.e.N = (int)Cout; g.e.K = (int)K; g.e.ldc = (int)Cout; g.e.split_k = 1;
+  return launch_gemm_planes(kNT, g, (hipStream_t)stream);
+}
+
+extern "C" int pl_conv2d_planes_wgrad(int mode, const void* dz_planes, int64_t dz_plane, const void* x_planes, int64_t x_plane,
+                                      int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH, int KW, int stride,
+                                      int pad, float* dw, float out_scale, const float* dyn_inv, float* slabs, void* stream) {
+  if (mode != PL_F16X3 && mode != PL_BF16) PL_FAIL(PL_EDTYPE, "pl_conv2d_planes_wgrad: mode %d", mode);
+  if (!dz_planes || !x_planes || !dw || Cout <= 0) PL_FAIL(PL_EINVAL, "pl_conv2d_planes_wgrad: null pointer");
+  PlanesGemmArgs g = {};
+  int64_t Ho, Wo;
+  PL_TRY(conv_planes_geom(g.e, B, H, W, Cin, KH, KW, stride, pad, &Ho, &Wo, "pl_conv2d_planes_wgrad"));
+  const int64_t N = (int64_t)KH * KW * Cin, K = B * Ho * Wo;
+  g.A = static_cast<const unsigned short*>(dz_planes); g.B = static_cast<const unsigned short*>(x_planes);
+  g.a_plane = dz_plane; g.b_plane = x_plane; g.lda = (int)Cout; g.ldb = 0;
+  g.mode = mode == PL_F16X3 ? 2 : 0;
+  g.out_scale = mode == PL_F16X3 ? out_scale : 1.0f;
+  g.dyn_inv = mode == PL_F16X3 ? dyn_inv : nullptr;
+  g.e.M = (int)Cout; g.e.N = (int)N; g.e.K = (int)K; g.e.ldc = (int)N;
+  const int splits = pl_gemm_planes_splits(Cout, N, K);
+  hipStream_t s = (hipStream_t)stream;
+  if (splits > 1) {
+    if (!slabs) PL_FAIL(PL_EWORKSPACE, "pl_conv2d_planes_wgrad: %d K slices need slabs", splits);
+    g.e.C = slabs; g.e.split_k = splits;
+    PL_TRY(launch_gemm_planes(kTN, g, s));
+    return launch_reduce_slabs(slabs, splits, Cout * N, dw, s);
+  }
+  g.e.C = dw; g.e.split_k = 1;
+  return launch_gemm_planes(kTN, g, s);
+}
+
 // ---------------------------------------------------------------------------------------
 // measurement hook (bench.py): per-launch GEMM durations from HIP events on the launch stream
 // ---------------------------------------------------------------------------------------

@@ -59,6 +59,12 @@ struct PlanesArgs {
   int lda, ldb, ldc;
   int split_k;       // > 1: slice z covers K/split_k and writes C + z*M*ldc
   size_t a_plane, b_plane;   // elements between two planes
+  // Implicit-GEMM convolution (16x16x32 loop; cv_cin == 0: none).  The gathered operand is the NHWC tensor x
+  // [B][cv_h][cv_w][cv_cin] (planes), every 32-k tile inside ONE filter tap (cv_cin % 32 == 0), padding pixels read as
+  // zeros (an out-of-range LDS-DMA lane writes zeros: tools/ubench/dma_oob_probe.hip):
+  //   forward / data gradient (NT, gathered A): A = x, row m = output pixel (b, oh, ow), k = (kh*cv_kw + kw)*cv_cin + ci;
+  //   weight gradient (TN, gathered B):          B = x, k = output pixel, column n = (kh*cv_kw + kw)*cv_cin + ci.
+  int cv_cin, cv_h, cv_w, cv_ho, cv_wo, cv_kw, cv_stride, cv_pad_h, cv_pad_w;
 };
 
 template <int BKX, int NPL, int NST = 3>

@@ -177,7 +177,8 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
 // under this loop's load -- and the staged epilogue for everything.  S16 = false (POSELIFT_MFMA32=1, same-box A/B): the
 // 32x32x16 loop; its accumulator layout is gemm_epilogue's, so only the addend / BatchNorm-backward cases are staged.
 // EDGE (16x16x32 loop only): M / N need not be multiples of 128 -- the conv path's 64-wide layers and ragged pixel counts
-template <bool A_KS, bool B_KS, int MODE, bool S16, bool EDGE = false>
+// CONV (16x16x32 loop only): 1 = A gathered as a convolution input (NT), 2 = B gathered for the weight gradient (TN)
+template <bool A_KS, bool B_KS, int MODE, bool S16, bool EDGE = false, int CONV = 0>
 __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block_id, const int nwork, char* lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave & 3) >> 1, wn = wave & 1;
@@ -187,7 +188,7 @@ __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block
   int m0, n0, slice;
   if constexpr (S16) {
     plp::f32x4v acc[plp::ModeCfg<MODE>::NACC][4][4];
-    if (!plp::planes_mainloop16<A_KS, B_KS, MODE, EDGE>(k.p, block_id, nwork, lds, acc, m0, n0, slice)) return;
+    if (!plp::planes_mainloop16<A_KS, B_KS, MODE, EDGE, CONV>(k.p, block_id, nwork, lds, acc, m0, n0, slice)) return;
     __syncthreads();                                   // every computing wave is done reading operand tiles
     const int q = lane >> 4, c = lane & 15;
 #pragma unroll
@@ -243,10 +244,10 @@ constexpr int lds_bytes() {
   return stages > 4 * 64 * 68 * 4 ? stages : 4 * 64 * 68 * 4;
 }
 
-template <bool A_KS, bool B_KS, int MODE, bool S16, bool EDGE = false>
+template <bool A_KS, bool B_KS, int MODE, bool S16, bool EDGE = false, int CONV = 0>
 __global__ __launch_bounds__(512) void planes_gemm_kernel(PlanesKern k) {
   __shared__ __attribute__((aligned(16))) char lds[lds_bytes<MODE>()];
-  planes_body<A_KS, B_KS, MODE, S16, EDGE>(k, blockIdx.x, gridDim.x, lds);
+  planes_body<A_KS, B_KS, MODE, S16, EDGE, CONV>(k, blockIdx.x, gridDim.x, lds);
 }
 
 // backward pair of one layer in one launch: workgroups [0, n0) run dX = dz W (NN), the rest dW = dz^T a (TN, split-K
@@ -280,6 +281,8 @@ PlanesKern kern_of(GemmLayout layout, const PlanesGemmArgs& a) {
   k.p.split_k = a.e.split_k;
   k.p.a_plane = (size_t)a.a_plane; k.p.b_plane = (size_t)a.b_plane;
   k.e = a.e;
+  k.p.cv_cin = a.e.conv_cin; k.p.cv_h = a.e.conv_h; k.p.cv_w = a.e.conv_w; k.p.cv_ho = a.e.conv_ho; k.p.cv_wo = a.e.conv_wo;
+  k.p.cv_kw = a.e.conv_kw; k.p.cv_stride = a.e.conv_stride; k.p.cv_pad_h = a.e.conv_pad_h; k.p.cv_pad_w = a.e.conv_pad_w;
   k.out_scale = a.out_scale;
   k.dyn_inv = a.dyn_inv;
   static const int vec = [] { const char* e = getenv("POSELIFT_ADDEND_SCALAR"); return (e && e[0] == '1') ? 0 : 1; }();
@@ -303,6 +306,19 @@ bool planes_gemm_ok(GemmLayout layout, const PlanesGemmArgs& a) {
   if (!a.A || !a.B || !e.C || e.M <= 0 || e.N <= 0 || e.K <= 0) return false;
   const int splits = e.split_k > 1 ? e.split_k : 1;
   if (e.K % (32 * splits)) return false;
+  if (e.conv_cin) {
+    // implicit-GEMM convolution: NT with A gathered (forward / data gradient) or TN with B gathered (weight gradient);
+    // the gathered tensor's bytes (every plane) must fit the DMA's 32-bit offsets
+    if (!mfma16_shape() || (layout != kNT && layout != kTN) || e.bnr_z) return false;
+    if (e.conv_h <= 0 || e.conv_w <= 0 || e.conv_ho <= 0 || e.conv_wo <= 0 || e.conv_kw <= 0 || e.conv_stride <= 0) return false;
+    const int64_t pixels = layout == kNT ? e.M : e.K;
+    if (pixels % ((int64_t)e.conv_ho * e.conv_wo)) return false;
+    const int64_t xb = pixels / ((int64_t)e.conv_ho * e.conv_wo) * e.conv_h * e.conv_w * e.conv_cin * 2;
+    const int npl_ = a.mode == plp::kF16x3 ? 2 : 1;
+    if (xb >= 0x7fffffe0ll || (int64_t)(npl_ - 1) * (layout == kNT ? a.a_plane : a.b_plane) * 2 + xb >= (1ll << 32)) return false;
+    if (layout == kNT && ((e.conv_cin & 31) || e.K % e.conv_cin)) return false;
+    if (layout == kTN && ((e.conv_cin & 7) || e.N % e.conv_cin)) return false;
+  }
   if (e.M % 128 || e.N % 128) {
     // overhanging tiles (16x16x32 loop, guarded epilogue): the source of an overhanging lane is clamped to the last valid
     // row / 8-column chunk, so a k-strided operand's extent must be a multiple of 8; no BatchNorm-backward epilogue there
@@ -342,7 +358,15 @@ int launch_gemm_planes(GemmLayout layout, const PlanesGemmArgs& a, hipStream_t s
     case kTN: hipLaunchKernelGGL((planes_gemm_kernel<true, true, MODE, S16>), grid, block, 0, s, k); break;      \
     default: PL_FAIL(PL_EINVAL, "gemm_planes: bad layout %d", (int)layout);                                     \
   }
-  if (is_edge(a)) {
+  if (a.e.conv_cin) {
+    if (layout == kNT) {
+      if (a.mode == plp::kF16x3) hipLaunchKernelGGL((planes_gemm_kernel<false, false, plp::kF16x3, true, true, 1>), grid, block, 0, s, k);
+      else hipLaunchKernelGGL((planes_gemm_kernel<false, false, plp::kBf16, true, true, 1>), grid, block, 0, s, k);
+    } else {
+      if (a.mode == plp::kF16x3) hipLaunchKernelGGL((planes_gemm_kernel<true, true, plp::kF16x3, true, true, 2>), grid, block, 0, s, k);
+      else hipLaunchKernelGGL((planes_gemm_kernel<true, true, plp::kBf16, true, true, 2>), grid, block, 0, s, k);
+    }
+  } else if (is_edge(a)) {
 #define PL_PLANES_LAUNCH_EDGE(MODE)                                                                                    \
   switch (layout) {                                                                                                    \
     case kNT: hipLaunchKernelGGL((planes_gemm_kernel<false, false, MODE, true, true>), grid, block, 0, s, k); break;   \

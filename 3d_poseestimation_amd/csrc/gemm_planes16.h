@@ -91,7 +91,11 @@ __device__ __forceinline__ f32x4v mfma16x16(const s16x8 a, const s16x8 b, const 
 // Whole tiles only (as planes_mainloop); 512 threads; returns false in the loader waves.
 // EDGE: M and N need not be multiples of 128 (M: any for a k-contiguous A, % 8 for a k-strided one; N % 8): see
 // glds_lane_off16.  K stays a whole number of 32-k tiles per slice.
-template <bool A_KS, bool B_KS, int MODE, bool EDGE = false>
+// CONV = 1 (with !A_KS, !B_KS): A gathered as an implicit-GEMM convolution input; CONV = 2 (A_KS, B_KS): B gathered as the
+// weight gradient's input (PlanesArgs::cv_*).  Only the loader waves change: per-lane source offsets from the pixel
+// decomposition, the tap's validity per lane, out-of-range (zero-filling) offsets for padding pixels.
+constexpr int kDmaOutOfRange = 0x7ffffff0;     // >= num_records of the gathered operand's descriptor
+template <bool A_KS, bool B_KS, int MODE, bool EDGE = false, int CONV = 0>
 __device__ __forceinline__ bool planes_mainloop16(const PlanesArgs& p, const int block_id, const int nwork,
                                                   char* __restrict__ lds, f32x4v (&acc)[ModeCfg<MODE>::NACC][4][4],
                                                   int& m0, int& n0, int& slice) {
@@ -148,21 +152,75 @@ __device__ __forceinline__ bool planes_mainloop16(const PlanesArgs& p, const int
   auto rotate = [&]() { const int o = st[0]; st[0] = st[1]; st[1] = st[2]; st[2] = o; };
 
   if (loader) {
+    static_assert(CONV == 0 || (CONV == 1 && !A_KS && !B_KS) || (CONV == 2 && A_KS && B_KS), "conv gathers: NT forward, TN wgrad");
     int oa[2], ob[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       oa[j] = (int)glds_lane_off16<A_KS>(lw + 4 * j, lane, p.lda, EDGE ? p.M - m0 : 0x7fffffff);
       ob[j] = (int)glds_lane_off16<B_KS>(lw + 4 * j, lane, p.ldb, EDGE ? p.N - n0 : 0x7fffffff);
     }
+    // ---- convolution gathers: descriptors on the whole tensor, offsets rebuilt per K tile by the (otherwise idle) loader VALU
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(CONV == 2 ? p.B : p.A), 0, 0x7fffffe0, 0x00020000);
+    int cih0[2] = {0, 0}, ciw0[2] = {0, 0}, cbase[2] = {0, 0};      // CONV 1: per DMA row of this lane
+    int ctap = 0, cc0 = 0, ckh = 0, ckw = 0;                        // CONV 1: filter tap / channel offset of the next tile issued
+    int wkh = 0, wkw = 0, wcol = 0;                                 // CONV 2: this lane's column chunk: tap and channel (fixed)
+    if (CONV == 1) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = (lw + 4 * j) * 16 + (lane >> 2);
+        const int m = min(m0 + row, p.M - 1);
+        const int ow = m % p.cv_wo, t2 = m / p.cv_wo;
+        const int oh = t2 % p.cv_ho, b = t2 / p.cv_ho;
+        cih0[j] = oh * p.cv_stride - p.cv_pad_h;
+        ciw0[j] = ow * p.cv_stride - p.cv_pad_w;
+        cbase[j] = ((b * p.cv_h + cih0[j]) * p.cv_w + ciw0[j]) * p.cv_cin * 2 + (((lane & 3) ^ kc16_swz(row)) << 4);
+      }
+      ctap = kbeg / p.cv_cin; cc0 = kbeg - ctap * p.cv_cin;
+      ckh = ctap / p.cv_kw; ckw = ctap - ckh * p.cv_kw;
+    }
+    if (CONV == 2) {
+      // the lane's 16-byte chunk = 8 consecutive columns n = (tap, ci .. ci+7) of the [k][N] image (cv_cin % 8 == 0)
+      const int ch = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (lw & 3));
+      const int n = min(n0 + ch * 8, p.N - 8);
+      const int tap = n / p.cv_cin;
+      wcol = n - tap * p.cv_cin;
+      wkh = tap / p.cv_kw; wkw = tap - wkh * p.cv_kw;
+    }
     auto issue = [&](const int kt, const int stage_off) {
       const int sa = kt * ga_step, sb = kt * gb_step;
       char* d = lds + stage_off + lw * 1024;
+      int va[2] = {oa[0], oa[1]}, vb[2] = {ob[0], ob[1]};
+      if (CONV == 1) {                                   // tiles are issued in K order: the tap advances incrementally
+        const int toff = ((ckh * p.cv_w + ckw) * p.cv_cin + cc0) * 2;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const bool ok = (unsigned)(cih0[j] + ckh) < (unsigned)p.cv_h && (unsigned)(ciw0[j] + ckw) < (unsigned)p.cv_w;
+          va[j] = ok ? cbase[j] + toff : kDmaOutOfRange;
+        }
+        cc0 += 32;
+        if (cc0 >= p.cv_cin) { cc0 = 0; if (++ckw == p.cv_kw) { ckw = 0; ++ckh; } }
+      }
+      if (CONV == 2) {
+        // k rows = output pixels kbeg + 32 kt + 4 (lw + 4 j) + (lane >> 4): pixel -> (b, oh, ow) -> the tap's input pixel
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int pix = kbeg + kt * 32 + (lw + 4 * j) * 4 + (lane >> 4);
+          const int ow = pix % p.cv_wo, t2 = pix / p.cv_wo;
+          const int oh = t2 % p.cv_ho, b = t2 / p.cv_ho;
+          const int ih = oh * p.cv_stride - p.cv_pad_h + wkh, iw = ow * p.cv_stride - p.cv_pad_w + wkw;
+          const bool ok = (unsigned)ih < (unsigned)p.cv_h && (unsigned)iw < (unsigned)p.cv_w;
+          vb[j] = ok ? (((b * p.cv_h + ih) * p.cv_w + iw) * p.cv_cin + wcol) * 2 : kDmaOutOfRange;
+        }
+      }
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          PLP_BLDS16(ra, d + pl * Cf::OPP + j * 4096, oa[j], sa + pl * apl);
-          PLP_BLDS16(rb, d + (NPL + pl) * Cf::OPP + j * 4096, ob[j], sb + pl * bpl);
+          if (CONV == 1) PLP_BLDS16(rx, d + pl * Cf::OPP + j * 4096, va[j], pl * apl);
+          else PLP_BLDS16(ra, d + pl * Cf::OPP + j * 4096, va[j], sa + pl * apl);
+          if (CONV == 2) PLP_BLDS16(rx, d + (NPL + pl) * Cf::OPP + j * 4096, vb[j], pl * bpl);
+          else PLP_BLDS16(rb, d + (NPL + pl) * Cf::OPP + j * 4096, vb[j], sb + pl * bpl);
         }
     };
     issue(0, st[0]);

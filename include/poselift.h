@@ -436,6 +436,18 @@ int pl_gemm_planes(int layout, int mode, const float* A, const float* B, float* 
  * dyn_inv a device scalar or NULL.  Any M; N % 8 == 0 (TN: M % 8 == 0 too); K % (32 * splits) == 0.  splits =
  * pl_gemm_planes_splits(M, N, K) > 1 needs slabs of splits * M * N floats (K slices summed in order into C). */
 int pl_gemm_planes_splits(int64_t M, int64_t N, int64_t K);
+/* KxK convolutions the same way (implicit GEMM: the loader waves gather the NHWC input planes tap by tap, padding pixels
+ * read as zeros; reference Resnet.py:58-60 conv2 and its autograd).  x_planes: planes of x [B][H][W][Cin], Cin % 32 == 0;
+ * w_planes: planes of the OHWI kernel [Cout][KH*KW*Cin]; y [B][Ho][Wo][Cout] fp32.  The data gradient of a stride-1
+ * convolution is the same call on the planes of dz with the kernel flipped and transposed ([Cin][KH][KW][Cout], pad
+ * KH-1-pad).  wgrad: dw [Cout][KH*KW*Cin] = sum over output pixels of dz (planes [B][Ho][Wo][Cout]) x gathered x; slabs:
+ * pl_gemm_planes_splits(Cout, KH*KW*Cin, B*Ho*Wo) * Cout * KH*KW*Cin floats when that is > 1.  out_scale / dyn_inv as above. */
+int pl_conv2d_planes_fwd(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W, int64_t Cin,
+                         const void* w_planes, int64_t w_plane, int64_t Cout, int KH, int KW, int stride, int pad,
+                         float* y, float out_scale, const float* dyn_inv, void* stream);
+int pl_conv2d_planes_wgrad(int mode, const void* dz_planes, int64_t dz_plane, const void* x_planes, int64_t x_plane,
+                           int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH, int KW, int stride,
+                           int pad, float* dw, float out_scale, const float* dyn_inv, float* slabs, void* stream);
 int pl_gemm_planes_raw(int layout, int mode, const void* A, int64_t a_plane, int64_t lda, const void* B, int64_t b_plane,
                        int64_t ldb, float* C, int64_t M, int64_t N, int64_t K, const float* bias, float out_scale,
                        const float* dyn_inv, float* slabs, void* stream);

@@ -548,3 +548,62 @@ def test_bf16_arithmetic_mode_trains(pkg):
     cos = float(torch.dot(g0, g1) / (g0.norm() * g1.norm()))
     assert cos > 0.98, cos                                     # same descent direction; not bit-close by design
     assert float((g0 - g1).norm()) > 0                          # and really a different arithmetic
+
+
+# ---------------------------------------------------------------------------- convolutions on the planes GEMM
+def _planes(pkg, t, scale=1.0):
+    from importlib import import_module
+    cv = import_module("3d_poseestimation_amd.conv")
+    return cv._planes_of(t, scale)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,K,stride,pad", [
+    (2, 16, 16, 64, 64, 3, 1, 1),        # layer1's conv2 in small: a 64-wide tile hanging over N
+    (2, 16, 24, 32, 128, 3, 2, 1),       # stride 2, one 32-k tile per tap
+    (2, 8, 8, 128, 72, 1, 2, 0),         # the stride-2 downsample: a row gather
+    (3, 9, 7, 64, 96, 3, 1, 1),          # odd map, 189 output pixels: ragged M (forward / data gradient only)
+    (1, 32, 32, 96, 256, 3, 1, 1),       # Cin not a power of two: taps of three 32-k tiles
+])
+def test_conv_planes_fwd_dgrad_wgrad_vs_torch_fp64(pkg, B, H, W, Cin, Cout, K, stride, pad):
+    """Implicit-GEMM convolution on the planes GEMM (LDS-DMA gather by the loader waves, zero-filling out-of-range lanes
+    for the padding): forward, data gradient (the same kernel on dz with the flipped kernel) and weight gradient (TN with
+    the gathered B operand) against torch's conv2d in fp64, inside the bound of an fp32 evaluation."""
+    L = pkg.lib()
+    g = torch.Generator().manual_seed(B * 131 + H * 17 + Cin + Cout + K)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(Cout, K, K, Cin, generator=g) * 0.05
+    Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    dz = torch.randn(B, Ho, Wo, Cout, generator=g)
+    xd, wd, dzd = x.to(DEV), w.to(DEV), dz.to(DEV)
+    xp, wp, dzp = _planes(pkg, xd, 1.0), _planes(pkg, wd, 16.0), _planes(pkg, dzd, 1.0)
+    s = torch.cuda.current_stream().cuda_stream
+    y = torch.full((B, Ho, Wo, Cout), float("nan"), device=DEV)
+    rc = L.pl_conv2d_planes_fwd(3, xp.data_ptr(), x.numel(), B, H, W, Cin, wp.data_ptr(), w.numel(), Cout,
+                                K, K, stride, pad, y.data_ptr(), 1.0 / 16.0, None, s)
+    assert rc == 0, L.pl_last_error()
+    x64 = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    w64 = w.double().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.conv2d(x64, w64, stride=stride, padding=pad)
+    ref.backward(dz.double().permute(0, 3, 1, 2))
+    mag = F.conv2d(x.double().abs().permute(0, 3, 1, 2), w.double().abs().permute(0, 3, 1, 2), stride=stride, padding=pad)
+    err = (y.cpu().double() - ref.detach().permute(0, 2, 3, 1)).abs()
+    assert bool((err <= 2e-6 * mag.permute(0, 2, 3, 1) + 1e-7).all()), float(err.max())
+    if stride == 1:
+        wf = w.flip(1, 2).permute(3, 1, 2, 0).contiguous().to(DEV)            # [Cin][KH][KW][Cout]
+        wfp = _planes(pkg, wf, 16.0)
+        dx = torch.full((B, H, W, Cin), float("nan"), device=DEV)
+        rc = L.pl_conv2d_planes_fwd(3, dzp.data_ptr(), dz.numel(), B, Ho, Wo, Cout, wfp.data_ptr(), wf.numel(),
+                                    Cin, K, K, 1, K - 1 - pad, dx.data_ptr(), 1.0 / 16.0, None, s)
+        assert rc == 0, L.pl_last_error()
+        want = x64.grad.permute(0, 2, 3, 1)
+        assert float((dx.cpu().double() - want).abs().max()) <= 3e-6 * float(want.abs().max()) * (K * K * Cout) ** 0.5
+    if (B * Ho * Wo) % 32 == 0:
+        n = Cout * K * K * Cin
+        splits = L.pl_gemm_planes_splits(Cout, K * K * Cin, B * Ho * Wo)
+        slabs = torch.empty(splits * n, device=DEV) if splits > 1 else None
+        dw = torch.full((Cout, K, K, Cin), float("nan"), device=DEV)
+        rc = L.pl_conv2d_planes_wgrad(3, dzp.data_ptr(), dz.numel(), xp.data_ptr(), x.numel(), B, H, W, Cin, Cout,
+                                      K, K, stride, pad, dw.data_ptr(), 1.0, None, slabs.data_ptr() if slabs is not None else None, s)
+        assert rc == 0, L.pl_last_error()
+        want = w64.grad.permute(0, 2, 3, 1)
+        assert float((dw.cpu().double() - want).abs().max()) <= 3e-6 * float(want.abs().max()) * (B * Ho * Wo) ** 0.5

@@ -23,6 +23,7 @@ def timed(step, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--B", type=int, default=32); ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--skip-eager", action="store_true")
     a = ap.parse_args()
     m = pkg.Model_3D().train()
     m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 31))
@@ -56,6 +57,11 @@ def main():
 
     t = timed(step_ours, a.iters)
     print(f"B={a.B} this library (fp32-grade arithmetic)        : {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
+    ours.compute_dtype = ours.preact.compute_dtype = "f16x3"
+    t = timed(step_ours, a.iters)
+    print(f"B={a.B} this library (fp32-grade, 1x1 on planes GEMM): {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
+    if a.skip_eager:
+        return
     ours.compute_dtype = ours.preact.compute_dtype = "bf16"
     t = timed(step_ours, a.iters)
     print(f"B={a.B} this library (bf16 arithmetic, fp32 storage) : {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")

@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""Profiling target: N training steps of Model_3D on the HIP path.  python3 tools/run_model3d_train.py [B] [iters]"""
+"""Profiling target: N training steps of Model_3D on the HIP path.  python3 tools/run_model3d_train.py [B] [iters] [bf16x6|f16x3|bf16]"""
 import importlib, os, sys, torch
 import torch.nn.functional as F
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("3d_poseestimation_amd")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-m = pkg.Model_3D().train()
+dtype = sys.argv[3] if len(sys.argv) > 3 else "bf16x6"
+m = pkg.Model_3D(compute_dtype=dtype).train()
 m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 31))
 with torch.no_grad():
     m.final_layer.weight.mul_(1e-3)
