@@ -109,39 +109,39 @@ class ResNet(nn.Module):
         return x
 
     def _blocks_train_planes(self, x, cv, bnr):
-        """The Bottleneck stack of a training step with the 1x1 convolutions on the planes GEMM (conv.py, bottom):
-        conv1, conv3 and the stride-1 downsample read operand planes written by the kernel that produced their input
-        (residual join / BatchNorm apply) and their backward reads dz planes written by the BatchNorm backward; the 3x3
-        convolutions and the stride-2 downsamples (a row gather, not a GEMM on contiguous rows) keep the bf16x6 kernels.
-        Same arithmetic class throughout (fp32-grade products, fp32 accumulation).  Resnet.py:65-93, :139-142."""
+        """The Bottleneck stack of a training step on the planes GEMM (conv.py, bottom): every convolution reads operand
+        planes written by the kernel that produced its input (residual join / BatchNorm apply) -- the 1x1 ones as plain
+        GEMMs, conv2 and the stride-2 downsample with the input gathered by the loader waves -- and every backward reads
+        dz planes written by the BatchNorm backward.  Only the block outputs exist in fp32 as well (the next join adds
+        them).  Same arithmetic class throughout (fp32-grade products, fp32 accumulation).  Resnet.py:65-93, :139-142."""
         bnp = conv.batchnorm_relu_train_planes
         xp = conv.to_planes(x)
         for li in (1, 2, 3, 4):
             for blk in getattr(self, f"layer{li}"):
                 B, H, W, cin = x.shape
-                mid, cout = blk.conv1.out_channels, blk.conv3.out_channels
-                ho, wo = (H - 1) // blk.stride + 1, (W - 1) // blk.stride + 1
-                ok = conv.planes_conv_supported(B * H * W, cin, mid) and conv.planes_conv_supported(B * ho * wo, mid, cout)
+                mid, cout, st = blk.conv1.out_channels, blk.conv3.out_channels, blk.stride
+                ho, wo = (H - 1) // st + 1, (W - 1) // st + 1
+                ok = (conv.planes_conv_supported(B * H * W, cin, mid) and conv.planes_conv_supported(B * ho * wo, mid, cout) and
+                      conv.planes_convk_supported(B, H, W, mid, mid, 3, st, 1) and
+                      (blk.downsample is None or conv.planes_convk_supported(B, H, W, cin, cout, 1, st, 0)))
                 if not ok:                     # (tiny maps / odd widths: the plain path, block by block)
                     identity = x
                     if blk.downsample is not None:
-                        identity = bnr(cv(x, blk.downsample[0], blk.stride, 0), blk.downsample[1], False)
+                        identity = bnr(cv(x, blk.downsample[0], st, 0), blk.downsample[1], False)
                     out = bnr(cv(x, blk.conv1, 1, 0), blk.bn1, True)
-                    out = bnr(cv(out, blk.conv2, blk.stride, 1), blk.bn2, True)
+                    out = bnr(cv(out, blk.conv2, st, 1), blk.bn2, True)
                     out = bnr(cv(out, blk.conv3, 1, 0), blk.bn3, False)
                     x, xp = conv.add_relu_planes(out, identity)
                     continue
                 identity = x
                 if blk.downsample is not None:
-                    if blk.stride == 1 and conv.planes_conv_supported(B * H * W, cin, cout):
-                        lk = conv.PlaneLink()
-                        identity = bnp(conv.conv1x1_planes(xp, blk.downsample[0].weight, lk), blk.downsample[1], False,
-                                       False, lk)
-                    else:
-                        identity = bnr(cv(x, blk.downsample[0], blk.stride, 0), blk.downsample[1], False)
-                l1, l3 = conv.PlaneLink(), conv.PlaneLink()
-                out = bnp(conv.conv1x1_planes(xp, blk.conv1.weight, l1), blk.bn1, True, False, l1)      # fp32: conv2 reads it
-                out = bnp(cv(out, blk.conv2, blk.stride, 1), blk.bn2, True, True, None)                # planes only: conv3
+                    lk = conv.PlaneLink()
+                    zd = (conv.conv1x1_planes(xp, blk.downsample[0].weight, lk) if st == 1 else
+                          conv.conv_planes(xp, blk.downsample[0].weight, st, 0, lk))
+                    identity = bnp(zd, blk.downsample[1], False, False, lk)
+                l1, l2, l3 = conv.PlaneLink(), conv.PlaneLink(), conv.PlaneLink()
+                out = bnp(conv.conv1x1_planes(xp, blk.conv1.weight, l1), blk.bn1, True, True, l1)
+                out = bnp(conv.conv_planes(out, blk.conv2.weight, st, 1, l2), blk.bn2, True, True, l2)
                 out = bnp(conv.conv1x1_planes(out, blk.conv3.weight, l3), blk.bn3, False, False, l3)
                 x, xp = conv.add_relu_planes(out, identity)
         return x

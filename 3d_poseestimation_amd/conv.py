@@ -634,3 +634,79 @@ class _ToPlanesFn(torch.autograd.Function):
 
 def to_planes(x):
     return _ToPlanesFn.apply(x)
+
+
+def _conv_planes_fwd(xp, x_shape, wp, w_shape, stride, pad, out_scale, dyn_inv=None):
+    """pl_conv2d_planes_fwd on carriers: xp planes of x [B][H][W][Cin], wp planes of the OHWI kernel w_shape."""
+    B, H, W, cin = x_shape
+    cout, kh, kw, _ = w_shape
+    ho, wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    y = torch.empty(B, ho, wo, cout, device=xp.device)
+    with torch.cuda.device(xp.device):
+        rc = _lib.lib().pl_conv2d_planes_fwd(_lib.PL_F16X3, xp.data_ptr(), B * H * W * cin, B, H, W, cin, wp.data_ptr(),
+                                             cout * kh * kw * cin, cout, kh, kw, stride, pad, y.data_ptr(), float(out_scale),
+                                             dyn_inv.data_ptr() if dyn_inv is not None else None, _lib.current_stream_ptr())
+    _lib.check(rc, "pl_conv2d_planes_fwd")
+    return y
+
+
+class _ConvKxKPlanesFn(torch.autograd.Function):
+    """KxK convolution (the Bottleneck's conv2, the stride-2 downsample) on the planes GEMM with the input gathered by the
+    loader waves: xp carrier of x's planes [B][H][W][Cin], w OHWI fp32 -> z [B][Ho][Wo][Cout] fp32.  backward takes dz as a
+    carrier (PlaneLink): the data gradient is the same kernel on dz with the kernel flipped and transposed (a stride-2
+    convolution's dz is first spread over the even pixels of a zero map), the weight gradient the TN GEMM over the output
+    pixels with the gathered x."""
+
+    @staticmethod
+    def forward(ctx, xp, w, stride, pad, link):
+        wp = _planes_of(w, WEIGHT_PLANE_SCALE)
+        z = _conv_planes_fwd(xp, xp.shape, wp, w.shape, stride, pad, 1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE))
+        ctx.save_for_backward(xp, w)
+        ctx.geom, ctx.link = (stride, pad), link
+        return z
+
+    @staticmethod
+    def backward(ctx, dzp):
+        xp, w = ctx.saved_tensors
+        stride, pad = ctx.geom
+        B, H, W, cin = xp.shape
+        cout, kh, kw, _ = w.shape
+        _, ho, wo, _ = dzp.shape
+        dzp = dzp.contiguous()
+        inv = ctx.link.dz_scale[1:]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wf = _planes_of(w.flip(1, 2).permute(3, 1, 2, 0), WEIGHT_PLANE_SCALE)          # [Cin][KH][KW][Cout]
+            if stride == 1:
+                src, shape = dzp, (B, ho, wo, cout)
+            else:
+                # dz at the even pixels of a zero map the size the stride-1 gradient expects (planes are 16-bit: as int16)
+                hu, wu = H + 2 * pad - kh + 1, W + 2 * pad - kw + 1
+                up = torch.zeros(2, B, hu, wu, cout, dtype=torch.int16, device=dzp.device)
+                up[:, :, ::stride, ::stride][:, :, :ho, :wo] = dzp.reshape(-1).view(torch.int16).reshape(2, B, ho, wo, cout)
+                src, shape = up.reshape(-1).view(torch.float32).reshape(B, hu, wu, cout), (B, hu, wu, cout)
+            dx = _conv_planes_fwd(src, shape, wf, (cin, kh, kw, cout), 1, kh - 1 - pad, 1.0 / WEIGHT_PLANE_SCALE, inv)
+        if ctx.needs_input_grad[1]:
+            L = _lib.lib()
+            n = cout * kh * kw * cin
+            splits = L.pl_gemm_planes_splits(cout, kh * kw * cin, B * ho * wo)
+            slabs = torch.empty(splits * n, device=dzp.device) if splits > 1 else None
+            dw = torch.empty(cout, kh, kw, cin, device=dzp.device)
+            with torch.cuda.device(dzp.device):
+                rc = L.pl_conv2d_planes_wgrad(_lib.PL_F16X3, dzp.data_ptr(), B * ho * wo * cout, xp.data_ptr(), B * H * W * cin,
+                                              B, H, W, cin, cout, kh, kw, stride, pad, dw.data_ptr(), 1.0 / ACT_PLANE_SCALE,
+                                              inv.data_ptr(), slabs.data_ptr() if slabs is not None else None,
+                                              _lib.current_stream_ptr())
+            _lib.check(rc, "pl_conv2d_planes_wgrad")
+        return dx, dw, None, None, None
+
+
+def conv_planes(xp, weight_oihw, stride, pad, link):
+    """xp: carrier [B, H, W, Cin]; weight: the nn.Conv2d parameter [Cout][Cin][KH][KW]."""
+    return _ConvKxKPlanesFn.apply(xp, to_ohwi(weight_oihw.float()), stride, pad, link)
+
+
+def planes_convk_supported(B, H, W, cin, cout, k, stride, pad):
+    ho, wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    big = max(B * H * W * cin, B * (H + 2) * (W + 2) * cout)
+    return cin % 32 == 0 and cout % 32 == 0 and (B * ho * wo) % 32 == 0 and big * 4 < (1 << 31)
