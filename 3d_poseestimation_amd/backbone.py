@@ -95,7 +95,7 @@ class ResNet(nn.Module):
             return conv.conv2d_nhwc_autograd(inp, w(m), stride, padding, ar)
         x = bnr(cv(x.float(), self.conv1, 2, 3), self.bn1, True)
         x = conv.maxpool3x3s2_nhwc_autograd(x)
-        if self.compute_dtype == "f16x3":
+        if self.compute_dtype in ("f16x3", "bf16p"):
             return self._blocks_train_planes(x, cv, bnr)
         for li in (1, 2, 3, 4):
             for blk in getattr(self, f"layer{li}"):
@@ -114,8 +114,12 @@ class ResNet(nn.Module):
         GEMMs, conv2 and the stride-2 downsample with the input gathered by the loader waves -- and every backward reads
         dz planes written by the BatchNorm backward.  Only the block outputs exist in fp32 as well (the next join adds
         them).  Same arithmetic class throughout (fp32-grade products, fp32 accumulation).  Resnet.py:65-93, :139-142."""
+        # "f16x3": two fp16 planes per operand (fp32-grade); "bf16p": ONE bf16 plane -- bf16 storage of the GEMM operands
+        # (activations, dz, weight shadow), everything off the planes path in bf16 arithmetic too (the throughput mode)
+        mode = conv._lib.PL_F16X3 if self.compute_dtype == "f16x3" else conv._lib.PL_BF16
+        PlaneLink = lambda: conv.PlaneLink(mode)     # noqa: E731
         bnp = conv.batchnorm_relu_train_planes
-        xp = conv.to_planes(x)
+        xp = conv.to_planes(x, mode)
         for li in (1, 2, 3, 4):
             for blk in getattr(self, f"layer{li}"):
                 B, H, W, cin = x.shape
@@ -131,19 +135,19 @@ class ResNet(nn.Module):
                     out = bnr(cv(x, blk.conv1, 1, 0), blk.bn1, True)
                     out = bnr(cv(out, blk.conv2, st, 1), blk.bn2, True)
                     out = bnr(cv(out, blk.conv3, 1, 0), blk.bn3, False)
-                    x, xp = conv.add_relu_planes(out, identity)
+                    x, xp = conv.add_relu_planes(out, identity, mode)
                     continue
                 identity = x
                 if blk.downsample is not None:
-                    lk = conv.PlaneLink()
+                    lk = PlaneLink()
                     zd = (conv.conv1x1_planes(xp, blk.downsample[0].weight, lk) if st == 1 else
                           conv.conv_planes(xp, blk.downsample[0].weight, st, 0, lk))
                     identity = bnp(zd, blk.downsample[1], False, False, lk)
-                l1, l2, l3 = conv.PlaneLink(), conv.PlaneLink(), conv.PlaneLink()
+                l1, l2, l3 = PlaneLink(), PlaneLink(), PlaneLink()
                 out = bnp(conv.conv1x1_planes(xp, blk.conv1.weight, l1), blk.bn1, True, True, l1)
                 out = bnp(conv.conv_planes(out, blk.conv2.weight, st, 1, l2), blk.bn2, True, True, l2)
                 out = bnp(conv.conv1x1_planes(out, blk.conv3.weight, l3), blk.bn3, False, False, l3)
-                x, xp = conv.add_relu_planes(out, identity)
+                x, xp = conv.add_relu_planes(out, identity, mode)
         return x
 
     def forward(self, x_nhwc):

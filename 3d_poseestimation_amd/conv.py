@@ -57,7 +57,7 @@ def _opt(t, name, n):
 
 # "f16x3": the 1x1 convolutions of a TRAINING step run on the planes GEMM (bottom of this file); everything else -- the
 # 3x3 / 7x7 / transposed convolutions, eval mode -- keeps the fp32-grade bf16x6 kernels
-ARITH = {"bf16x6": _lib.PL_BF16X6, "bf16": _lib.PL_BF16, "f16x3": _lib.PL_BF16X6}
+ARITH = {"bf16x6": _lib.PL_BF16X6, "bf16": _lib.PL_BF16, "f16x3": _lib.PL_BF16X6, "bf16p": _lib.PL_BF16}
 
 
 def conv2d_nhwc(x, w_ohwi, stride=1, padding=0, scale=None, shift=None, bias=None, relu=0, resid=None,
@@ -439,24 +439,26 @@ WEIGHT_PLANE_SCALE = 16.0    # kWeightPlaneScale
 class PlaneLink:
     """Connects the BatchNorm behind a planes convolution to that convolution's backward: the BatchNorm backward writes
     dz as planes (fp16, scaled by a power of two chosen on the device) and leaves {S, 1/S} here for the two GEMMs."""
-    __slots__ = ("dz_scale",)
+    __slots__ = ("dz_scale", "mode")
 
-    def __init__(self):
+    def __init__(self, mode=_lib.PL_F16X3):
         self.dz_scale = None
+        self.mode = mode          # PL_F16X3: two fp16 planes (fp32-grade); PL_BF16: one bf16 plane (bf16 STORAGE of the operands)
 
 
-def _planes_of(t, scale):
-    """fp32 tensor -> carrier holding its PL_F16X3 planes (weights: once per step and direction, they are small)."""
+def _planes_of(t, scale, mode=_lib.PL_F16X3):
+    """fp32 tensor -> carrier holding its planes (weights: once per step and direction, they are small).  A PL_BF16
+    carrier uses the first half of its bytes."""
     t = t.contiguous()
     out = torch.empty_like(t)
     with torch.cuda.device(t.device):
-        rc = _lib.lib().pl_planes_split(t.data_ptr(), t.numel(), _lib.PL_F16X3, float(scale), out.data_ptr(),
+        rc = _lib.lib().pl_planes_split(t.data_ptr(), t.numel(), mode, float(scale), out.data_ptr(),
                                         _lib.current_stream_ptr())
     _lib.check(rc, "pl_planes_split")
     return out
 
 
-def _gemm_planes_raw(layout, a, a_rows_cols, b, b_rows_cols, M, N, K, out_scale, dyn_inv=None):
+def _gemm_planes_raw(layout, a, a_rows_cols, b, b_rows_cols, M, N, K, out_scale, dyn_inv=None, mode=_lib.PL_F16X3):
     """C [M][N] fp32 from two carriers (planes of row-major matrices a_rows_cols / b_rows_cols)."""
     L = _lib.lib()
     dev = a.device
@@ -464,7 +466,7 @@ def _gemm_planes_raw(layout, a, a_rows_cols, b, b_rows_cols, M, N, K, out_scale,
     splits = L.pl_gemm_planes_splits(M, N, K)
     slabs = torch.empty(splits * M * N, device=dev) if splits > 1 else None
     with torch.cuda.device(dev):
-        rc = L.pl_gemm_planes_raw(layout, _lib.PL_F16X3, a.data_ptr(), a_rows_cols[0] * a_rows_cols[1], a_rows_cols[1],
+        rc = L.pl_gemm_planes_raw(layout, mode, a.data_ptr(), a_rows_cols[0] * a_rows_cols[1], a_rows_cols[1],
                                   b.data_ptr(), b_rows_cols[0] * b_rows_cols[1], b_rows_cols[1], C.data_ptr(), M, N, K,
                                   None, float(out_scale), dyn_inv.data_ptr() if dyn_inv is not None else None,
                                   slabs.data_ptr() if slabs is not None else None, _lib.current_stream_ptr())
@@ -486,9 +488,9 @@ class _Conv1x1PlanesFn(torch.autograd.Function):
     def forward(ctx, xp, w, link):
         rows, cin = xp.shape
         cout = w.shape[0]
-        wp = _planes_of(w, WEIGHT_PLANE_SCALE)
+        wp = _planes_of(w, WEIGHT_PLANE_SCALE, link.mode)
         z = _gemm_planes_raw(0, xp, (rows, cin), wp, (cout, cin), rows, cout, cin,
-                             1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE))
+                             1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), None, link.mode)
         ctx.save_for_backward(xp, w)
         ctx.link = link
         return z
@@ -499,13 +501,13 @@ class _Conv1x1PlanesFn(torch.autograd.Function):
         rows, cin = xp.shape
         cout = w.shape[0]
         dzp = dzp.contiguous()
-        inv = ctx.link.dz_scale[1:]                      # 1 / S of the dz planes (device scalar)
+        inv, mode = ctx.link.dz_scale[1:], ctx.link.mode   # 1 / S of the dz planes (device scalar; fp16 planes only)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wtp = _planes_of(w.t(), WEIGHT_PLANE_SCALE)  # [Cin][Cout]: the data gradient is NT on W^T
-            dx = _gemm_planes_raw(0, dzp, (rows, cout), wtp, (cin, cout), rows, cin, cout, 1.0 / WEIGHT_PLANE_SCALE, inv)
+            wtp = _planes_of(w.t(), WEIGHT_PLANE_SCALE, mode)  # [Cin][Cout]: the data gradient is NT on W^T
+            dx = _gemm_planes_raw(0, dzp, (rows, cout), wtp, (cin, cout), rows, cin, cout, 1.0 / WEIGHT_PLANE_SCALE, inv, mode)
         if ctx.needs_input_grad[1]:
-            dw = _gemm_planes_raw(2, dzp, (rows, cout), xp, (rows, cin), cout, cin, rows, 1.0 / ACT_PLANE_SCALE, inv)
+            dw = _gemm_planes_raw(2, dzp, (rows, cout), xp, (rows, cin), cout, cin, rows, 1.0 / ACT_PLANE_SCALE, inv, mode)
         return dx, dw, None
 
 
@@ -523,7 +525,7 @@ class _BNPlanesFn(torch.autograd.Function):
     carrier of its planes, range-scaled on the device (link.dz_scale)."""
 
     @staticmethod
-    def forward(ctx, z, gamma, beta, running_mean, running_var, batches, eps, momentum, relu, out_planes, link):
+    def forward(ctx, z, gamma, beta, running_mean, running_var, batches, eps, momentum, relu, out_planes, link, mode):
         shape = z.shape
         C = shape[-1]
         z2 = z.contiguous().reshape(-1, C)
@@ -542,7 +544,7 @@ class _BNPlanesFn(torch.autograd.Function):
                                       running_mean.data_ptr(), running_var.data_ptr(), batches.data_ptr(), int(relu),
                                       None if out_planes else y.data_ptr(), bits.data_ptr(), mean.data_ptr(),
                                       rstd.data_ptr(), scratch.data_ptr(), y.data_ptr() if out_planes else None,
-                                      _lib.PL_F16X3, _lib.current_stream_ptr())
+                                      mode, _lib.current_stream_ptr())
         _lib.check(rc, "pl_bn_train_fwd_ex")
         ctx.save_for_backward(z2, bits, mean, rstd, gamma)
         ctx.shape, ctx.link = shape, link
@@ -563,17 +565,19 @@ class _BNPlanesFn(torch.autograd.Function):
             rc = L.pl_bn_train_bwd_ex(dy2.data_ptr(), bits.data_ptr(), z2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                       gamma.data_ptr(), rows, C, None if link is not None else dz.data_ptr(),
                                       dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(),
-                                      dz.data_ptr() if link is not None else None, _lib.PL_F16X3,
+                                      dz.data_ptr() if link is not None else None,
+                                      link.mode if link is not None else _lib.PL_F16X3,
                                       link.dz_scale.data_ptr() if link is not None else None, _lib.current_stream_ptr())
         _lib.check(rc, "pl_bn_train_bwd_ex")
-        return dz.reshape(ctx.shape), dgamma, dbeta, None, None, None, None, None, None, None, None
+        return dz.reshape(ctx.shape), dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
-def batchnorm_relu_train_planes(z, bn, relu=True, out_planes=False, link=None):
+def batchnorm_relu_train_planes(z, bn, relu=True, out_planes=False, link=None, mode=_lib.PL_F16X3):
     if bn.momentum is None:
         raise NotImplementedError("cumulative moving average (momentum=None)")
     return _BNPlanesFn.apply(z, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                             float(bn.eps), float(bn.momentum), bool(relu), bool(out_planes), link)
+                             float(bn.eps), float(bn.momentum), bool(relu), bool(out_planes), link,
+                             link.mode if link is not None else mode)
 
 
 class _AddReLUPlanesFn(torch.autograd.Function):
@@ -581,7 +585,7 @@ class _AddReLUPlanesFn(torch.autograd.Function):
     convolutions); backward: one masked pass over the SUM of the two gradients (no separate add)."""
 
     @staticmethod
-    def forward(ctx, a, b):
+    def forward(ctx, a, b, mode):
         if a.shape != b.shape:
             raise ValueError("add_relu: shapes differ")
         C = a.shape[-1]
@@ -593,7 +597,7 @@ class _AddReLUPlanesFn(torch.autograd.Function):
         bits = torch.empty(rows, 4 * ((C + 255) // 256), dtype=torch.int64, device=a2.device)
         with torch.cuda.device(a2.device):
             rc = _lib.lib().pl_add_relu_fwd_ex(a2.data_ptr(), b2.data_ptr(), rows, C, out.data_ptr(), bits.data_ptr(),
-                                               outp.data_ptr(), _lib.PL_F16X3, _lib.current_stream_ptr())
+                                               outp.data_ptr(), mode, _lib.current_stream_ptr())
         _lib.check(rc, "pl_add_relu_fwd_ex")
         ctx.save_for_backward(bits)
         ctx.shape = a.shape
@@ -613,37 +617,37 @@ class _AddReLUPlanesFn(torch.autograd.Function):
                                                 g2.shape[0], C, dx.data_ptr(), _lib.current_stream_ptr())
         _lib.check(rc, "pl_mask_add_by_bits")
         dx = dx.reshape(ctx.shape)
-        return dx, dx
+        return dx, dx, None
 
 
-def add_relu_planes(a, b):
-    return _AddReLUPlanesFn.apply(a, b)
+def add_relu_planes(a, b, mode=_lib.PL_F16X3):
+    return _AddReLUPlanesFn.apply(a, b, mode)
 
 
 class _ToPlanesFn(torch.autograd.Function):
     """fp32 tensor -> carrier of its planes (the stem's max-pool output, read by layer1's first 1x1 convolutions)."""
 
     @staticmethod
-    def forward(ctx, x):
-        return _planes_of(x, ACT_PLANE_SCALE)
+    def forward(ctx, x, mode):
+        return _planes_of(x, ACT_PLANE_SCALE, mode)
 
     @staticmethod
     def backward(ctx, g):
-        return g
+        return g, None
 
 
-def to_planes(x):
-    return _ToPlanesFn.apply(x)
+def to_planes(x, mode=_lib.PL_F16X3):
+    return _ToPlanesFn.apply(x, mode)
 
 
-def _conv_planes_fwd(xp, x_shape, wp, w_shape, stride, pad, out_scale, dyn_inv=None):
+def _conv_planes_fwd(xp, x_shape, wp, w_shape, stride, pad, out_scale, dyn_inv=None, mode=_lib.PL_F16X3):
     """pl_conv2d_planes_fwd on carriers: xp planes of x [B][H][W][Cin], wp planes of the OHWI kernel w_shape."""
     B, H, W, cin = x_shape
     cout, kh, kw, _ = w_shape
     ho, wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
     y = torch.empty(B, ho, wo, cout, device=xp.device)
     with torch.cuda.device(xp.device):
-        rc = _lib.lib().pl_conv2d_planes_fwd(_lib.PL_F16X3, xp.data_ptr(), B * H * W * cin, B, H, W, cin, wp.data_ptr(),
+        rc = _lib.lib().pl_conv2d_planes_fwd(mode, xp.data_ptr(), B * H * W * cin, B, H, W, cin, wp.data_ptr(),
                                              cout * kh * kw * cin, cout, kh, kw, stride, pad, y.data_ptr(), float(out_scale),
                                              dyn_inv.data_ptr() if dyn_inv is not None else None, _lib.current_stream_ptr())
     _lib.check(rc, "pl_conv2d_planes_fwd")
@@ -659,8 +663,8 @@ class _ConvKxKPlanesFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xp, w, stride, pad, link):
-        wp = _planes_of(w, WEIGHT_PLANE_SCALE)
-        z = _conv_planes_fwd(xp, xp.shape, wp, w.shape, stride, pad, 1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE))
+        wp = _planes_of(w, WEIGHT_PLANE_SCALE, link.mode)
+        z = _conv_planes_fwd(xp, xp.shape, wp, w.shape, stride, pad, 1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), None, link.mode)
         ctx.save_for_backward(xp, w)
         ctx.geom, ctx.link = (stride, pad), link
         return z
@@ -673,19 +677,21 @@ class _ConvKxKPlanesFn(torch.autograd.Function):
         cout, kh, kw, _ = w.shape
         _, ho, wo, _ = dzp.shape
         dzp = dzp.contiguous()
-        inv = ctx.link.dz_scale[1:]
+        inv, mode = ctx.link.dz_scale[1:], ctx.link.mode
+        npl = 2 if mode == _lib.PL_F16X3 else 1
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wf = _planes_of(w.flip(1, 2).permute(3, 1, 2, 0), WEIGHT_PLANE_SCALE)          # [Cin][KH][KW][Cout]
+            wf = _planes_of(w.flip(1, 2).permute(3, 1, 2, 0), WEIGHT_PLANE_SCALE, mode)    # [Cin][KH][KW][Cout]
             if stride == 1:
                 src, shape = dzp, (B, ho, wo, cout)
             else:
                 # dz at the even pixels of a zero map the size the stride-1 gradient expects (planes are 16-bit: as int16)
                 hu, wu = H + 2 * pad - kh + 1, W + 2 * pad - kw + 1
                 up = torch.zeros(2, B, hu, wu, cout, dtype=torch.int16, device=dzp.device)
-                up[:, :, ::stride, ::stride][:, :, :ho, :wo] = dzp.reshape(-1).view(torch.int16).reshape(2, B, ho, wo, cout)
+                up[:npl, :, ::stride, ::stride][:, :, :ho, :wo] = \
+                    dzp.reshape(-1).view(torch.int16)[:npl * B * ho * wo * cout].reshape(npl, B, ho, wo, cout)
                 src, shape = up.reshape(-1).view(torch.float32).reshape(B, hu, wu, cout), (B, hu, wu, cout)
-            dx = _conv_planes_fwd(src, shape, wf, (cin, kh, kw, cout), 1, kh - 1 - pad, 1.0 / WEIGHT_PLANE_SCALE, inv)
+            dx = _conv_planes_fwd(src, shape, wf, (cin, kh, kw, cout), 1, kh - 1 - pad, 1.0 / WEIGHT_PLANE_SCALE, inv, mode)
         if ctx.needs_input_grad[1]:
             L = _lib.lib()
             n = cout * kh * kw * cin
@@ -693,7 +699,7 @@ class _ConvKxKPlanesFn(torch.autograd.Function):
             slabs = torch.empty(splits * n, device=dzp.device) if splits > 1 else None
             dw = torch.empty(cout, kh, kw, cin, device=dzp.device)
             with torch.cuda.device(dzp.device):
-                rc = L.pl_conv2d_planes_wgrad(_lib.PL_F16X3, dzp.data_ptr(), B * ho * wo * cout, xp.data_ptr(), B * H * W * cin,
+                rc = L.pl_conv2d_planes_wgrad(mode, dzp.data_ptr(), B * ho * wo * cout, xp.data_ptr(), B * H * W * cin,
                                               B, H, W, cin, cout, kh, kw, stride, pad, dw.data_ptr(), 1.0 / ACT_PLANE_SCALE,
                                               inv.data_ptr(), slabs.data_ptr() if slabs is not None else None,
                                               _lib.current_stream_ptr())

@@ -607,3 +607,28 @@ def test_conv_planes_fwd_dgrad_wgrad_vs_torch_fp64(pkg, B, H, W, Cin, Cout, K, s
         assert rc == 0, L.pl_last_error()
         want = w64.grad.permute(0, 2, 3, 1)
         assert float((dw.cpu().double() - want).abs().max()) <= 3e-6 * float(want.abs().max()) * (B * Ho * Wo) ** 0.5
+
+
+def test_model3d_bf16_storage_train_step_tracks_the_fp32_grade_one(pkg):
+    """compute_dtype "bf16p": the Bottleneck convolutions on ONE bf16 operand plane (bf16 storage of activations, dz and the
+    weight shadow; fp32 accumulation, fp32 BatchNorm statistics) and bf16 arithmetic elsewhere -- the throughput mode, never
+    the parity-gated one: its loss and gradients must track the fp32-grade step at bf16 accuracy."""
+    import copy
+    torch.manual_seed(11)
+    m = pkg.Model_3D().train()
+    m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 61))
+    with torch.no_grad():
+        m.final_layer.weight.mul_(1e-3)
+    frames = pkg.synth.seeded_frames(4, 62, size=256).to(DEV)
+    target = torch.randn(4, 51, device=DEV)
+    out = {}
+    for dt in ("bf16x6", "bf16p"):
+        md = copy.deepcopy(m).to(DEV)
+        md.compute_dtype = md.preact.compute_dtype = dt
+        loss = ((md(frames) - target) ** 2).mean()
+        loss.backward()
+        out[dt] = (float(loss.detach()), torch.cat([p.grad.reshape(-1) for p in md.parameters() if p.grad is not None]).double())
+    (l0, g0), (l1, g1) = out["bf16x6"], out["bf16p"]
+    assert abs(l1 - l0) < 2e-2 * abs(l0), (l0, l1)
+    cos = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
+    assert cos > 0.98 and bool(torch.isfinite(g1).all()), cos

@@ -59,7 +59,10 @@ def main():
     print(f"B={a.B} this library (fp32-grade arithmetic)        : {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
     ours.compute_dtype = ours.preact.compute_dtype = "f16x3"
     t = timed(step_ours, a.iters)
-    print(f"B={a.B} this library (fp32-grade, 1x1 on planes GEMM): {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
+    print(f"B={a.B} this library (fp32-grade, planes GEMM convs)  : {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
+    ours.compute_dtype = ours.preact.compute_dtype = "bf16p"
+    t = timed(step_ours, a.iters)
+    print(f"B={a.B} this library (bf16 operand storage, planes)   : {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
     if a.skip_eager:
         return
     ours.compute_dtype = ours.preact.compute_dtype = "bf16"
