@@ -42,7 +42,7 @@ class ResNet(nn.Module):
     """ResNet("resnet50" | "resnet101" | "resnet152"): the Bottleneck architectures of Resnet.py:104-110."""
     LAYERS = {"resnet50": [3, 4, 6, 3], "resnet101": [3, 4, 23, 3], "resnet152": [3, 8, 36, 3]}
 
-    def __init__(self, architecture="resnet50", compute_dtype="bf16x6"):
+    def __init__(self, architecture="resnet50", compute_dtype="f16x3"):
         super().__init__()
         self.compute_dtype = compute_dtype          # "bf16x6" (fp32-grade), "bf16", or "f16x3" (fp32-grade; training: 1x1 convolutions on the planes GEMM)
         if architecture not in self.LAYERS:
@@ -179,7 +179,7 @@ class ResNet(nn.Module):
 class _HeatmapNet(nn.Module):
     """Backbone + three transposed convolutions + final 1x1 convolution: the part Model_3D and Model_2D share."""
 
-    def __init__(self, depth_dim, architecture="resnet50", compute_dtype="bf16x6"):
+    def __init__(self, depth_dim, architecture="resnet50", compute_dtype="f16x3"):
         super().__init__()
         self.compute_dtype = compute_dtype
         self.deconv_dim = [256, 256, 256]
@@ -252,7 +252,7 @@ class _HeatmapNet(nn.Module):
 
 
 class Model_3D(_HeatmapNet):
-    def __init__(self, architecture="resnet50", compute_dtype="bf16x6"):
+    def __init__(self, architecture="resnet50", compute_dtype="f16x3"):
         super().__init__(64, architecture, compute_dtype)
 
     def forward(self, x):
@@ -264,7 +264,7 @@ class Model_3D(_HeatmapNet):
 
 
 class Model_2D(_HeatmapNet):
-    def __init__(self, architecture="resnet50", compute_dtype="bf16x6"):
+    def __init__(self, architecture="resnet50", compute_dtype="f16x3"):
         super().__init__(1, architecture, compute_dtype)
 
     def forward(self, x):
