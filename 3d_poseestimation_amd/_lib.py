@@ -152,6 +152,8 @@ SIGNATURES = {
                                       _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_float, _P, _P, _P]),
     "pl_conv2d_planes_fwd": (_c.c_int, [_c.c_int, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P,
                                         _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_float, _P, _P]),
+    "pl_deconv4x4s2_planes_fwd": (_c.c_int, [_c.c_int, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P,
+                                             _c.c_int64, _c.c_int64, _P, _c.c_float, _P, _P]),
     "pl_conv2d_planes_wgrad": (_c.c_int, [_c.c_int, _P, _c.c_int64, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64,
                                           _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_float,
                                           _P, _P, _P]),

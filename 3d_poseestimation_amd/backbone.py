@@ -84,7 +84,7 @@ class ResNet(nn.Module):
             self._cache = (v, {k: (tuple(t.detach() for t in x) if isinstance(x, tuple) else x) for k, x in f.items()})
         return self._cache[1]
 
-    def _forward_train(self, x):
+    def _forward_train(self, x, want_planes=False):
         """Training mode: batch statistics, running statistics updated, differentiable (Resnet.py:135-142, :65-93)."""
         def w(m):
             return conv.to_ohwi(m.weight.float())
@@ -96,7 +96,8 @@ class ResNet(nn.Module):
         x = bnr(cv(x.float(), self.conv1, 2, 3), self.bn1, True)
         x = conv.maxpool3x3s2_nhwc_autograd(x)
         if self.compute_dtype in ("f16x3", "bf16p"):
-            return self._blocks_train_planes(x, cv, bnr)
+            x, xp = self._blocks_train_planes(x, cv, bnr)
+            return (x, xp) if want_planes else x
         for li in (1, 2, 3, 4):
             for blk in getattr(self, f"layer{li}"):
                 identity = x
@@ -148,7 +149,7 @@ class ResNet(nn.Module):
                 out = bnp(conv.conv_planes(out, blk.conv2.weight, st, 1, l2), blk.bn2, True, True, l2)
                 out = bnp(conv.conv1x1_planes(out, blk.conv3.weight, l3), blk.bn3, False, False, l3)
                 x, xp = conv.add_relu_planes(out, identity, mode)
-        return x
+        return x, xp
 
     def forward(self, x_nhwc):
         """x [B, H, W, 3] fp32 (NHWC, as the phase4 loader delivers frames, Model.py:88) -> [B, H/32, W/32, 2048]."""
@@ -224,6 +225,30 @@ class _HeatmapNet(nn.Module):
     def _heatmap_logits_train(self, x_nhwc, nhwc=False):
         """Training mode, differentiable: [B, H, W, 3] -> [B, J*depth, H/4, W/4] (NCHW for the soft-argmax), or the
         NHWC logits as the final convolution writes them (nhwc=True: the depth-64 head reads them in place)."""
+        if self.compute_dtype in ("f16x3", "bf16p"):
+            # the head's transposed convolutions on the planes GEMM too (conv.py: _DeconvPlanesFn): the backbone hands over
+            # its output as planes, every BatchNorm between two of them writes planes only
+            mode = conv._lib.PL_F16X3 if self.compute_dtype == "f16x3" else conv._lib.PL_BF16
+            out, outp = self.preact._forward_train(x_nhwc, want_planes=True)
+            for i in (0, 3, 6):
+                B, H, W, cin = out.shape
+                cout = self.deconv_layers[i].weight.shape[1]
+                last = i == 6
+                if outp is not None and conv.planes_deconv_supported(B, H, W, cin, cout):
+                    lk = conv.PlaneLink(mode)
+                    z = conv.deconv4x4s2_planes(outp, self.deconv_layers[i].weight, lk)
+                    out = conv.batchnorm_relu_train_planes(z, self.deconv_layers[i + 1], True, not last, lk)
+                    outp = None if last else out
+                else:
+                    if outp is not None and out is outp:        # a planes-only tensor cannot feed the plain path
+                        raise RuntimeError("deconvolution head: map too small for the planes path after a planes-only layer")
+                    out = conv.batchnorm_relu_train(
+                        conv.deconv4x4s2_nhwc_autograd(out, self.deconv_layers[i].weight, "bf16x6" if mode == conv._lib.PL_F16X3 else "bf16"),
+                        self.deconv_layers[i + 1], True)
+                    outp = None
+            out = conv.conv2d_bias_nhwc_autograd(out, conv.to_ohwi(self.final_layer.weight.float()), self.final_layer.bias,
+                                                 arith=self.compute_dtype)
+            return out if nhwc else conv.nhwc_to_nchw_autograd(out)
         out = self.preact(x_nhwc)
         for i in (0, 3, 6):
             out = conv.batchnorm_relu_train(

@@ -716,3 +716,60 @@ def planes_convk_supported(B, H, W, cin, cout, k, stride, pad):
     ho, wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     big = max(B * H * W * cin, B * (H + 2) * (W + 2) * cout)
     return cin % 32 == 0 and cout % 32 == 0 and (B * ho * wo) % 32 == 0 and big * 4 < (1 << 31)
+
+
+class _DeconvPlanesFn(torch.autograd.Function):
+    """nn.ConvTranspose2d(4, 2, 1, bias=False) on the planes GEMM: xp carrier of x's planes [B][H][W][Cin], weight in torch's
+    [Cin][Cout][4][4] layout -> y [B][2H][2W][Cout] fp32 (four 2x2-tap gathers, one per output parity).  y = C^T x for the
+    stride-2 convolution C with the same filter, so the backward (dy as a carrier, PlaneLink) is dx = C dy -- the gathered
+    forward kernel, 4x4 stride 2 -- and dW = the weight gradient of C with the roles of x and dy exchanged."""
+
+    @staticmethod
+    def forward(ctx, xp, weight, link):
+        B, H, W, cin = xp.shape
+        cout = weight.shape[1]
+        wsub = _planes_of(deconv_subkernels(weight.float()), WEIGHT_PLANE_SCALE, link.mode)
+        y = torch.empty(B, 2 * H, 2 * W, cout, device=xp.device)
+        with torch.cuda.device(xp.device):
+            rc = _lib.lib().pl_deconv4x4s2_planes_fwd(link.mode, xp.data_ptr(), xp.numel(), B, H, W, cin, wsub.data_ptr(),
+                                                      wsub.numel(), cout, y.data_ptr(),
+                                                      1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), None,
+                                                      _lib.current_stream_ptr())
+        _lib.check(rc, "pl_deconv4x4s2_planes_fwd")
+        ctx.save_for_backward(xp, weight)
+        ctx.link = link
+        return y
+
+    @staticmethod
+    def backward(ctx, dyp):
+        xp, weight = ctx.saved_tensors
+        B, H, W, cin = xp.shape
+        cout = weight.shape[1]
+        dyp = dyp.contiguous()
+        inv, mode = ctx.link.dz_scale[1:], ctx.link.mode
+        dx = dw = None
+        if ctx.needs_input_grad[0]:       # C dy: OHWI kernel [Cin][4][4][Cout]
+            wc = _planes_of(weight.float().permute(0, 2, 3, 1), WEIGHT_PLANE_SCALE, mode)
+            dx = _conv_planes_fwd(dyp, (B, 2 * H, 2 * W, cout), wc, (cin, 4, 4, cout), 2, 1, 1.0 / WEIGHT_PLANE_SCALE, inv, mode)
+        if ctx.needs_input_grad[1]:       # wgrad of C: "output gradient" x [B][H][W][Cin], gathered input dy -> [Cin][4][4][Cout]
+            L = _lib.lib()
+            n = cin * 16 * cout
+            splits = L.pl_gemm_planes_splits(cin, 16 * cout, B * H * W)
+            slabs = torch.empty(splits * n, device=dyp.device) if splits > 1 else None
+            dwc = torch.empty(cin, 4, 4, cout, device=dyp.device)
+            with torch.cuda.device(dyp.device):
+                rc = L.pl_conv2d_planes_wgrad(mode, xp.data_ptr(), xp.numel(), dyp.data_ptr(), dyp.numel(), B, 2 * H, 2 * W,
+                                              cout, cin, 4, 4, 2, 1, dwc.data_ptr(), 1.0 / ACT_PLANE_SCALE, inv.data_ptr(),
+                                              slabs.data_ptr() if slabs is not None else None, _lib.current_stream_ptr())
+            _lib.check(rc, "pl_conv2d_planes_wgrad")
+            dw = dwc.permute(0, 3, 1, 2).contiguous()
+        return dx, dw, None
+
+
+def deconv4x4s2_planes(xp, weight_iohw, link):
+    return _DeconvPlanesFn.apply(xp, weight_iohw, link)
+
+
+def planes_deconv_supported(B, H, W, cin, cout):
+    return (cin % 32 == 0 and cout % 32 == 0 and (B * H * W) % 32 == 0 and
+            max(B * H * W * cin, B * 4 * H * W * cout) * 4 < (1 << 31))

@@ -84,6 +84,18 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
       }
     }
   }
+  if (EDGE && e.scat_on) {                       // one output parity of a transposed convolution (GemmArgs::scat_*)
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      if (!ok(it)) continue;
+      const int m = row0 + 4 * it;
+      const int c = m % e.conv_wo, t = m / e.conv_wo;
+      const int a = t % e.conv_ho, b = t / e.conv_ho;
+      const size_t orow = ((size_t)b * 2 * e.conv_ho + 2 * a + e.scat_ph) * 2 * e.conv_wo + 2 * c + e.scat_pw;
+      *reinterpret_cast<float4*>(C + orow * e.ldc + col0) = v[it];
+    }
+    return;
+  }
 #pragma unroll
   for (int it = 0; it < 16; ++it)
     if (ok(it)) *reinterpret_cast<float4*>(C + o0 + (size_t)it * 4 * e.ldc) = v[it];
@@ -317,6 +329,8 @@ bool planes_gemm_ok(GemmLayout layout, const PlanesGemmArgs& a) {
     const int npl_ = a.mode == plp::kF16x3 ? 2 : 1;
     if (xb >= 0x7fffffe0ll || (int64_t)(npl_ - 1) * (layout == kNT ? a.a_plane : a.b_plane) * 2 + xb >= (1ll << 32)) return false;
     if (layout == kNT && ((e.conv_cin & 31) || e.K % e.conv_cin)) return false;
+    if (e.scat_on && (layout != kNT || e.split_k > 1 || e.bias || e.addend || e.resid || e.col_scale || e.relu || e.stat_sum))
+      return false;
     if (layout == kTN && ((e.conv_cin & 7) || e.N % e.conv_cin)) return false;
   }
   if (e.M % 128 || e.N % 128) {

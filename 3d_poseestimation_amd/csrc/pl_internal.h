@@ -72,6 +72,10 @@ struct GemmArgs {
   float* bnr_part_dy;       // [M/64][N]
   float* bnr_part_dyz;      // [M/64][N]
   float* bnr_amax;          // [(M/64) * (N/64)][2] or NULL
+  // planes convolution launches only: row m = (b, a, c) of a conv_ho x conv_wo grid is stored at pixel
+  // (b, 2a + scat_ph, 2c + scat_pw) of a [B][2 conv_ho][2 conv_wo][ldc] map (one output parity of a 4x4 stride-2
+  // transposed convolution); plain stores only
+  int scat_on, scat_ph, scat_pw;
   // host side only: scratch for the small-batch split-K path (gemm_thin.hip); NULL = never take it
   float* thin_scratch;
   size_t thin_scratch_floats;

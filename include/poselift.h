@@ -445,6 +445,13 @@ int pl_gemm_planes_splits(int64_t M, int64_t N, int64_t K);
 int pl_conv2d_planes_fwd(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W, int64_t Cin,
                          const void* w_planes, int64_t w_plane, int64_t Cout, int KH, int KW, int stride, int pad,
                          float* y, float out_scale, const float* dyn_inv, void* stream);
+/* nn.ConvTranspose2d(4, 2, 1, bias=False) forward the same way (Model.py:47-63): four 2x2-tap gathers at the input
+ * resolution, one per output parity, stored straight into y [B][2H][2W][Cout]; wsub_planes = planes of
+ * conv.deconv_subkernels(weight) [4][Cout][2][2][Cin].  Its data gradient is pl_conv2d_planes_fwd (4x4, stride 2, pad 1)
+ * on the planes of dy, its weight gradient pl_conv2d_planes_wgrad with the roles of x and dy exchanged. */
+int pl_deconv4x4s2_planes_fwd(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W, int64_t Cin,
+                              const void* wsub_planes, int64_t wsub_plane, int64_t Cout, float* y, float out_scale,
+                              const float* dyn_inv, void* stream);
 int pl_conv2d_planes_wgrad(int mode, const void* dz_planes, int64_t dz_plane, const void* x_planes, int64_t x_plane,
                            int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH, int KW, int stride,
                            int pad, float* dw, float out_scale, const float* dyn_inv, float* slabs, void* stream);
