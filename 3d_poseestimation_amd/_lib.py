@@ -152,6 +152,9 @@ SIGNATURES = {
                                       _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_float, _P, _P, _P]),
     "pl_conv2d_planes_fwd": (_c.c_int, [_c.c_int, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P,
                                         _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_float, _P, _P]),
+    "pl_softargmax3d_nhwc_bwd_ex": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _c.c_int,
+                                               _P, _P]),
+    "pl_colsum_planes": (_c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_int64, _P, _P, _P, _P]),
     "pl_deconv4x4s2_planes_fwd": (_c.c_int, [_c.c_int, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P,
                                              _c.c_int64, _c.c_int64, _P, _c.c_float, _P, _P]),
     "pl_conv2d_planes_wgrad": (_c.c_int, [_c.c_int, _P, _c.c_int64, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64,

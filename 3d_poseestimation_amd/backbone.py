@@ -222,7 +222,7 @@ class _HeatmapNet(nn.Module):
         """The same in the reference's layout [B, J*depth, 64, 64] (Model.py:91)."""
         return conv.nhwc_to_nchw(self.heatmap_logits_nhwc(x_nhwc))
 
-    def _heatmap_logits_train(self, x_nhwc, nhwc=False):
+    def _heatmap_logits_train(self, x_nhwc, nhwc=False, final_link=None):
         """Training mode, differentiable: [B, H, W, 3] -> [B, J*depth, H/4, W/4] (NCHW for the soft-argmax), or the
         NHWC logits as the final convolution writes them (nhwc=True: the depth-64 head reads them in place)."""
         if self.compute_dtype in ("f16x3", "bf16p"):
@@ -233,7 +233,7 @@ class _HeatmapNet(nn.Module):
             for i in (0, 3, 6):
                 B, H, W, cin = out.shape
                 cout = self.deconv_layers[i].weight.shape[1]
-                last = i == 6
+                last = i == 6 and final_link is None      # (final_link: the final convolution reads planes as well)
                 if outp is not None and conv.planes_deconv_supported(B, H, W, cin, cout):
                     lk = conv.PlaneLink(mode)
                     z = conv.deconv4x4s2_planes(outp, self.deconv_layers[i].weight, lk)
@@ -246,6 +246,13 @@ class _HeatmapNet(nn.Module):
                         conv.deconv4x4s2_nhwc_autograd(out, self.deconv_layers[i].weight, "bf16x6" if mode == conv._lib.PL_F16X3 else "bf16"),
                         self.deconv_layers[i + 1], True)
                     outp = None
+            if final_link is not None and outp is not None:
+                final_link.mode = mode
+                return conv.conv1x1_bias_planes(outp, self.final_layer.weight, self.final_layer.bias, final_link)
+            if final_link is not None:
+                final_link.mode = None                   # (told the caller: the logits' gradient is wanted in fp32)
+            if outp is not None:
+                raise RuntimeError("deconvolution head: planes-only activation in front of the plain final convolution")
             out = conv.conv2d_bias_nhwc_autograd(out, conv.to_ohwi(self.final_layer.weight.float()), self.final_layer.bias,
                                                  arith=self.compute_dtype)
             return out if nhwc else conv.nhwc_to_nchw_autograd(out)
@@ -264,6 +271,11 @@ class _HeatmapNet(nn.Module):
         the same frames; their reference forwards disagree about the input layout, this entry point does not)."""
         if self.training:
             if self.depth_dim == 64:
+                if self.compute_dtype in ("f16x3", "bf16p"):
+                    # the final convolution on the planes GEMM: its gradient arrives as planes written by the soft-argmax backward
+                    lk = conv.PlaneLink()
+                    logits = self._heatmap_logits_train(x_nhwc, nhwc=True, final_link=lk)
+                    return soft_argmax_3d_nhwc(logits, self.num_joints, lk if lk.mode is not None else None)
                 return soft_argmax_3d_nhwc(self._heatmap_logits_train(x_nhwc, nhwc=True), self.num_joints)
             logits = self._heatmap_logits_train(x_nhwc)
             return (soft_argmax_3d(logits, self.num_joints, self.depth_dim) if self.depth_dim > 1
@@ -283,7 +295,7 @@ class Model_3D(_HeatmapNet):
     def forward(self, x):
         """x [B, 256, 256, 3] NHWC frames -> [B, 51] (x, y, z) per joint in (-1, 1)  (Model.py:83-137)."""
         if self.training:
-            return soft_argmax_3d_nhwc(self._heatmap_logits_train(x, nhwc=True), self.num_joints)
+            return self.predict_nhwc(x)
         with torch.no_grad():
             return soft_argmax_3d_nhwc(self.heatmap_logits_nhwc(x), self.num_joints)
 

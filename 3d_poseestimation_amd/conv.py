@@ -773,3 +773,57 @@ def deconv4x4s2_planes(xp, weight_iohw, link):
 def planes_deconv_supported(B, H, W, cin, cout):
     return (cin % 32 == 0 and cout % 32 == 0 and (B * H * W) % 32 == 0 and
             max(B * H * W * cin, B * 4 * H * W * cout) * 4 < (1 << 31))
+
+
+class _ConvBiasPlanesFn(torch.autograd.Function):
+    """The head's final 1x1 convolution with bias (Model.py:66-69) on the planes GEMM: xp carrier [rows][Cin], w [Cout][Cin],
+    bias [Cout] -> logits [rows][Cout] fp32.  backward takes dlogits as a carrier written by the soft-argmax backward
+    (heads.py, PlaneLink): data gradient NT on W^T, weight gradient TN over the pixels, bias gradient = column sums of the
+    planes."""
+
+    @staticmethod
+    def forward(ctx, xp, w, bias, link):
+        rows, cin = xp.shape
+        cout = w.shape[0]
+        mode = link.mode
+        wp = _planes_of(w, WEIGHT_PLANE_SCALE, mode)
+        L = _lib.lib()
+        y = torch.empty(rows, cout, device=xp.device)
+        with torch.cuda.device(xp.device):
+            rc = L.pl_gemm_planes_raw(0, mode, xp.data_ptr(), rows * cin, cin, wp.data_ptr(), cout * cin, cin, y.data_ptr(), rows,
+                                      cout, cin, bias.data_ptr(), 1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), None, None,
+                                      _lib.current_stream_ptr())
+        _lib.check(rc, "pl_gemm_planes_raw")
+        ctx.save_for_backward(xp, w)
+        ctx.link = link
+        return y
+
+    @staticmethod
+    def backward(ctx, dyp):
+        xp, w = ctx.saved_tensors
+        rows, cin = xp.shape
+        cout = w.shape[0]
+        dyp = dyp.contiguous()
+        inv, mode = ctx.link.dz_scale[1:], ctx.link.mode
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wtp = _planes_of(w.t(), WEIGHT_PLANE_SCALE, mode)
+            dx = _gemm_planes_raw(0, dyp, (rows, cout), wtp, (cin, cout), rows, cin, cout, 1.0 / WEIGHT_PLANE_SCALE, inv, mode)
+        if ctx.needs_input_grad[1]:
+            dw = _gemm_planes_raw(2, dyp, (rows, cout), xp, (rows, cin), cout, cin, rows, 1.0 / ACT_PLANE_SCALE, inv, mode)
+        if ctx.needs_input_grad[2]:
+            L = _lib.lib()
+            db = torch.empty(cout, device=dyp.device)
+            scratch = torch.empty(L.pl_colsum_scratch_bytes(rows, cout), dtype=torch.uint8, device=dyp.device)
+            with torch.cuda.device(dyp.device):
+                rc = L.pl_colsum_planes(dyp.data_ptr(), mode, rows, cout, inv.data_ptr(), db.data_ptr(), scratch.data_ptr(),
+                                        _lib.current_stream_ptr())
+            _lib.check(rc, "pl_colsum_planes")
+        return dx, dw, db, None
+
+
+def conv1x1_bias_planes(xp, weight_oihw, bias, link):
+    shape = xp.shape
+    cout, cin = weight_oihw.shape[0], weight_oihw.shape[1]
+    y = _ConvBiasPlanesFn.apply(xp.reshape(-1, cin), weight_oihw.float().reshape(cout, cin), bias.float(), link)
+    return y.reshape(*shape[:-1], cout)

@@ -16,6 +16,7 @@
 //   pl_nhwc_to_nchw          layout pass for callers that want [B][J*D][H][W] (Model_2D's head)
 //   pl_colsum, pl_upsample2x_zero_nhwc   bias gradient; placement of a 1x1 stride-2 convolution's input gradient
 #include "pl_internal.h"
+#include "plane_store.h"
 
 namespace pl {
 namespace {
@@ -200,6 +201,31 @@ __global__ __launch_bounds__(NTHR) void colsum_wide_kernel(const float* __restri
   if (active)
     for (int r = blockIdx.y * 4 + wave; r < rows; r += gridDim.y * 4) {
       const float4 v = *reinterpret_cast<const float4*>(X + (size_t)r * cols + c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  sm[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && active) {
+    float4 t = sm[0][lane];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) { t.x += sm[w][lane].x; t.y += sm[w][lane].y; t.z += sm[w][lane].z; t.w += sm[w][lane].w; }
+    *reinterpret_cast<float4*>(part + (size_t)blockIdx.y * cols + c) = t;
+  }
+}
+
+// the same over a tensor that exists only as operand planes (the conv head's dlogits): x = (h + l / 2048) * inv[0]
+__global__ __launch_bounds__(NTHR) void colsum_wide_planes_kernel(const unsigned short* __restrict__ h, const unsigned short* __restrict__ l,
+                                                                  int kind, const float* __restrict__ inv, int rows, int cols,
+                                                                  float* __restrict__ part) {
+  __shared__ float4 sm[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const bool active = c < cols;
+  const float iv = inv ? inv[0] : 1.0f;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (active)
+    for (int r = blockIdx.y * 4 + wave; r < rows; r += gridDim.y * 4) {
+      const float4 v = load_planes4(kind, h, l, (size_t)r * cols + c, iv);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
   sm[wave][lane] = s;
@@ -822,6 +848,21 @@ extern "C" int pl_colsum(const float* X, int64_t rows, int64_t cols, float* out,
   }
   PL_TRY(launch_colsum_partial(X, (int)rows, (int)cols, static_cast<float*>(scratch), s));
   return launch_reduce_slabs(static_cast<const float*>(scratch), colsum_chunks((int)rows), cols, out, s);
+}
+
+// column sums of a [rows][cols] tensor given as operand planes (scratch: pl_colsum_scratch_bytes); cols % 4 == 0
+extern "C" int pl_colsum_planes(const void* planes, int planes_mode, int64_t rows, int64_t cols, const float* inv_scale,
+                                float* out, void* scratch, void* stream) {
+  if (!planes || !out || !scratch) PL_FAIL(PL_EINVAL, "pl_colsum_planes: null pointer");
+  if (rows <= 0 || rows > INT32_MAX || cols <= 0 || cols > INT32_MAX || (cols & 3)) PL_FAIL(PL_ESHAPE, "pl_colsum_planes: rows=%lld cols=%lld", (long long)rows, (long long)cols);
+  PlaneOut po;
+  PL_TRY(plane_out_of(planes_mode, const_cast<void*>(planes), rows * cols, 1.0f, nullptr, &po, "pl_colsum_planes"));
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = colsum_wide_chunks(rows);
+  hipLaunchKernelGGL(colsum_wide_planes_kernel, dim3((unsigned)((cols + 255) / 256), rc), dim3(NTHR), 0, s, po.h, po.l, po.kind,
+                     planes_mode == PL_F16X3 ? inv_scale : nullptr, (int)rows, (int)cols, static_cast<float*>(scratch));
+  PL_CHECK_LAUNCH("colsum_wide_planes");
+  return launch_reduce_slabs(static_cast<const float*>(scratch), rc, cols, out, s);
 }
 
 extern "C" int pl_upsample2x_zero_nhwc(const float* x, int64_t B, int64_t Hi, int64_t Wi, int64_t C, float* y,

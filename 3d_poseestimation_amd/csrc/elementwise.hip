@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "pl_internal.h"
+#include "plane_store.h"
 
 namespace pl {
 namespace {
@@ -25,34 +26,6 @@ __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<floa
 
 // ---- GEMM operand planes written by the kernel that produces the tensor (pl_internal.h PlaneOut) ----------
 // Four consecutive elements per lane: one 8-byte store per plane (512 B per wave instruction).
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-struct PlaneDst { unsigned short* h; unsigned short* l; float scale; int kind; };
-
-__device__ __forceinline__ PlaneDst plane_dst(const PlaneOut& o) {
-  PlaneDst d = {o.h, o.l, o.scale, o.kind};
-  if (o.kind == 2 && o.dyn) d.scale = o.dyn[0];
-  return d;
-}
-
-__device__ __forceinline__ void store_planes4(const PlaneDst& d, size_t off, float4 v) {
-  if (d.kind == 2) {
-    const float a[4] = {v.x * d.scale, v.y * d.scale, v.z * d.scale, v.w * d.scale};
-    f16x4 hh, ll;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      hh[j] = (_Float16)a[j];
-      ll[j] = (_Float16)((a[j] - (float)hh[j]) * 2048.0f);
-    }
-    *reinterpret_cast<f16x4*>(d.h + off) = hh;
-    *reinterpret_cast<f16x4*>(d.l + off) = ll;
-  } else if (d.kind == 1) {
-    bf16x4 q;
-    q[0] = (__bf16)v.x; q[1] = (__bf16)v.y; q[2] = (__bf16)v.z; q[3] = (__bf16)v.w;
-    *reinterpret_cast<bf16x4*>(d.h + off) = q;
-  }
-}
-
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, int64_t n4, PlaneOut o) {
   const PlaneDst d = plane_dst(o);
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1424,7 +1397,7 @@ extern "C" size_t pl_bn_train_scratch_bytes(int64_t rows, int64_t C) {
 }
 
 // operand planes of a [n]-element tensor for the planes GEMM: mode PL_F16X3 -> [2][n] fp16 (h, l), PL_BF16 -> [n] bf16
-static int plane_out_of(int mode, void* planes, int64_t n, float scale, const float* dyn, PlaneOut* po, const char* who) {
+int pl::plane_out_of(int mode, void* planes, int64_t n, float scale, const float* dyn, PlaneOut* po, const char* who) {
   *po = PlaneOut{nullptr, nullptr, scale, dyn, 0};
   if (!planes) return PL_OK;
   if (mode != PL_F16X3 && mode != PL_BF16) PL_FAIL(PL_EDTYPE, "%s: planes want PL_F16X3 or PL_BF16 (mode %d)", who, mode);

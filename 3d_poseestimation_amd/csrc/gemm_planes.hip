@@ -327,7 +327,8 @@ bool planes_gemm_ok(GemmLayout layout, const PlanesGemmArgs& a) {
     if (pixels % ((int64_t)e.conv_ho * e.conv_wo)) return false;
     const int64_t xb = pixels / ((int64_t)e.conv_ho * e.conv_wo) * e.conv_h * e.conv_w * e.conv_cin * 2;
     const int npl_ = a.mode == plp::kF16x3 ? 2 : 1;
-    if (xb >= 0x7fffffe0ll || (int64_t)(npl_ - 1) * (layout == kNT ? a.a_plane : a.b_plane) * 2 + xb >= (1ll << 32)) return false;
+    if (xb >= 0x7fffffe0ll) return false;
+    (void)npl_;
     if (layout == kNT && ((e.conv_cin & 31) || e.K % e.conv_cin)) return false;
     if (e.scat_on && (layout != kNT || e.split_k > 1 || e.bias || e.addend || e.resid || e.col_scale || e.relu || e.stat_sum))
       return false;
@@ -343,8 +344,12 @@ bool planes_gemm_ok(GemmLayout layout, const PlanesGemmArgs& a) {
   if (((a.a_plane | a.b_plane) & 7) != 0) return false;
   const int npl = npl_of(a.mode);
   const bool a_ks = layout == kTN, b_ks = layout != kNT;
-  const int64_t a_ext = (int64_t)(npl - 1) * a.a_plane * 2 + (a_ks ? (int64_t)e.K * a.lda * 2 : (int64_t)128 * a.lda * 2 + (int64_t)e.K * 2);
-  const int64_t b_ext = (int64_t)(npl - 1) * a.b_plane * 2 + (b_ks ? (int64_t)e.K * a.ldb * 2 : (int64_t)128 * a.ldb * 2 + (int64_t)e.K * 2);
+  // byte offsets inside ONE plane and ONE K slice, from the tile origin (the 16x16x32 loop: plane stride and slice origin are
+  // in the descriptor's 64-bit base; the 32x32x16 loop adds the plane stride to the 32-bit scalar offset)
+  const int64_t ks = e.K / splits;
+  const int64_t pa = mfma16_shape() ? 0 : (int64_t)(npl - 1) * a.a_plane * 2, pb = mfma16_shape() ? 0 : (int64_t)(npl - 1) * a.b_plane * 2;
+  const int64_t a_ext = pa + (a_ks ? ks * a.lda * 2 : (int64_t)128 * a.lda * 2 + ks * 2);
+  const int64_t b_ext = pb + (b_ks ? ks * a.ldb * 2 : (int64_t)128 * a.ldb * 2 + ks * 2);
   if (a_ext >= (1ll << 31) || b_ext >= (1ll << 31)) return false;
   if ((e.stat_sum != nullptr) != (e.stat_m2 != nullptr)) return false;
   if ((e.col_scale != nullptr) != (e.col_shift != nullptr)) return false;

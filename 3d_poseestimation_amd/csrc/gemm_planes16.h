@@ -138,11 +138,15 @@ __device__ __forceinline__ bool planes_mainloop16(const PlanesArgs& p, const int
 
   const __bf16* ta = A_KS ? p.A + (size_t)kbeg * p.lda + m0 : p.A + (size_t)m0 * p.lda + kbeg;
   const __bf16* tb = B_KS ? p.B + (size_t)kbeg * p.ldb + n0 : p.B + (size_t)n0 * p.ldb + kbeg;
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(ta), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(tb), 0, 0x7fffffff, 0x00020000);
+  // one descriptor per plane (64-bit plane stride in the base: a plane of the conv head's 4.5 GB gradient is 2.3 GB away)
+  __amdgpu_buffer_rsrc_t ra[NPL], rb[NPL];
+#pragma unroll
+  for (int pl = 0; pl < NPL; ++pl) {
+    ra[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(ta + (size_t)pl * p.a_plane), 0, 0x7fffffff, 0x00020000);
+    rb[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(tb + (size_t)pl * p.b_plane), 0, 0x7fffffff, 0x00020000);
+  }
   const int ga_step = A_KS ? 32 * p.lda * 2 : 64;
   const int gb_step = B_KS ? 32 * p.ldb * 2 : 64;
-  const int apl = (int)(p.a_plane * 2), bpl = (int)(p.b_plane * 2);
   auto barrier = [&]() {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -160,8 +164,11 @@ __device__ __forceinline__ bool planes_mainloop16(const PlanesArgs& p, const int
       ob[j] = (int)glds_lane_off16<B_KS>(lw + 4 * j, lane, p.ldb, EDGE ? p.N - n0 : 0x7fffffff);
     }
     // ---- convolution gathers: descriptors on the whole tensor, offsets rebuilt per K tile by the (otherwise idle) loader VALU
-    const __amdgpu_buffer_rsrc_t rx =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(CONV == 2 ? p.B : p.A), 0, 0x7fffffe0, 0x00020000);
+    __amdgpu_buffer_rsrc_t rx[NPL];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+      rx[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(CONV == 2 ? p.B + (size_t)pl * p.b_plane : p.A + (size_t)pl * p.a_plane),
+                                                 0, 0x7fffffe0, 0x00020000);
     int cih0[2] = {0, 0}, ciw0[2] = {0, 0}, cbase[2] = {0, 0};      // CONV 1: per DMA row of this lane
     int ctap = 0, cc0 = 0, ckh = 0, ckw = 0;                        // CONV 1: filter tap / channel offset of the next tile issued
     int wkh = 0, wkw = 0, wcol = 0;                                 // CONV 2: this lane's column chunk: tap and channel (fixed)
@@ -217,10 +224,10 @@ __device__ __forceinline__ bool planes_mainloop16(const PlanesArgs& p, const int
       for (int pl = 0; pl < NPL; ++pl)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          if (CONV == 1) PLP_BLDS16(rx, d + pl * Cf::OPP + j * 4096, va[j], pl * apl);
-          else PLP_BLDS16(ra, d + pl * Cf::OPP + j * 4096, va[j], sa + pl * apl);
-          if (CONV == 2) PLP_BLDS16(rx, d + (NPL + pl) * Cf::OPP + j * 4096, vb[j], pl * bpl);
-          else PLP_BLDS16(rb, d + (NPL + pl) * Cf::OPP + j * 4096, vb[j], sb + pl * bpl);
+          if (CONV == 1) PLP_BLDS16(rx[pl], d + pl * Cf::OPP + j * 4096, va[j], 0);
+          else PLP_BLDS16(ra[pl], d + pl * Cf::OPP + j * 4096, va[j], sa);
+          if (CONV == 2) PLP_BLDS16(rx[pl], d + (NPL + pl) * Cf::OPP + j * 4096, vb[j], 0);
+          else PLP_BLDS16(rb[pl], d + (NPL + pl) * Cf::OPP + j * 4096, vb[j], sb);
         }
     };
     issue(0, st[0]);

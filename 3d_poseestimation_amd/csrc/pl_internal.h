@@ -122,6 +122,8 @@ int launch_gemm_planes(GemmLayout layout, const PlanesGemmArgs& a, hipStream_t s
 int launch_gemm_planes_pair(const PlanesGemmArgs& nn, const PlanesGemmArgs& tn, hipStream_t s);
 // x [n] fp32 -> planes (static scale); n % 4 == 0, 16-byte aligned
 int launch_split_planes(const float* x, int64_t n, const PlaneOut& out, hipStream_t s);
+// PlaneOut of a caller's planes buffer ([2][n] fp16 for PL_F16X3, [n] bf16 for PL_BF16; NULL -> kind 0)
+int plane_out_of(int mode, void* planes, int64_t n, float scale, const float* dyn, PlaneOut* po, const char* who);
 
 int launch_gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t s);
 // M <= thin_gemm_max_m() rows (NT, NN): the contraction split over the chip, exact fp32 MFMA, slabs + one reduce/epilogue

@@ -10,6 +10,7 @@
 //   backward: read logits, write dlogits       dl = p * sum_a g_a * c_a * (idx_a - E_a)
 // HBM-bound: 4 B read per voxel forward, 4 B read + 4 B written backward.
 #include "pl_internal.h"
+#include "plane_store.h"
 
 namespace pl {
 namespace {
@@ -181,9 +182,11 @@ __global__ __launch_bounds__(NTHR) void softargmax_bwd_kernel(const float* __res
 __global__ __launch_bounds__(NTHR) void softargmax_nhwc_bwd_kernel(const float* __restrict__ logits,
                                                                    const float* __restrict__ stats,
                                                                    const float* __restrict__ gcoords, int J, int H,
-                                                                   int W, int64_t n4, float* __restrict__ dlogits) {
+                                                                   int W, int64_t n4, float* __restrict__ dlogits,
+                                                                   PlaneOut po) {
   const int64_t t = (int64_t)blockIdx.x * NTHR + threadIdx.x;
   if (t >= n4) return;
+  const PlaneDst pd = plane_dst(po);
   const int c4 = J * 16;                           // float4s per pixel
   const int q = (int)(t % c4);
   const int64_t bp = t / c4;
@@ -203,7 +206,8 @@ __global__ __launch_bounds__(NTHR) void softargmax_nhwc_bwd_kernel(const float* 
   o.y = __expf(v.y - m) * inv * fmaf(gz, z0 + 1.f, base);
   o.z = __expf(v.z - m) * inv * fmaf(gz, z0 + 2.f, base);
   o.w = __expf(v.w - m) * inv * fmaf(gz, z0 + 3.f, base);
-  reinterpret_cast<float4*>(dlogits)[t] = o;
+  if (dlogits) reinterpret_cast<float4*>(dlogits)[t] = o;
+  if (pd.kind) store_planes4(pd, (size_t)t * 4, o);        // the final convolution's gradient GEMMs read planes
 }
 
 int check_dims(int64_t BJ, int64_t D, int64_t H, int64_t W, int ncoord, const char* who) {
@@ -262,15 +266,29 @@ extern "C" int pl_softargmax3d_nhwc_fwd(const float* logits, int64_t B, int64_t 
 
 extern "C" int pl_softargmax3d_nhwc_bwd(const float* logits, const float* stats, const float* gcoords, int64_t B,
                                         int64_t J, int64_t H, int64_t W, float* dlogits, void* stream) {
-  if (!logits || !stats || !gcoords || !dlogits) PL_FAIL(PL_EINVAL, "pl_softargmax3d_nhwc_bwd: null pointer");
+  if (!dlogits) PL_FAIL(PL_EINVAL, "pl_softargmax3d_nhwc_bwd: null pointer");
+  return pl_softargmax3d_nhwc_bwd_ex(logits, stats, gcoords, B, J, H, W, dlogits, nullptr, 0, nullptr, stream);
+}
+
+// + dl_planes (optional): dlogits also / only (dlogits == NULL) as operand planes for the final convolution's gradient
+// GEMMs.  PL_F16X3: the planes hold dl_scale[0] * dlogits -- dl_scale = {S, 1/S} on the device, S a power of two the
+// CALLER derives from the bound |dlogit| <= 2 max_(b,j) sum_c |g_c| (softmax weights <= 1, index offsets < the map size).
+extern "C" int pl_softargmax3d_nhwc_bwd_ex(const float* logits, const float* stats, const float* gcoords, int64_t B,
+                                           int64_t J, int64_t H, int64_t W, float* dlogits, void* dl_planes, int planes_mode,
+                                           const float* dl_scale, void* stream) {
+  if (!logits || !stats || !gcoords || (!dlogits && !dl_planes)) PL_FAIL(PL_EINVAL, "pl_softargmax3d_nhwc_bwd: null pointer");
   if ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15)
     PL_FAIL(PL_EINVAL, "pl_softargmax3d_nhwc_bwd: tensors not 16-byte aligned");
   if (B <= 0 || J <= 0 || H <= 0 || W <= 0 || B * J > 0x7fffffff || H * W > (1 << 24))
     PL_FAIL(PL_ESHAPE, "pl_softargmax3d_nhwc_bwd: bad dims");
   const int64_t n4 = B * H * W * J * 16;
   if (n4 > (int64_t)INT32_MAX * NTHR) PL_FAIL(PL_ESHAPE, "pl_softargmax3d_nhwc_bwd: too large");
+  if (dl_planes && planes_mode == PL_F16X3 && !dl_scale) PL_FAIL(PL_EINVAL, "pl_softargmax3d_nhwc_bwd_ex: fp16 planes need dl_scale");
+  PlaneOut po;
+  PL_TRY(plane_out_of(planes_mode, dl_planes, n4 * 4, 1.0f, planes_mode == PL_F16X3 ? dl_scale : nullptr, &po,
+                      "pl_softargmax3d_nhwc_bwd_ex"));
   hipLaunchKernelGGL(softargmax_nhwc_bwd_kernel, dim3((unsigned)((n4 + NTHR - 1) / NTHR)), dim3(NTHR), 0,
-                     (hipStream_t)stream, logits, stats, gcoords, (int)J, (int)H, (int)W, n4, dlogits);
+                     (hipStream_t)stream, logits, stats, gcoords, (int)J, (int)H, (int)W, n4, dlogits, po);
   PL_CHECK_LAUNCH("softargmax_nhwc_bwd");
   return PL_OK;
 }

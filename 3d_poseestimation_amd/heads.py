@@ -55,9 +55,20 @@ def soft_argmax_2d(out, num_joints=17):
     return _SoftArgmaxFn.apply(x, B * num_joints, 1, H, W, 2, 0).reshape(B, num_joints * 2)
 
 
+def _pow2_scale_for_bound(bound):
+    """{S, 1/S} on the device: S the power of two that maps `bound` (a 0-d device tensor >= max |value|) into [2^13, 2^14)
+    -- the range scale of fp16 operand planes (conv.py PlaneLink); bound 0 / inf / nan -> 1."""
+    ok = torch.isfinite(bound) & (bound > 0)
+    e = torch.frexp(torch.where(ok, bound, torch.ones_like(bound))).exponent
+    S = torch.ldexp(torch.ones_like(bound), 14 - e)
+    S = torch.where(ok, S, torch.ones_like(bound))
+    return torch.stack([S, 1.0 / S]).float().contiguous()
+
+
 class _SoftArgmax3dNHWCFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, num_joints):
+    def forward(ctx, x, num_joints, link=None):
+        ctx.link = link
         B, H, W, _ = x.shape
         coords = torch.empty(B * num_joints, 3, dtype=torch.float32, device=x.device)
         stats = torch.empty(B * num_joints, 5, dtype=torch.float32, device=x.device)
@@ -75,14 +86,25 @@ class _SoftArgmax3dNHWCFn(torch.autograd.Function):
         B, H, W, _ = x.shape
         g = g.contiguous()
         dl = torch.empty_like(x)
+        link = ctx.link
+        if link is not None:
+            # the final convolution runs on the planes GEMM (conv.py): dlogits leave as a carrier of their planes, fp16 ones
+            # scaled by a power of two from the bound |dlogit| <= 2 max_(b,j) sum_c |g_c| (softmax weights <= 1)
+            link.dz_scale = _pow2_scale_for_bound(2.0 * g.reshape(-1, 3).abs().sum(1).max())
+            with torch.cuda.device(x.device):
+                rc = _lib.lib().pl_softargmax3d_nhwc_bwd_ex(x.data_ptr(), stats.data_ptr(), g.data_ptr(), B, ctx.num_joints, H, W,
+                                                            None, dl.data_ptr(), link.mode, link.dz_scale.data_ptr(),
+                                                            _lib.current_stream_ptr())
+            _lib.check(rc, "pl_softargmax3d_nhwc_bwd_ex")
+            return dl, None, None
         with torch.cuda.device(x.device):
             rc = _lib.lib().pl_softargmax3d_nhwc_bwd(x.data_ptr(), stats.data_ptr(), g.data_ptr(), B, ctx.num_joints,
                                                      H, W, dl.data_ptr(), _lib.current_stream_ptr())
         _lib.check(rc, "pl_softargmax3d_nhwc_bwd")
-        return dl, None
+        return dl, None, None
 
 
-def soft_argmax_3d_nhwc(out, num_joints=17):
+def soft_argmax_3d_nhwc(out, num_joints=17, link=None):
     """(B, H, W, num_joints*64) NHWC logits (depth_dim 64) -> (B, num_joints*3), differentiable: what Model_3D's
     final 1x1 convolution writes, read in place -- no NHWC <-> NCHW pass in either direction."""
     x = out.contiguous()
@@ -90,4 +112,4 @@ def soft_argmax_3d_nhwc(out, num_joints=17):
     B, H, W, C = x.shape
     if C != num_joints * 64:
         raise ValueError(f"expected {num_joints * 64} channels (depth 64), got {C}")
-    return _SoftArgmax3dNHWCFn.apply(x, num_joints).reshape(B, num_joints * 3)
+    return _SoftArgmax3dNHWCFn.apply(x, num_joints, link).reshape(B, num_joints * 3)

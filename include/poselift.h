@@ -445,6 +445,14 @@ int pl_gemm_planes_splits(int64_t M, int64_t N, int64_t K);
 int pl_conv2d_planes_fwd(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W, int64_t Cin,
                          const void* w_planes, int64_t w_plane, int64_t Cout, int KH, int KW, int stride, int pad,
                          float* y, float out_scale, const float* dyn_inv, void* stream);
+/* The head's last link on planes: the 3-D soft-argmax backward writing dlogits (4.5 GB at B = 256) as operand planes for the
+ * final 1x1 convolution's gradient GEMMs (dlogits may be NULL), and the bias gradient as column sums of those planes.
+ * PL_F16X3: dl_scale = {S, 1/S} on the device, S a power of two the caller derives from |dlogit| <= 2 max sum_c |g_c|. */
+int pl_softargmax3d_nhwc_bwd_ex(const float* logits, const float* stats, const float* gcoords, int64_t B, int64_t J,
+                                int64_t H, int64_t W, float* dlogits, void* dl_planes, int planes_mode,
+                                const float* dl_scale, void* stream);
+int pl_colsum_planes(const void* planes, int planes_mode, int64_t rows, int64_t cols, const float* inv_scale, float* out,
+                     void* scratch, void* stream);
 /* nn.ConvTranspose2d(4, 2, 1, bias=False) forward the same way (Model.py:47-63): four 2x2-tap gathers at the input
  * resolution, one per output parity, stored straight into y [B][2H][2W][Cout]; wsub_planes = planes of
  * conv.deconv_subkernels(weight) [4][Cout][2][2][Cin].  Its data gradient is pl_conv2d_planes_fwd (4x4, stride 2, pad 1)
