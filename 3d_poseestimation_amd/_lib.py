@@ -119,7 +119,8 @@ SIGNATURES = {
     "pl_mask_by_bits": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P]),
     "pl_planes_split": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_float, _P, _P]),
     "pl_bn_train_fwd_ex": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _c.c_float, _c.c_float, _P, _P, _P, _c.c_int,
-                                      _P, _P, _P, _P, _P, _P, _c.c_int, _P]),
+                                      _P, _P, _P, _P, _P, _P, _c.c_int, _P, _P]),
+    "pl_gemm_stat_groups": (_c.c_int, [_c.c_int64]),
     "pl_bn_train_bwd_ex": (_c.c_int, [_P, _P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _P, _P, _P, _P, _P, _c.c_int, _P, _P]),
     "pl_add_relu_fwd_ex": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_int, _P]),
     "pl_mask_add_by_bits": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _P, _P]),
@@ -149,9 +150,9 @@ SIGNATURES = {
                                   _c.c_float, _c.c_float, _P, _P]),
     "pl_gemm_planes_splits": (_c.c_int, [_c.c_int64, _c.c_int64, _c.c_int64]),
     "pl_gemm_planes_raw": (_c.c_int, [_c.c_int, _c.c_int, _P, _c.c_int64, _c.c_int64, _P, _c.c_int64, _c.c_int64, _P,
-                                      _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_float, _P, _P, _P]),
+                                      _c.c_int64, _c.c_int64, _c.c_int64, _P, _c.c_float, _P, _P, _P, _P]),
     "pl_conv2d_planes_fwd": (_c.c_int, [_c.c_int, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P,
-                                        _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_float, _P, _P]),
+                                        _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_float, _P, _P, _P]),
     "pl_softargmax3d_nhwc_bwd_ex": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _c.c_int,
                                                _P, _P]),
     "pl_colsum_planes": (_c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_int64, _P, _P, _P, _P]),

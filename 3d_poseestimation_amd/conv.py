@@ -439,10 +439,11 @@ WEIGHT_PLANE_SCALE = 16.0    # kWeightPlaneScale
 class PlaneLink:
     """Connects the BatchNorm behind a planes convolution to that convolution's backward: the BatchNorm backward writes
     dz as planes (fp16, scaled by a power of two chosen on the device) and leaves {S, 1/S} here for the two GEMMs."""
-    __slots__ = ("dz_scale", "mode")
+    __slots__ = ("dz_scale", "mode", "stat")
 
     def __init__(self, mode=_lib.PL_F16X3):
         self.dz_scale = None
+        self.stat = None          # forward: the convolution's epilogue statistics [2][groups][C] for the BatchNorm behind it
         self.mode = mode          # PL_F16X3: two fp16 planes (fp32-grade); PL_BF16: one bf16 plane (bf16 STORAGE of the operands)
 
 
@@ -458,7 +459,12 @@ def _planes_of(t, scale, mode=_lib.PL_F16X3):
     return out
 
 
-def _gemm_planes_raw(layout, a, a_rows_cols, b, b_rows_cols, M, N, K, out_scale, dyn_inv=None, mode=_lib.PL_F16X3):
+def _stat_buffer(rows, cols, dev):
+    """[2][groups][cols]: what a GEMM epilogue writes as training-mode BatchNorm partial statistics of its output."""
+    return torch.empty(2, _lib.lib().pl_gemm_stat_groups(rows), cols, device=dev)
+
+
+def _gemm_planes_raw(layout, a, a_rows_cols, b, b_rows_cols, M, N, K, out_scale, dyn_inv=None, mode=_lib.PL_F16X3, stat=None):
     """C [M][N] fp32 from two carriers (planes of row-major matrices a_rows_cols / b_rows_cols)."""
     L = _lib.lib()
     dev = a.device
@@ -469,7 +475,8 @@ def _gemm_planes_raw(layout, a, a_rows_cols, b, b_rows_cols, M, N, K, out_scale,
         rc = L.pl_gemm_planes_raw(layout, mode, a.data_ptr(), a_rows_cols[0] * a_rows_cols[1], a_rows_cols[1],
                                   b.data_ptr(), b_rows_cols[0] * b_rows_cols[1], b_rows_cols[1], C.data_ptr(), M, N, K,
                                   None, float(out_scale), dyn_inv.data_ptr() if dyn_inv is not None else None,
-                                  slabs.data_ptr() if slabs is not None else None, _lib.current_stream_ptr())
+                                  slabs.data_ptr() if slabs is not None else None,
+                                  stat.data_ptr() if stat is not None else None, _lib.current_stream_ptr())
     _lib.check(rc, "pl_gemm_planes_raw")
     return C
 
@@ -489,14 +496,18 @@ class _Conv1x1PlanesFn(torch.autograd.Function):
         rows, cin = xp.shape
         cout = w.shape[0]
         wp = _planes_of(w, WEIGHT_PLANE_SCALE, link.mode)
+        # the BatchNorm behind this convolution reads the epilogue's statistics (no pass over z) -- unless the GEMM is split over K
+        stat = (_stat_buffer(rows, cout, xp.device) if _lib.lib().pl_gemm_planes_splits(rows, cout, cin) == 1
+                else torch.empty(0, device=xp.device))
         z = _gemm_planes_raw(0, xp, (rows, cin), wp, (cout, cin), rows, cout, cin,
-                             1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), None, link.mode)
+                             1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), None, link.mode, stat if stat.numel() else None)
         ctx.save_for_backward(xp, w)
         ctx.link = link
-        return z
+        ctx.mark_non_differentiable(stat)
+        return z, stat
 
     @staticmethod
-    def backward(ctx, dzp):
+    def backward(ctx, dzp, _gstat):
         xp, w = ctx.saved_tensors
         rows, cin = xp.shape
         cout = w.shape[0]
@@ -515,7 +526,8 @@ def conv1x1_planes(xp, weight_oihw, link):
     """xp: carrier [B, H, W, Cin] of the input's planes; weight: the nn.Conv2d parameter [Cout][Cin][1][1]."""
     shape = xp.shape
     cout, cin = weight_oihw.shape[0], weight_oihw.shape[1]
-    z = _Conv1x1PlanesFn.apply(xp.reshape(-1, cin), weight_oihw.float().reshape(cout, cin), link)
+    z, stat = _Conv1x1PlanesFn.apply(xp.reshape(-1, cin), weight_oihw.float().reshape(cout, cin), link)
+    link.stat = stat if stat.numel() else None
     return z.reshape(*shape[:-1], cout)
 
 
@@ -539,12 +551,15 @@ class _BNPlanesFn(torch.autograd.Function):
         bits = torch.empty(rows, 4 * ((C + 255) // 256), dtype=torch.int64, device=dev)
         mean, rstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
         scratch = torch.empty(L.pl_bn_train_scratch_bytes(rows, C), dtype=torch.uint8, device=dev)
+        gstat = link.stat if link is not None else None
+        if link is not None:
+            link.stat = None
         with torch.cuda.device(dev):
             rc = L.pl_bn_train_fwd_ex(z2.data_ptr(), rows, C, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
                                       running_mean.data_ptr(), running_var.data_ptr(), batches.data_ptr(), int(relu),
                                       None if out_planes else y.data_ptr(), bits.data_ptr(), mean.data_ptr(),
                                       rstd.data_ptr(), scratch.data_ptr(), y.data_ptr() if out_planes else None,
-                                      mode, _lib.current_stream_ptr())
+                                      mode, gstat.data_ptr() if gstat is not None else None, _lib.current_stream_ptr())
         _lib.check(rc, "pl_bn_train_fwd_ex")
         ctx.save_for_backward(z2, bits, mean, rstd, gamma)
         ctx.shape, ctx.link = shape, link
@@ -640,7 +655,7 @@ def to_planes(x, mode=_lib.PL_F16X3):
     return _ToPlanesFn.apply(x, mode)
 
 
-def _conv_planes_fwd(xp, x_shape, wp, w_shape, stride, pad, out_scale, dyn_inv=None, mode=_lib.PL_F16X3):
+def _conv_planes_fwd(xp, x_shape, wp, w_shape, stride, pad, out_scale, dyn_inv=None, mode=_lib.PL_F16X3, stat=None):
     """pl_conv2d_planes_fwd on carriers: xp planes of x [B][H][W][Cin], wp planes of the OHWI kernel w_shape."""
     B, H, W, cin = x_shape
     cout, kh, kw, _ = w_shape
@@ -649,7 +664,8 @@ def _conv_planes_fwd(xp, x_shape, wp, w_shape, stride, pad, out_scale, dyn_inv=N
     with torch.cuda.device(xp.device):
         rc = _lib.lib().pl_conv2d_planes_fwd(mode, xp.data_ptr(), B * H * W * cin, B, H, W, cin, wp.data_ptr(),
                                              cout * kh * kw * cin, cout, kh, kw, stride, pad, y.data_ptr(), float(out_scale),
-                                             dyn_inv.data_ptr() if dyn_inv is not None else None, _lib.current_stream_ptr())
+                                             dyn_inv.data_ptr() if dyn_inv is not None else None,
+                                             stat.data_ptr() if stat is not None else None, _lib.current_stream_ptr())
     _lib.check(rc, "pl_conv2d_planes_fwd")
     return y
 
@@ -664,13 +680,19 @@ class _ConvKxKPlanesFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xp, w, stride, pad, link):
         wp = _planes_of(w, WEIGHT_PLANE_SCALE, link.mode)
-        z = _conv_planes_fwd(xp, xp.shape, wp, w.shape, stride, pad, 1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), None, link.mode)
+        B, H, W, _ = xp.shape
+        cout, kh, kw, _ = w.shape
+        rows = B * ((H + 2 * pad - kh) // stride + 1) * ((W + 2 * pad - kw) // stride + 1)
+        stat = _stat_buffer(rows, cout, xp.device)
+        z = _conv_planes_fwd(xp, xp.shape, wp, w.shape, stride, pad, 1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), None, link.mode,
+                             stat)
         ctx.save_for_backward(xp, w)
         ctx.geom, ctx.link = (stride, pad), link
-        return z
+        ctx.mark_non_differentiable(stat)
+        return z, stat
 
     @staticmethod
-    def backward(ctx, dzp):
+    def backward(ctx, dzp, _gstat):
         xp, w = ctx.saved_tensors
         stride, pad = ctx.geom
         B, H, W, cin = xp.shape
@@ -709,7 +731,9 @@ class _ConvKxKPlanesFn(torch.autograd.Function):
 
 def conv_planes(xp, weight_oihw, stride, pad, link):
     """xp: carrier [B, H, W, Cin]; weight: the nn.Conv2d parameter [Cout][Cin][KH][KW]."""
-    return _ConvKxKPlanesFn.apply(xp, to_ohwi(weight_oihw.float()), stride, pad, link)
+    z, stat = _ConvKxKPlanesFn.apply(xp, to_ohwi(weight_oihw.float()), stride, pad, link)
+    link.stat = stat
+    return z
 
 
 def planes_convk_supported(B, H, W, cin, cout, k, stride, pad):
@@ -791,7 +815,7 @@ class _ConvBiasPlanesFn(torch.autograd.Function):
         y = torch.empty(rows, cout, device=xp.device)
         with torch.cuda.device(xp.device):
             rc = L.pl_gemm_planes_raw(0, mode, xp.data_ptr(), rows * cin, cin, wp.data_ptr(), cout * cin, cin, y.data_ptr(), rows,
-                                      cout, cin, bias.data_ptr(), 1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), None, None,
+                                      cout, cin, bias.data_ptr(), 1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), None, None, None,
                                       _lib.current_stream_ptr())
         _lib.check(rc, "pl_gemm_planes_raw")
         ctx.save_for_backward(xp, w)

@@ -791,7 +791,7 @@ extern "C" int pl_gemm_planes_splits(int64_t M, int64_t N, int64_t K) {
 
 extern "C" int pl_gemm_planes_raw(int layout, int mode, const void* A, int64_t a_plane, int64_t lda, const void* Bm,
                                   int64_t b_plane, int64_t ldb, float* C, int64_t M, int64_t N, int64_t K, const float* bias,
-                                  float out_scale, const float* dyn_inv, float* slabs, void* stream) {
+                                  float out_scale, const float* dyn_inv, float* slabs, float* stat, void* stream) {
   if (layout < 0 || layout > 2) PL_FAIL(PL_EINVAL, "pl_gemm_planes_raw: layout %d", layout);
   if (mode != PL_F16X3 && mode != PL_BF16) PL_FAIL(PL_EDTYPE, "pl_gemm_planes_raw: mode %d", mode);
   if (!A || !Bm || !C) PL_FAIL(PL_EINVAL, "pl_gemm_planes_raw: null pointer");
@@ -808,14 +808,17 @@ extern "C" int pl_gemm_planes_raw(int layout, int mode, const void* A, int64_t a
   const int splits = pl_gemm_planes_splits(M, N, K);
   if (splits > 1) {
     if (!slabs) PL_FAIL(PL_EWORKSPACE, "pl_gemm_planes_raw: %d K slices need slabs", splits);
-    if (bias) PL_FAIL(PL_EINVAL, "pl_gemm_planes_raw: no bias on a split-K problem");
+    if (bias || stat) PL_FAIL(PL_EINVAL, "pl_gemm_planes_raw: no bias / statistics on a split-K problem");
     g.e.C = slabs; g.e.split_k = splits;
     PL_TRY(launch_gemm_planes((GemmLayout)layout, g, s));
     return launch_reduce_slabs(slabs, splits, M * N, C, s);
   }
   g.e.C = C; g.e.split_k = 1; g.e.bias = bias;
+  if (stat) { g.e.stat_sum = stat; g.e.stat_m2 = stat + (size_t)gemm_stat_groups((int)M) * N; }
   return launch_gemm_planes((GemmLayout)layout, g, s);
 }
+
+extern "C" int pl_gemm_stat_groups(int64_t M) { return M > 0 && M <= INT32_MAX ? gemm_stat_groups((int)M) : 0; }
 
 // KxK convolutions on the planes GEMM with the input gathered by the loader waves (implicit GEMM, gemm_planes16.h)
 static int conv_planes_geom(GemmArgs& e, int64_t B, int64_t H, int64_t W, int64_t Cin, int KH, int KW, int stride, int pad,
@@ -832,7 +835,7 @@ static int conv_planes_geom(GemmArgs& e, int64_t B, int64_t H, int64_t W, int64_
 
 extern "C" int pl_conv2d_planes_fwd(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W, int64_t Cin,
                                     const void* w_planes, int64_t w_plane, int64_t Cout, int KH, int KW, int stride, int pad,
-                                    float* y, float out_scale, const float* dyn_inv, void* stream) {
+                                    float* y, float out_scale, const float* dyn_inv, float* stat, void* stream) {
   if (mode != PL_F16X3 && mode != PL_BF16) PL_FAIL(PL_EDTYPE, "pl_conv2d_planes_fwd: mode %d", mode);
   if (!x_planes || !w_planes || !y || Cout <= 0) PL_FAIL(PL_EINVAL, "pl_conv2d_planes_fwd: null pointer");
   PlanesGemmArgs g = {};
@@ -845,6 +848,7 @@ extern "C" int pl_conv2d_planes_fwd(int mode, const void* x_planes, int64_t x_pl
   g.out_scale = mode == PL_F16X3 ? out_scale : 1.0f;
   g.dyn_inv = mode == PL_F16X3 ? dyn_inv : nullptr;
   g.e.C = y; g.e.M = (int)(B * Ho * Wo); g.e.N = (int)Cout; g.e.K = (int)K; g.e.ldc = (int)Cout; g.e.split_k = 1;
+  if (stat) { g.e.stat_sum = stat; g.e.stat_m2 = stat + (size_t)gemm_stat_groups(g.e.M) * Cout; }
   return launch_gemm_planes(kNT, g, (hipStream_t)stream);
 }
 

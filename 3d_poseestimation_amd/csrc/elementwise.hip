@@ -992,6 +992,38 @@ inline int stream_rows_grid(int B, int strips) {
 // =====================================================================================
 // launchers
 // =====================================================================================
+// (sum, M2) partials over 64-row groups (what a GEMM epilogue emits) merged F at a time, in group order (Chan et al.), into
+// the [2][Gp][H] layout bn_finalize walks with group_rows = 64 F: a 1M-pixel map has 16384 such partials per column.
+__global__ __launch_bounds__(NTHR) void bn_merge_groups_kernel(const float* __restrict__ in, int G, int rows, int H, int F,
+                                                               float* __restrict__ out, int Gp) {
+  const int c = blockIdx.x * NTHR + threadIdx.x;
+  if (c >= H) return;
+  const int gp = blockIdx.y;
+  const size_t GH = (size_t)G * H;
+  float S = 0.f, Q = 0.f, na = 0.f;
+  for (int f0 = 0; f0 < F; f0 += 8) {
+    float s[8], q[8], n[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {                       // eight groups' loads in flight
+      const int g = gp * F + f0 + u;
+      n[u] = (f0 + u < F && g < G) ? (float)max(0, min(64, rows - 64 * g)) : 0.f;
+      s[u] = q[u] = 0.f;
+      if (n[u] > 0.f) { s[u] = in[(size_t)g * H + c]; q[u] = in[GH + (size_t)g * H + c]; }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (n[u] == 0.f) continue;
+      if (na == 0.f) { S = s[u]; Q = q[u]; na = n[u]; continue; }
+      const float d = s[u] / n[u] - S / na;
+      Q += q[u] + d * d * (na * n[u] / (na + n[u]));
+      S += s[u];
+      na += n[u];
+    }
+  }
+  out[(size_t)gp * H + c] = S;
+  out[(size_t)Gp * H + (size_t)gp * H + c] = Q;
+}
+
 int launch_bn_finalize(const float* stat, int G, int world, int B, int H,
                        const float* gamma, const float* beta, float eps, float momentum,
                        float* running_mean, float* running_var, int64_t* batches, float* mean,
@@ -1389,7 +1421,8 @@ extern "C" size_t pl_bn_train_scratch_bytes(int64_t rows, int64_t C) {
   if (rows <= 0 || C <= 0) return 0;
   const int R = bn_replicas(rows, C);
   const int64_t rv = rows / R;                      // rows of the reshaped view
-  const size_t fwd = ((size_t)2 * R * bn_groups(rv) * C + 2 * (size_t)C) * sizeof(float);
+  size_t fwd = ((size_t)2 * R * bn_groups(rv) * C + 2 * (size_t)C) * sizeof(float);
+  if (fwd < ((size_t)2 * 512 * C + 2 * (size_t)C) * sizeof(float)) fwd = ((size_t)2 * 512 * C + 2 * (size_t)C) * sizeof(float);
   const int rc = bwd_row_chunks((int)rv, (int)C * R);
   const size_t bwd = ((size_t)2 * R * rc * C + 3 * (size_t)C + (size_t)rc * R * C +
                       (size_t)2 * ((C * R + 255) / 256) * rc + 16) * sizeof(float);     // ... + the dz range maxima
@@ -1420,14 +1453,14 @@ extern "C" int pl_bn_train_fwd(const float* z, int64_t rows, int64_t C, const fl
                                float* y, uint64_t* bits, float* mean, float* rstd, void* scratch, void* stream) {
   if (!y) PL_FAIL(PL_EINVAL, "pl_bn_train_fwd: null pointer");
   return pl_bn_train_fwd_ex(z, rows, C, gamma, beta, eps, momentum, running_mean, running_var, batches, relu, y, bits, mean,
-                            rstd, scratch, nullptr, 0, stream);
+                            rstd, scratch, nullptr, 0, nullptr, stream);
 }
 
 // + y_planes (optional): the output also / only (y == NULL) as operand planes of the next 1x1 convolution's planes GEMM
 extern "C" int pl_bn_train_fwd_ex(const float* z, int64_t rows, int64_t C, const float* gamma, const float* beta, float eps,
                                   float momentum, float* running_mean, float* running_var, int64_t* batches, int relu,
                                   float* y, uint64_t* bits, float* mean, float* rstd, void* scratch, void* y_planes,
-                                  int planes_mode, void* stream) {
+                                  int planes_mode, const float* gemm_stat, void* stream) {
   if (!z || !gamma || !beta || (!y && !y_planes) || !bits || !mean || !rstd || !scratch) PL_FAIL(PL_EINVAL, "pl_bn_train_fwd: null pointer");
   PlaneOut ypo;
   PL_TRY(plane_out_of(planes_mode, y_planes, rows * C, kActPlaneScale, nullptr, &ypo, "pl_bn_train_fwd_ex"));
@@ -1439,10 +1472,30 @@ extern "C" int pl_bn_train_fwd_ex(const float* z, int64_t rows, int64_t C, const
   float* stat = static_cast<float*>(scratch);
   float* scale = stat + (size_t)2 * R * G * Hc;
   float* shift = scale + Hc;
-  hipLaunchKernelGGL(bn_colstats_kernel, dim3((H + 255) / 256, G), dim3(NTHR), 0, s, z, B, H, gs, Hc, stat);
-  PL_CHECK_LAUNCH("bn_colstats");
-  PL_TRY(launch_bn_finalize(stat, G, R, B, Hc, gamma, beta, eps, momentum, running_mean, running_var, batches, mean, rstd,
-                            scale, shift, s, gs));
+  if (gemm_stat) {
+    // the convolution's GEMM epilogue already left (sum, M2) per 64-row group and column: [2][gemm_stat_groups(rows)][C]
+    // -- no pass over z for the statistics; more than 512 groups are merged F at a time first
+    const int G64 = gemm_stat_groups((int)rows);
+    const float* st = gemm_stat;
+    int Gf = G64, gsf = 64;
+    if (G64 > 512) {
+      const int F = (G64 + 511) / 512;
+      Gf = (G64 + F - 1) / F; gsf = 64 * F;
+      float* merged = stat;                              // (scratch >= 2 * 512 * C floats: pl_bn_train_scratch_bytes)
+      scale = merged + (size_t)2 * Gf * Hc; shift = scale + Hc;
+      hipLaunchKernelGGL(bn_merge_groups_kernel, dim3((Hc + NTHR - 1) / NTHR, Gf), dim3(NTHR), 0, s, gemm_stat, G64, (int)rows,
+                         Hc, F, merged, Gf);
+      PL_CHECK_LAUNCH("bn_merge_groups");
+      st = merged;
+    }
+    PL_TRY(launch_bn_finalize(st, Gf, 1, (int)rows, Hc, gamma, beta, eps, momentum, running_mean, running_var, batches, mean,
+                              rstd, scale, shift, s, gsf));
+  } else {
+    hipLaunchKernelGGL(bn_colstats_kernel, dim3((H + 255) / 256, G), dim3(NTHR), 0, s, z, B, H, gs, Hc, stat);
+    PL_CHECK_LAUNCH("bn_colstats");
+    PL_TRY(launch_bn_finalize(stat, G, R, B, Hc, gamma, beta, eps, momentum, running_mean, running_var, batches, mean, rstd,
+                              scale, shift, s, gs));
+  }
   const int strips = (H + 255) / 256;
   dim3 grid(strips, stream_rows_grid(B, strips));
   hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NTHR), 0, s, z, scale, shift, (const float*)nullptr, y, bits, B, H,

@@ -257,7 +257,9 @@ int pl_mask_by_bits(const float* g, const uint64_t* bits, int64_t rows, int64_t 
  * LDS-DMA).  planes of an n-element tensor: planes_mode PL_F16X3 -> [2][n] fp16 (h = fp16(S x), l = fp16((S x - h) 2048)),
  * PL_BF16 -> [n] bf16; 16-byte aligned, n % 8 == 0; NULL = none.  Replaces the same reference code as the plain forms.
  *   pl_planes_split     : planes of an fp32 tensor with the static scale S (weights: 16; activations: 1)
- *   pl_bn_train_fwd_ex  : y may be NULL when only the planes are wanted (S = 1)
+ *   pl_bn_train_fwd_ex  : y may be NULL when only the planes are wanted (S = 1); gemm_stat (optional): the batch statistics
+ *                         as the producing GEMM's epilogue left them -- [2][pl_gemm_stat_groups(rows)][C]: per 64-row group
+ *                         the column sums, then the sums of squares about the group mean -- instead of a pass over z
  *   pl_bn_train_bwd_ex  : dz may be NULL; PL_F16X3 planes hold S dz with S a power of two chosen on the device from a range
  *                         bound of dz; dz_scale (device, 2 floats) receives {S, 1/S} -- pass dz_scale + 1 as dyn_inv below
  *   pl_add_relu_fwd_ex  : out (fp32, the next join reads it) AND its planes (S = 1)
@@ -266,7 +268,7 @@ int pl_planes_split(const float* x, int64_t n, int planes_mode, float scale, voi
 int pl_bn_train_fwd_ex(const float* z, int64_t rows, int64_t C, const float* gamma, const float* beta, float eps,
                        float momentum, float* running_mean, float* running_var, int64_t* batches, int relu,
                        float* y, uint64_t* bits, float* mean, float* rstd, void* scratch, void* y_planes,
-                       int planes_mode, void* stream);
+                       int planes_mode, const float* gemm_stat, void* stream);
 int pl_bn_train_bwd_ex(const float* dy, const uint64_t* bits, const float* z, const float* mean, const float* rstd,
                        const float* gamma, int64_t rows, int64_t C, float* dz, float* dgamma, float* dbeta,
                        void* scratch, void* dz_planes, int planes_mode, float* dz_scale, void* stream);
@@ -434,8 +436,11 @@ int pl_gemm_planes(int layout, int mode, const float* A, const float* B, float* 
  * a_plane / b_plane: elements between the two fp16 planes of an operand (unused for PL_BF16); lda / ldb: row strides
  * of the plane matrices in elements (% 8 == 0).  C = out_scale * [dyn_inv[0] *] (A B) (+ bias): out_scale = 1 / (S_A S_B),
  * dyn_inv a device scalar or NULL.  Any M; N % 8 == 0 (TN: M % 8 == 0 too); K % (32 * splits) == 0.  splits =
- * pl_gemm_planes_splits(M, N, K) > 1 needs slabs of splits * M * N floats (K slices summed in order into C). */
+ * pl_gemm_planes_splits(M, N, K) > 1 needs slabs of splits * M * N floats (K slices summed in order into C).
+ * stat (optional, unsplit problems; also on pl_conv2d_planes_fwd): [2][pl_gemm_stat_groups(M)][N] -- the epilogue also emits
+ * training-mode BatchNorm partial statistics of C, for pl_bn_train_fwd_ex. */
 int pl_gemm_planes_splits(int64_t M, int64_t N, int64_t K);
+int pl_gemm_stat_groups(int64_t M);   /* 64-row statistics groups a GEMM epilogue emits for M rows (2 per 128-row tile) */
 /* KxK convolutions the same way (implicit GEMM: the loader waves gather the NHWC input planes tap by tap, padding pixels
  * read as zeros; reference Resnet.py:58-60 conv2 and its autograd).  x_planes: planes of x [B][H][W][Cin], Cin % 32 == 0;
  * w_planes: planes of the OHWI kernel [Cout][KH*KW*Cin]; y [B][Ho][Wo][Cout] fp32.  The data gradient of a stride-1
@@ -444,7 +449,7 @@ int pl_gemm_planes_splits(int64_t M, int64_t N, int64_t K);
  * pl_gemm_planes_splits(Cout, KH*KW*Cin, B*Ho*Wo) * Cout * KH*KW*Cin floats when that is > 1.  out_scale / dyn_inv as above. */
 int pl_conv2d_planes_fwd(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W, int64_t Cin,
                          const void* w_planes, int64_t w_plane, int64_t Cout, int KH, int KW, int stride, int pad,
-                         float* y, float out_scale, const float* dyn_inv, void* stream);
+                         float* y, float out_scale, const float* dyn_inv, float* stat, void* stream);
 /* The head's last link on planes: the 3-D soft-argmax backward writing dlogits (4.5 GB at B = 256) as operand planes for the
  * final 1x1 convolution's gradient GEMMs (dlogits may be NULL), and the bias gradient as column sums of those planes.
  * PL_F16X3: dl_scale = {S, 1/S} on the device, S a power of two the caller derives from |dlogit| <= 2 max sum_c |g_c|. */
@@ -465,7 +470,7 @@ int pl_conv2d_planes_wgrad(int mode, const void* dz_planes, int64_t dz_plane, co
                            int pad, float* dw, float out_scale, const float* dyn_inv, float* slabs, void* stream);
 int pl_gemm_planes_raw(int layout, int mode, const void* A, int64_t a_plane, int64_t lda, const void* B, int64_t b_plane,
                        int64_t ldb, float* C, int64_t M, int64_t N, int64_t K, const float* bias, float out_scale,
-                       const float* dyn_inv, float* slabs, void* stream);
+                       const float* dyn_inv, float* slabs, float* stat, void* stream);
 
 /* ---- next row N1: fused softmax + integral soft-argmax ----------------------------------- */
 /* Tail of Model_3D.forward  phase4_joined/Model.py:94-133 (ncoord 3, centred 1: (E/dim - 0.5)*2)

@@ -578,9 +578,18 @@ def test_conv_planes_fwd_dgrad_wgrad_vs_torch_fp64(pkg, B, H, W, Cin, Cout, K, s
     xp, wp, dzp = _planes(pkg, xd, 1.0), _planes(pkg, wd, 16.0), _planes(pkg, dzd, 1.0)
     s = torch.cuda.current_stream().cuda_stream
     y = torch.full((B, Ho, Wo, Cout), float("nan"), device=DEV)
+    G = L.pl_gemm_stat_groups(B * Ho * Wo)
+    stat = torch.full((2, G, Cout), float("nan"), device=DEV)        # the epilogue's BatchNorm partial statistics of y
     rc = L.pl_conv2d_planes_fwd(3, xp.data_ptr(), x.numel(), B, H, W, Cin, wp.data_ptr(), w.numel(), Cout,
-                                K, K, stride, pad, y.data_ptr(), 1.0 / 16.0, None, s)
+                                K, K, stride, pad, y.data_ptr(), 1.0 / 16.0, None, stat.data_ptr(), s)
     assert rc == 0, L.pl_last_error()
+    y2 = y.reshape(-1, Cout).double().cpu()
+    for g in range(G):
+        blk = y2[64 * g:64 * (g + 1)]
+        want_s = blk.sum(0) if len(blk) else torch.zeros(Cout, dtype=torch.float64)
+        want_q = ((blk - blk.mean(0)) ** 2).sum(0) if len(blk) else torch.zeros(Cout, dtype=torch.float64)
+        assert float((stat[0, g].cpu().double() - want_s).abs().max()) <= 1e-4 * max(1.0, float(want_s.abs().max()))
+        assert float((stat[1, g].cpu().double() - want_q).abs().max()) <= 1e-4 * max(1.0, float(want_q.abs().max()))
     x64 = x.double().permute(0, 3, 1, 2).requires_grad_(True)
     w64 = w.double().permute(0, 3, 1, 2).requires_grad_(True)
     ref = F.conv2d(x64, w64, stride=stride, padding=pad)
@@ -593,7 +602,7 @@ def test_conv_planes_fwd_dgrad_wgrad_vs_torch_fp64(pkg, B, H, W, Cin, Cout, K, s
         wfp = _planes(pkg, wf, 16.0)
         dx = torch.full((B, H, W, Cin), float("nan"), device=DEV)
         rc = L.pl_conv2d_planes_fwd(3, dzp.data_ptr(), dz.numel(), B, Ho, Wo, Cout, wfp.data_ptr(), wf.numel(),
-                                    Cin, K, K, 1, K - 1 - pad, dx.data_ptr(), 1.0 / 16.0, None, s)
+                                    Cin, K, K, 1, K - 1 - pad, dx.data_ptr(), 1.0 / 16.0, None, None, s)
         assert rc == 0, L.pl_last_error()
         want = x64.grad.permute(0, 2, 3, 1)
         assert float((dx.cpu().double() - want).abs().max()) <= 3e-6 * float(want.abs().max()) * (K * K * Cout) ** 0.5
