@@ -78,9 +78,13 @@ inline int planes_kind(const PLDesc* d, int64_t B) {       // PlaneOut::kind of 
 // BatchNorm-backward pass 1 of hidden layer l is folded into the epilogue of the dX GEMM of layer l+1 (which produces
 // its incoming gradient) whenever that GEMM is a planes GEMM: every hidden layer but the top one.  A pure function of
 // (descriptor, layer), so the ranges of a cut backward agree on it.  POSELIFT_BNR_UNFUSED=1: the separate pass (A/B).
+// The top layer's incoming gradient comes from the 51-wide output layer (g = dy W5, skinny.hip): that kernel carries the
+// same epilogue (POSELIFT_BNR_TOP_UNFUSED=1: the stand-alone pass for the top layer only).
 inline bool fused_reduce(const PLDesc* d, bool planes, int l, int L, bool eval_bn) {
   static const bool off = [] { const char* e = getenv("POSELIFT_BNR_UNFUSED"); return e && e[0] == '1'; }();
-  return planes && d->bn && !eval_bn && !off && l < L - 1;
+  static const bool top_off = [] { const char* e = getenv("POSELIFT_BNR_TOP_UNFUSED"); return e && e[0] == '1'; }();
+  if (!planes || !d->bn || eval_bn || off) return false;
+  return l < L - 1 || (!top_off && skinny_supported(d->out_dim, d->hidden));
 }
 inline int arith_of(const PLDesc* d) { return d->dtype == PL_F16X3 ? (int)PL_BF16X6 : d->dtype; }
 
@@ -215,7 +219,7 @@ Ws plan(const PLDesc* d, int64_t B) {
     w.wp.push_back(0);
     for (int l = 1; l < w.L; ++l) w.wp.push_back(take((size_t)H * H * 4));
     w.dzp = take(w.act_bytes);
-    w.amax = take(std::max((size_t)((H + 255) / 256) * w.RC, (size_t)(B / 64) * (H / 64)) * 2 * 4);
+    w.amax = take(std::max((size_t)((H + 255) / 256) * w.RC, (size_t)(B / 64) * (H / 32)) * 2 * 4);
     w.dzscale = take((size_t)w.L * 2 * 4);
   }
   w.total = o;
@@ -585,7 +589,15 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
     GemmArgs g = {};
     g.A = dy; g.B = W5; g.C = GA; g.M = Bi; g.N = H; g.K = O; g.lda = O; g.ldb = H; g.ldc = H; g.split_k = 1;
     if (skinny_supported(O, H)) {
-      PL_TRY(launch_skinny_wide_out(dy, W5, nullptr, GA, Bi, O, H, true, nullptr, nullptr, s));
+      GemmArgs be = {};
+      const int lt = w.L - 1;
+      if (fused_reduce(d, w.planes, lt, w.L, eval_bn)) {      // pass 1 of the top hidden layer, on the block just produced
+        be.bnr_z = f32(ws, w.z[lt]); be.bnr_bits = u64(ws, w.bits[lt]);
+        be.bnr_mean = f32(ws, w.mean[lt]); be.bnr_rstd = f32(ws, w.rstd[lt]); be.bnr_kscale = kscale;
+        be.bnr_part_dy = f32(ws, w.stat); be.bnr_part_dyz = f32(ws, w.stat) + (size_t)(Bi / 64) * H;
+        be.bnr_amax = (w.pkind == 2 && lt > 0) ? f32(ws, w.amax) : nullptr;
+      }
+      PL_TRY(launch_skinny_wide_out(dy, W5, nullptr, GA, Bi, O, H, true, nullptr, nullptr, s, &be));
     } else {
       PL_TRY(launch_gemm_f32(kNN, g, s));
     }
@@ -608,7 +620,7 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
       // the fp32-operand GEMM: +17 us per GEMM for the 7.5 us kernel it removed)
       const bool fr = fused_reduce(d, w.planes, l, w.L, eval_bn);
       const int rc_l = fr ? Bi / 64 : w.RC;
-      const int n_amax_l = fr ? (Bi / 64) * (H / 64) : n_amax;
+      const int n_amax_l = fr ? (Bi / 64) * (l == w.L - 1 ? H / 32 : H / 64) : n_amax;   // (top layer: skinny epilogue, 32-column strips)
       float* stat = f32(ws, w.stat);
       float* mine = stat + (size_t)((eval_bn || fr) ? 0 : sync_rank(d)) * 2 * rc_l * H;
       if (!fr) {

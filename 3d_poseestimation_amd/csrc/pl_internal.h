@@ -206,8 +206,11 @@ int launch_fill(float* p, int64_t n, float v, hipStream_t s);
 bool skinny_supported(int K, int H);           // narrow dimension specialised (34, 51), H % 128 == 0
 int skinny_chunks(int B);                      // row tasks (64 rows each)
 int skinny_stat_groups(int B);                 // 64-row BN statistics groups it emits
+// bnr (optional, w_transposed only): its bnr_* fields = BatchNorm-backward pass 1 of the layer that consumes `out` as its
+// incoming gradient, done on the block just produced (amax per (64-row group, 32-column strip): (B/64) * (H/32) pairs)
 int launch_skinny_wide_out(const float* X, const float* W, const float* bias, float* out, int B, int K,
-                           int H, bool w_transposed, float* stat_sum, float* stat_m2, hipStream_t s);
+                           int H, bool w_transposed, float* stat_sum, float* stat_m2, hipStream_t s,
+                           const GemmArgs* bnr = nullptr);
 // reduce == false: only the partials are written (part: skinny_in_chunks(B) x K x H floats); the caller combines them
 // (launch_reduce_rows_multi: R = skinny_in_chunks(B), H = K*H, transK = K when out_transposed)
 int launch_skinny_wide_in(const float* X, const float* D, float* out, int B, int K, int H,

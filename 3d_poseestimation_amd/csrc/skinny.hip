@@ -33,10 +33,18 @@ __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * 
 // STATS: BatchNorm partial statistics (sum, M2 about the group mean) per 64-row group.
 // The workgroup's four waves take four neighbouring column strips of the SAME row group, so the
 // 64 narrow rows are staged once in LDS (coalesced) and read back as MFMA A fragments.
-template <int K, bool WT, bool STATS>
+// BNR (g = dy W5 only): BatchNorm-backward pass 1 of the top hidden layer on the block just produced, as the planes GEMM's
+// epilogue does for the layers below (GemmArgs::bnr_*): per 64-row group and column sum dy and sum dy*zhat
+// (dy = g * bit * kscale), per (group, 32-column strip) max |dy| and max |zhat|.  Whole groups only (B % 64 == 0).
+struct SkinnyBnr {
+  const float* z; const uint64_t* bits; const float* mean; const float* rstd; float kscale;
+  float* part_dy; float* part_dyz; float* amax;
+};
+
+template <int K, bool WT, bool STATS, bool BNR = false>
 __global__ __launch_bounds__(NTHR) void skinny_wide_out_kernel(
     const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
-    float* __restrict__ out, int B, int H, float* __restrict__ stat_sum, float* __restrict__ stat_m2) {
+    float* __restrict__ out, int B, int H, float* __restrict__ stat_sum, float* __restrict__ stat_m2, SkinnyBnr bn) {
   constexpr int KS = (K + 1) / 2;            // MFMA steps, 2 k each
   constexpr int KL = 2 * KS + 1;             // LDS row stride (odd: conflict-free column reads)
   __shared__ float xs[RG * KL];
@@ -102,6 +110,46 @@ __global__ __launch_bounds__(NTHR) void skinny_wide_out_kernel(
         if (row < B) {
           out[(size_t)row * H + c] = v;
           ssum += v;
+        }
+      }
+    }
+    if (BNR) {
+      const int wpr = ((H + 255) >> 8) * 4;
+      const uint64_t* bw = bn.bits + (size_t)(c >> 8) * 4 + (c & 3);
+      const int bit = (c & 255) >> 2;
+      const float mu = bn.mean[c], rs = bn.rstd[c];
+      float zz[2][16];
+      uint64_t ww[2][16];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const size_t row = (size_t)(g0 + t * 32 + acc_row(r, h));
+          zz[t][r] = bn.z[row * H + c];
+          ww[t][r] = bw[row * wpr];
+        }
+      float s1 = 0.f, s2 = 0.f, mxd = 0.f, mxz = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float dv = ((ww[t][r] >> bit) & 1ull) ? acc[t][r] * bn.kscale : 0.f;
+          const float zh = (zz[t][r] - mu) * rs;
+          s1 += dv;
+          s2 = fmaf(dv, zh, s2);
+          mxd = fmaxf(mxd, fabsf(dv)); mxz = fmaxf(mxz, fabsf(zh));
+        }
+      s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+      if (h == 0) {
+        bn.part_dy[(size_t)(g0 >> 6) * H + c] = s1;
+        bn.part_dyz[(size_t)(g0 >> 6) * H + c] = s2;
+      }
+      if (bn.amax) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mxd = fmaxf(mxd, __shfl_xor(mxd, o)); mxz = fmaxf(mxz, __shfl_xor(mxz, o)); }
+        if (lane == 0) {
+          float* q = bn.amax + ((size_t)(g0 >> 6) * (H >> 5) + (c >> 5)) * 2;
+          q[0] = mxd; q[1] = mxz;
         }
       }
     }
@@ -323,10 +371,20 @@ int skinny_stat_groups(int B) { return (B + 63) / 64; }
 
 // forward of the input layer (+ BN statistics)  /  g = dy W5 (transposed weights, no bias)
 int launch_skinny_wide_out(const float* X, const float* W, const float* bias, float* out, int B, int K,
-                           int H, bool w_transposed, float* stat_sum, float* stat_m2, hipStream_t s) {
+                           int H, bool w_transposed, float* stat_sum, float* stat_m2, hipStream_t s, const GemmArgs* bnr) {
   if (!skinny_supported(K, H)) PL_FAIL(PL_ESHAPE, "skinny_wide_out: K=%d H=%d not specialised", K, H);
   dim3 grid(skinny_chunks(B) * (H / 128)), block(NTHR);
-#define PL_SK(KK, WT, ST) hipLaunchKernelGGL((skinny_wide_out_kernel<KK, WT, ST>), grid, block, 0, s, X, W, bias, out, B, H, stat_sum, stat_m2)
+  SkinnyBnr bn = {};
+  if (bnr && bnr->bnr_z) {
+    if (!w_transposed || stat_sum || (B & 63)) PL_FAIL(PL_EINVAL, "skinny_wide_out: BatchNorm-backward epilogue only on g = dy W, whole groups");
+    bn = SkinnyBnr{bnr->bnr_z, bnr->bnr_bits, bnr->bnr_mean, bnr->bnr_rstd, bnr->bnr_kscale, bnr->bnr_part_dy, bnr->bnr_part_dyz,
+                   bnr->bnr_amax};
+    if (K == 34) hipLaunchKernelGGL((skinny_wide_out_kernel<34, true, false, true>), grid, block, 0, s, X, W, bias, out, B, H, stat_sum, stat_m2, bn);
+    else hipLaunchKernelGGL((skinny_wide_out_kernel<51, true, false, true>), grid, block, 0, s, X, W, bias, out, B, H, stat_sum, stat_m2, bn);
+    PL_CHECK_LAUNCH("skinny_wide_out");
+    return PL_OK;
+  }
+#define PL_SK(KK, WT, ST) hipLaunchKernelGGL((skinny_wide_out_kernel<KK, WT, ST>), grid, block, 0, s, X, W, bias, out, B, H, stat_sum, stat_m2, bn)
   const bool st = stat_sum != nullptr;
   if (K == 34 && !w_transposed) { if (st) PL_SK(34, false, true); else PL_SK(34, false, false); }
   else if (K == 34) { if (st) PL_SK(34, true, true); else PL_SK(34, true, false); }
