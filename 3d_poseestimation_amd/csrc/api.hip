@@ -550,8 +550,11 @@ static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, 
 // The gradient flowing between two calls lives in the workspace (GA/GB), so the pass can be cut
 // at any layer boundary: the data-parallel driver all-reduces the first half's gradients while
 // the second half is still computing.
+// loss_out != NULL (the fused train step): the MSE loss is finalised by this range's one reduce launch (a kind-2 job:
+// mse_final_kernel's sum) and the device step counter ticks there, instead of in a launch of their own after the forward.
 static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B, void* ws, size_t ws_bytes,
-                    float* dx, float* grads, void* stream, bool do_output, int l_hi, int l_lo, bool eval_bn = false) {
+                    float* dx, float* grads, void* stream, bool do_output, int l_hi, int l_lo, bool eval_bn = false,
+                    float* loss_out = nullptr) {
   PL_TRY(check_desc(d, true));
   if (!x || !dy || !grads) PL_FAIL(PL_EINVAL, "pl_lifter_bwd: null x/dy/flat_grads");
   if (B <= 0) PL_FAIL(PL_ESHAPE, "pl_lifter_bwd: B=%lld", (long long)B);
@@ -693,9 +696,17 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
       PL_TRY(launch_gemm_f32(kNN, g, s));
     }
   }
+  float inv_n = 0.f;
+  uint64_t* tick = nullptr;
+  if (loss_out) {
+    const int64_t n = B * O;
+    job(f32(ws, w.mse), loss_out, mse_partials(n), 1, 2, 0);
+    inv_n = 1.0f / (float)n;
+    tick = const_cast<uint64_t*>(d->step_dev);
+  }
   if (jpart.empty()) return PL_OK;
   return launch_reduce_rows_multi(jpart.data(), jR.data(), jH.data(), jout.data(), (int)jpart.size(), s, jkind.data(),
-                                  jtrans.data());
+                                  jtrans.data(), inv_n, tick);
 }
 
 extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, int64_t B, void* ws,
@@ -946,8 +957,8 @@ extern "C" int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const fl
   const int L = 1 + 2 * d->num_stage;
   if (hi == L) {
     PL_TRY(pl_lifter_fwd_train(d, x, y, B, ws, ws_bytes, seed, step, nullptr, stream));
-    PL_TRY(mse_fwd_bwd_tick(y, target, B * d->out_dim, 1.0f, dy, loss, f32(ws, w.mse),
-                            const_cast<uint64_t*>(d->step_dev), stream));
+    PL_TRY(mse_partial_only(y, target, B * d->out_dim, 1.0f, dy, f32(ws, w.mse), stream));
   }
-  return bwd_impl(d, x, dy, B, ws, ws_bytes, nullptr, grads, stream, hi == L, hi == L ? L - 1 : hi, lo);
+  return bwd_impl(d, x, dy, B, ws, ws_bytes, nullptr, grads, stream, hi == L, hi == L ? L - 1 : hi, lo, false,
+                  hi == L ? loss : nullptr);
 }

@@ -658,14 +658,38 @@ __global__ __launch_bounds__(NTHR) void colsum_partial_kernel(const float* __res
 // (many partial rows, few columns: 16 columns x 16 row-parts per workgroup, as reduce_rows_kernel), the skinny
 // layers' weight-gradient partials (transK: the transposed store of dW0), and the split-K slabs of the 1024-wide weight
 // gradients (few slabs, 1M outputs: streamed as float4, slab by slab in order -- kind 1).
-constexpr int kMaxRowJobs = 12;
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sm[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  const int nw = blockDim.x >> 6;
+  for (int w = 0; w < nw; ++w) t += sm[w];
+  __syncthreads();
+  return t;
+}
+
+constexpr int kMaxRowJobs = 16;
 struct RowJobs { const float* part[kMaxRowJobs]; float* out[kMaxRowJobs]; int R[kMaxRowJobs]; int H[kMaxRowJobs];
-                 int kind[kMaxRowJobs]; int transK[kMaxRowJobs]; };
+                 int kind[kMaxRowJobs]; int transK[kMaxRowJobs]; float inv_n; uint64_t* tick; };
 __global__ __launch_bounds__(NTHR) void reduce_rows_multi_kernel(RowJobs j) {
   __shared__ float red[RPARTS][RCOLS];
   const int job = blockIdx.y;
   const int R = j.R[job], H = j.H[job];
   const float* __restrict__ part = j.part[job];
+  if (j.kind[job] == 2) {                    // the MSE loss of the fused train step: mse_final_kernel's sum, bit for bit
+    if (blockIdx.x) return;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < R; i += blockDim.x) acc += part[i];
+    const float t = block_sum(acc, &red[0][0]);
+    if (threadIdx.x == 0) {
+      j.out[job][0] = t * j.inv_n;
+      if (j.tick) j.tick[0] += 1;
+    }
+    return;
+  }
   if (j.kind[job] == 1) {                    // H % 4 == 0, 16-byte aligned (checked on the host)
     const int n4 = H >> 2;
     for (int i = blockIdx.x * NTHR + threadIdx.x; i < n4; i += gridDim.x * NTHR) {
@@ -727,19 +751,6 @@ __global__ void bn_eval_stats_kernel(const float* __restrict__ gamma, const floa
 __global__ void fill_kernel(float* p, int64_t n, float v) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = v;
-}
-
-__device__ __forceinline__ float block_sum(float v, float* sm) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) sm[wave] = v;
-  __syncthreads();
-  float t = 0.f;
-  const int nw = blockDim.x >> 6;
-  for (int w = 0; w < nw; ++w) t += sm[w];
-  __syncthreads();
-  return t;
 }
 
 // ---- MSE(mean) forward + backward ---------------------------------------------------------
@@ -1145,9 +1156,10 @@ int launch_reduce_slabs_bias(const float* slabs, int nslab, int rows, int cols, 
 }
 
 int launch_reduce_rows_multi(const float* const* part, const int* R, const int* H, float* const* out, int njobs,
-                             hipStream_t s, const int* kind, const int* transK) {
+                             hipStream_t s, const int* kind, const int* transK, float loss_inv_n, uint64_t* loss_tick) {
   for (int base = 0; base < njobs; base += kMaxRowJobs) {
     RowJobs j = {};
+    j.inv_n = loss_inv_n; j.tick = loss_tick;
     const int n = njobs - base < kMaxRowJobs ? njobs - base : kMaxRowJobs;
     int gx = 1;
     for (int k = 0; k < n; ++k) {
@@ -1159,6 +1171,8 @@ int launch_reduce_rows_multi(const float* const* part, const int* R, const int* 
         if ((j.H[k] & 3) || !aligned16(j.part[k]) || !aligned16(j.out[k])) PL_FAIL(PL_EINVAL, "reduce_rows_multi: slab job alignment");
         need = ((j.H[k] >> 2) + NTHR - 1) / NTHR;
         if (need > 1024) need = 1024;
+      } else if (j.kind[k] == 2) {
+        need = 1;
       } else {
         need = (j.H[k] + RCOLS - 1) / RCOLS;
       }
@@ -1234,6 +1248,19 @@ extern "C" int pl_mse_fwd_bwd(const float* pred, const float* tgt, int64_t n, fl
                               float* dpred, float* loss_out, void* scratch, void* stream) {
   return mse_fwd_bwd_tick(pred, tgt, n, grad_scale, dpred, loss_out, scratch, nullptr, stream);
 }
+
+// the first half of mse_fwd_bwd_tick: dpred and the per-workgroup partial sums; the loss itself is summed later by a kind-2
+// job of launch_reduce_rows_multi (R = mse_partials(n), inv_n = 1 / n)
+int pl::mse_partial_only(const float* pred, const float* tgt, int64_t n, float grad_scale, float* dpred, void* scratch,
+                         void* stream) {
+  if (!pred || !tgt || !scratch) PL_FAIL(PL_EINVAL, "pl_mse_fwd_bwd: null pointer");
+  if (n <= 0) PL_FAIL(PL_ESHAPE, "pl_mse_fwd_bwd: n = %lld", (long long)n);
+  hipLaunchKernelGGL(mse_partial_kernel, dim3(mse_blocks(n)), dim3(NTHR), 0, (hipStream_t)stream, pred, tgt, n,
+                     grad_scale * 2.0f / (float)n, dpred, (float*)scratch);
+  PL_CHECK_LAUNCH("mse_partial");
+  return PL_OK;
+}
+int pl::mse_partials(int64_t n) { return mse_blocks(n); }
 
 int pl::mse_fwd_bwd_tick(const float* pred, const float* tgt, int64_t n, float grad_scale, float* dpred,
                          float* loss_out, void* scratch, uint64_t* tick, void* stream) {

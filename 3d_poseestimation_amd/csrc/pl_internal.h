@@ -186,8 +186,12 @@ int launch_bn_bwd_dz(const float* g, const uint64_t* bits, const float* z, const
 // out[i] = sum_s slabs[s*n + i]
 int launch_reduce_slabs(const float* slabs, int nslab, int64_t n, float* out, hipStream_t s);
 // njobs independent out[c] = sum_r part[r][c] reductions in one launch
+// kind 2 (at most one job): out[0] = (sum of the R MSE partials) * loss_inv_n, then loss_tick[0] += 1 -- mse_final_kernel
 int launch_reduce_rows_multi(const float* const* part, const int* R, const int* H, float* const* out, int njobs,
-                             hipStream_t s, const int* kind = nullptr, const int* transK = nullptr);
+                             hipStream_t s, const int* kind = nullptr, const int* transK = nullptr, float loss_inv_n = 0.f,
+                             uint64_t* loss_tick = nullptr);
+int mse_partial_only(const float* pred, const float* tgt, int64_t n, float grad_scale, float* dpred, void* scratch, void* stream);
+int mse_partials(int64_t n);
 // out[r][c] = bias[c] + sum_s slabs[s][r][c]
 int launch_reduce_slabs_bias(const float* slabs, int nslab, int rows, int cols, const float* bias,
                              float* out, hipStream_t s);
