@@ -206,7 +206,7 @@ Ws plan(const PLDesc* d, int64_t B) {
   }
   w.slab_floats = slab / 4;
   w.slabs = take(slab);
-  w.outpart = take((size_t)colsum_chunks((int)B) * d->out_dim * 4);
+  w.outpart = take((size_t)std::max(colsum_chunks((int)B), skinny_in_chunks((int)B)) * d->out_dim * 4);
   w.dyout = take((size_t)B * d->out_dim * 4);                 // d loss / d y of the fused train step
   w.mse = take(pl_mse_scratch_bytes(B * d->out_dim));
   w.dzp = w.amax = w.dzscale = 0;
@@ -581,13 +581,16 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
   const float* W5 = d->params + P.off[4 * w.L];
   const float* h_last = f32(ws, w.act[w.L - 1]);
   if (skinny_supported(O, H)) {
-    PL_TRY(launch_skinny_wide_in(dy, h_last, grads + P.off[4 * w.L], Bi, O, H, false, f32(ws, w.skp_out), s, false));
+    // dW5 partials, and -- the kernel holds every row of dy in its A fragments -- the bias gradient's partial column sums
+    PL_TRY(launch_skinny_wide_in(dy, h_last, grads + P.off[4 * w.L], Bi, O, H, false, f32(ws, w.skp_out), s, false,
+                                 f32(ws, w.outpart)));
     job(f32(ws, w.skp_out), grads + P.off[4 * w.L], skinny_in_chunks(Bi), O * H, 0, 0);
+    job(f32(ws, w.outpart), grads + P.off[4 * w.L + 1], skinny_in_chunks(Bi), O, 0, 0);
   } else {
     PL_TRY(gemm_tn_reduced(dy, O, h_last, H, grads + P.off[4 * w.L], O, H, Bi, slabs, s));
+    PL_TRY(launch_colsum_partial(dy, Bi, O, f32(ws, w.outpart), s));
+    job(f32(ws, w.outpart), grads + P.off[4 * w.L + 1], colsum_chunks(Bi), O, 0, 0);
   }
-  PL_TRY(launch_colsum_partial(dy, Bi, O, f32(ws, w.outpart), s));
-  job(f32(ws, w.outpart), grads + P.off[4 * w.L + 1], colsum_chunks(Bi), O, 0, 0);
   {
     GemmArgs g = {};
     g.A = dy; g.B = W5; g.C = GA; g.M = Bi; g.N = H; g.K = O; g.lda = O; g.ldb = H; g.ldc = H; g.split_k = 1;

@@ -217,8 +217,10 @@ int launch_skinny_wide_out(const float* X, const float* W, const float* bias, fl
                            const GemmArgs* bnr = nullptr);
 // reduce == false: only the partials are written (part: skinny_in_chunks(B) x K x H floats); the caller combines them
 // (launch_reduce_rows_multi: R = skinny_in_chunks(B), H = K*H, transK = K when out_transposed)
+// xsum (optional): skinny_in_chunks(B) x K partial column sums of X (the output layer's bias gradient: X = dy), to be combined
+// like any other partial (R = skinny_in_chunks(B), H = K)
 int launch_skinny_wide_in(const float* X, const float* D, float* out, int B, int K, int H,
-                          bool out_transposed, float* part, hipStream_t s, bool reduce = true);
+                          bool out_transposed, float* part, hipStream_t s, bool reduce = true, float* xsum = nullptr);
 int skinny_in_chunks(int B);
 bool skinny_narrow_out_supported(int H, int N);
 size_t skinny_narrow_out_part_floats(int B, int H);

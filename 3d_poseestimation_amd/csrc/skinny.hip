@@ -183,10 +183,12 @@ __global__ __launch_bounds__(NTHR) void skinny_wide_out_kernel(
 // large as the read of D itself), and the combine kernel walks 16 partials instead of 64 at B = 4096.
 constexpr int IN_CHUNK = 4 * RG;
 
+// xsum (optional): xsum[chunk][k] = sum over the chunk's rows of X[r][k] -- the bias gradient of the output layer is the
+// column sum of dy, and the first strip's workgroup of every chunk has all of dy's rows in its A fragments anyway.
 template <int K>
 __global__ __launch_bounds__(NTHR) void skinny_wide_in_kernel(const float* __restrict__ X,
                                                               const float* __restrict__ D, int B, int H,
-                                                              float* __restrict__ part) {
+                                                              float* __restrict__ part, float* __restrict__ xsum) {
   __shared__ float red[3][32 * 64];          // accumulators of waves 1..3
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
@@ -200,6 +202,8 @@ __global__ __launch_bounds__(NTHR) void skinny_wide_in_kernel(const float* __res
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
   const int k1 = min(32 + j, K - 1);         // second k tile: clamp instead of masking (rows >= K are dropped)
+  const bool do_xsum = xsum != nullptr && (blockIdx.x % strips) == 0;      // (workgroup-uniform)
+  float xs0 = 0.f, xs1 = 0.f;                // this lane's rows (parity h) of columns j and 32 + j
   if (r_base + RG <= B) {                    // whole group: no guards
     // Loads in explicit batches of 16 row pairs (48 per wave in flight), pinned above their MFMAs: left to
     // itself hipcc keeps ONE iteration's three loads in flight and waits for them before every MFMA
@@ -221,6 +225,10 @@ __global__ __launch_bounds__(NTHR) void skinny_wide_in_kernel(const float* __res
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], d[s], acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], d[s], acc[1], 0, 0, 0);
       }
+      if (do_xsum) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) { xs0 += a0[s]; xs1 += a1[s]; }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   } else {
@@ -233,7 +241,22 @@ __global__ __launch_bounds__(NTHR) void skinny_wide_in_kernel(const float* __res
       const float a1 = ok ? X[(size_t)r * K + k1] : 0.f;
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, d, acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, d, acc[1], 0, 0, 0);
+      xs0 += a0; xs1 += a1;
     }
+  }
+  if (do_xsum) {
+    // rows of both parities, then the four waves in wave order (through the tail of `red`, unused until the barrier below)
+    xs0 += __shfl_xor(xs0, 32); xs1 += __shfl_xor(xs1, 32);
+    float* xr = &red[2][32 * 64 - 4 * 64];
+    if (h == 0) { xr[wave * 64 + j] = xs0; xr[wave * 64 + 32 + j] = xs1; }
+    __syncthreads();
+    if (wave == 0 && h == 0) {
+      const float t0 = ((xr[j] + xr[64 + j]) + xr[128 + j]) + xr[192 + j];
+      const float t1 = ((xr[32 + j] + xr[64 + 32 + j]) + xr[128 + 32 + j]) + xr[192 + 32 + j];
+      xsum[(size_t)ch * K + j] = t0;
+      if (32 + j < K) xsum[(size_t)ch * K + 32 + j] = t1;
+    }
+    __syncthreads();
   }
   if (wave > 0) {
 #pragma unroll
@@ -397,12 +420,12 @@ int launch_skinny_wide_out(const float* X, const float* W, const float* bias, fl
 
 // out = X^T D, X [B][K], D [B][H]; out is [K][H] or, transposed, [H][K]; part: chunks*K*H floats
 int launch_skinny_wide_in(const float* X, const float* D, float* out, int B, int K, int H,
-                          bool out_transposed, float* part, hipStream_t s, bool reduce) {
+                          bool out_transposed, float* part, hipStream_t s, bool reduce, float* xsum) {
   if (!skinny_supported(K, H)) PL_FAIL(PL_ESHAPE, "skinny_wide_in: K=%d H=%d not specialised", K, H);
   const int nc = skinny_in_chunks(B);
   dim3 grid(nc * (H / 32)), block(NTHR);
-  if (K == 34) hipLaunchKernelGGL((skinny_wide_in_kernel<34>), grid, block, 0, s, X, D, B, H, part);
-  else hipLaunchKernelGGL((skinny_wide_in_kernel<51>), grid, block, 0, s, X, D, B, H, part);
+  if (K == 34) hipLaunchKernelGGL((skinny_wide_in_kernel<34>), grid, block, 0, s, X, D, B, H, part, xsum);
+  else hipLaunchKernelGGL((skinny_wide_in_kernel<51>), grid, block, 0, s, X, D, B, H, part, xsum);
   PL_CHECK_LAUNCH("skinny_wide_in");
   if (!reduce) return PL_OK;
   const int n = K * H;
