@@ -460,7 +460,8 @@ extern "C" int pl_lifter_fwd_eval(const PLDesc* d, const float* x, float* y, int
 // saved in the workspace (pre-activations, ReLU bitmaps): BatchNorm normalises with the running statistics (which are
 // not touched), Dropout is the identity.  pl_lifter_fwd_eval is the fast, nothing-saved form of the same function.
 static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, void* ws, size_t ws_bytes,
-                          uint64_t seed, uint64_t step, const uint64_t* inject_keep, void* stream, bool eval_bn);
+                          uint64_t seed, uint64_t step, const uint64_t* inject_keep, void* stream, bool eval_bn,
+                          bool defer_out_reduce = false);
 
 extern "C" int pl_lifter_fwd_train(const PLDesc* d, const float* x, float* y, int64_t B, void* ws,
                                    size_t ws_bytes, uint64_t seed, uint64_t step,
@@ -474,7 +475,8 @@ extern "C" int pl_lifter_fwd_eval_saved(const PLDesc* d, const float* x, float* 
 }
 
 static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, void* ws, size_t ws_bytes,
-                          uint64_t seed, uint64_t step, const uint64_t* inject_keep, void* stream, bool eval_bn) {
+                          uint64_t seed, uint64_t step, const uint64_t* inject_keep, void* stream, bool eval_bn,
+                          bool defer_out_reduce) {
   PL_TRY(check_desc(d, true));
   if (!x || !y) PL_FAIL(PL_EINVAL, "pl_lifter_fwd_train: null x/y");
   if (B <= 0) PL_FAIL(PL_ESHAPE, "pl_lifter_fwd_train: B=%lld", (long long)B);
@@ -539,6 +541,9 @@ static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, 
                            eval_bn ? nullptr : d->step_dev));
     a_in = act;
   }
+  if (defer_out_reduce)   // (the fused train step: y = bias + slabs is formed by the MSE pass, mse_partial_from_slabs)
+    return launch_skinny_narrow_out(a_in, d->params + P.off[4 * w.L], d->params + P.off[4 * w.L + 1], y, (int)B, H, d->out_dim,
+                                    f32(ws, w.slabs), s, false);
   return gemm_out_layer(a_in, d->params + P.off[4 * w.L], d->params + P.off[4 * w.L + 1], y, (int)B,
                         d->out_dim, H, f32(ws, w.slabs), s);
 }
@@ -959,8 +964,19 @@ extern "C" int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const fl
   float* dy = f32(ws, w.dyout);
   const int L = 1 + 2 * d->num_stage;
   if (hi == L) {
-    PL_TRY(pl_lifter_fwd_train(d, x, y, B, ws, ws_bytes, seed, step, nullptr, stream));
-    PL_TRY(mse_partial_only(y, target, B * d->out_dim, 1.0f, dy, f32(ws, w.mse), stream));
+    const int H = d->hidden, O = d->out_dim;
+    static const bool head_off = [] { const char* e = getenv("POSELIFT_HEAD_UNFUSED"); return e && e[0] == '1'; }();
+    const int so = skinny_narrow_out_supported(H, O) ? skinny_narrow_out_splits((int)B, H) : 0;
+    if (!head_off && so && mse_from_slabs_supported(so, O)) {
+      // the output Linear's slab reduce folded into the MSE pass: one launch less, the same bits
+      PL_TRY(fwd_saved_impl(d, x, y, B, ws, ws_bytes, seed, step, nullptr, stream, false, true));
+      const ParamLayout P = param_layout(d);
+      PL_TRY(mse_partial_from_slabs(f32(ws, w.slabs), so, (int)B, O, d->params + P.off[4 * L + 1], target, 1.0f, y, dy,
+                                    f32(ws, w.mse), stream));
+    } else {
+      PL_TRY(pl_lifter_fwd_train(d, x, y, B, ws, ws_bytes, seed, step, nullptr, stream));
+      PL_TRY(mse_partial_only(y, target, B * d->out_dim, 1.0f, dy, f32(ws, w.mse), stream));
+    }
   }
   return bwd_impl(d, x, dy, B, ws, ws_bytes, nullptr, grads, stream, hi == L, hi == L ? L - 1 : hi, lo, false,
                   hi == L ? loss : nullptr);

@@ -770,6 +770,50 @@ __global__ __launch_bounds__(NTHR) void mse_partial_kernel(const float* __restri
   if (threadIdx.x == 0) part[blockIdx.x] = t;
 }
 
+// mse_partial_kernel with pred[i] formed on the fly from the output Linear's split-K slabs (part[s][r][64 padded columns]) and
+// stored: y[i] = bias[n] + slabs in order -- skinny_narrow_out_reduce_kernel's sum -- then the same d, fmaf and block_sum on the
+// same thread -> element map: y, dpred and the partials equal the two-launch route's bit for bit.  NS slabs, N columns.
+template <int NS, int N>
+__global__ __launch_bounds__(NTHR) void mse_partial_from_slabs_kernel(const float* __restrict__ part, int B,
+                                                                      const float* __restrict__ bias,
+                                                                      const float* __restrict__ tgt, float coef,
+                                                                      float* __restrict__ y, float* __restrict__ dpred,
+                                                                      float* __restrict__ mpart) {
+  __shared__ float sm[4];
+  const int64_t n = (int64_t)B * N;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const size_t slab = (size_t)B * 64;
+  float acc = 0.f;
+  for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += 4 * stride) {
+    float u[4][NS], t[4], bs[4];
+    int64_t idx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                       // up to four elements of this thread: every load issued first
+      idx[q] = i0 + q * stride;
+      const bool ok = idx[q] < n;
+      const int r = ok ? (int)(idx[q] / N) : 0, c = ok ? (int)(idx[q] - (int64_t)r * N) : 0;
+      const float* p = part + (size_t)r * 64 + c;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) u[q][s] = ok ? p[(size_t)s * slab] : 0.f;
+      t[q] = ok ? tgt[idx[q]] : 0.f;
+      bs[q] = (ok && bias) ? bias[c] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (idx[q] >= n) continue;
+      float a = bs[q];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) a += u[q][s];
+      y[idx[q]] = a;
+      const float d = a - t[q];
+      acc = fmaf(d, d, acc);
+      dpred[idx[q]] = d * coef;
+    }
+  }
+  const float tsum = block_sum(acc, sm);
+  if (threadIdx.x == 0) mpart[blockIdx.x] = tsum;
+}
+
 __global__ __launch_bounds__(NTHR) void mse_final_kernel(const float* __restrict__ part, int np,
                                                          float inv_n, float* __restrict__ loss, uint64_t* tick) {
   __shared__ float sm[4];
@@ -1261,6 +1305,21 @@ int pl::mse_partial_only(const float* pred, const float* tgt, int64_t n, float g
   return PL_OK;
 }
 int pl::mse_partials(int64_t n) { return mse_blocks(n); }
+
+// y = bias + slabs, dpred, MSE partials in one launch (mse_partial_from_slabs_kernel); false: shape not specialised
+bool pl::mse_from_slabs_supported(int splits, int N) { return splits == 8 && (N == 51 || N == 34); }
+int pl::mse_partial_from_slabs(const float* part, int splits, int B, int N, const float* bias, const float* tgt, float grad_scale,
+                               float* y, float* dpred, void* scratch, void* stream) {
+  if (!part || !tgt || !y || !dpred || !scratch) PL_FAIL(PL_EINVAL, "mse_partial_from_slabs: null pointer");
+  if (!mse_from_slabs_supported(splits, N) || B < 1) PL_FAIL(PL_ESHAPE, "mse_partial_from_slabs: splits=%d N=%d", splits, N);
+  const int64_t n = (int64_t)B * N;
+  const float coef = grad_scale * 2.0f / (float)n;
+  const dim3 grid(mse_blocks(n)), block(NTHR);
+  if (N == 51) hipLaunchKernelGGL((mse_partial_from_slabs_kernel<8, 51>), grid, block, 0, (hipStream_t)stream, part, B, bias, tgt, coef, y, dpred, (float*)scratch);
+  else hipLaunchKernelGGL((mse_partial_from_slabs_kernel<8, 34>), grid, block, 0, (hipStream_t)stream, part, B, bias, tgt, coef, y, dpred, (float*)scratch);
+  PL_CHECK_LAUNCH("mse_partial_from_slabs");
+  return PL_OK;
+}
 
 int pl::mse_fwd_bwd_tick(const float* pred, const float* tgt, int64_t n, float grad_scale, float* dpred,
                          float* loss_out, void* scratch, uint64_t* tick, void* stream) {

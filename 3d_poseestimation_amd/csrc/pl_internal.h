@@ -192,6 +192,10 @@ int launch_reduce_rows_multi(const float* const* part, const int* R, const int* 
                              uint64_t* loss_tick = nullptr);
 int mse_partial_only(const float* pred, const float* tgt, int64_t n, float grad_scale, float* dpred, void* scratch, void* stream);
 int mse_partials(int64_t n);
+// the output Linear's slab reduce folded into the MSE partial pass (fused train step; bit-identical to the two launches)
+bool mse_from_slabs_supported(int splits, int N);
+int mse_partial_from_slabs(const float* part, int splits, int B, int N, const float* bias, const float* tgt, float grad_scale,
+                           float* y, float* dpred, void* scratch, void* stream);
 // out[r][c] = bias[c] + sum_s slabs[s][r][c]
 int launch_reduce_slabs_bias(const float* slabs, int nslab, int rows, int cols, const float* bias,
                              float* out, hipStream_t s);
@@ -224,7 +228,9 @@ int launch_skinny_wide_in(const float* X, const float* D, float* out, int B, int
 int skinny_in_chunks(int B);
 bool skinny_narrow_out_supported(int H, int N);
 size_t skinny_narrow_out_part_floats(int B, int H);
+// part: [splits][B][64] slabs; reduce == false: only the slabs are written (y = bias + their sum is left to the caller)
 int launch_skinny_narrow_out(const float* h, const float* W, const float* bias, float* y, int B, int H,
-                             int N, float* part, hipStream_t s);
+                             int N, float* part, hipStream_t s, bool reduce = true);
+int skinny_narrow_out_splits(int B, int H);
 
 }  // namespace pl

@@ -446,13 +446,14 @@ bool skinny_narrow_out_supported(int H, int N) { return N <= 64 && H % 8 == 0; }
 size_t skinny_narrow_out_part_floats(int B, int H) { return (size_t)skinny_narrow_out_splits(B, H) * B * 64; }
 
 int launch_skinny_narrow_out(const float* h, const float* W, const float* bias, float* y, int B, int H,
-                             int N, float* part, hipStream_t s) {
+                             int N, float* part, hipStream_t s, bool reduce) {
   if (!skinny_narrow_out_supported(H, N)) PL_FAIL(PL_ESHAPE, "skinny_narrow_out: H=%d N=%d", H, N);
   const int splits = skinny_narrow_out_splits(B, H);
   const int tasks = ((B + 31) / 32) * splits;
   hipLaunchKernelGGL(skinny_narrow_out_kernel, dim3((tasks + 3) / 4), dim3(NTHR), 0, s, h, W, B, H, N, splits,
                      part);
   PL_CHECK_LAUNCH("skinny_narrow_out");
+  if (!reduce) return PL_OK;                  // the caller combines the slabs (mse_partial_from_slabs)
   const int64_t n = (int64_t)B * 64;
   hipLaunchKernelGGL(skinny_narrow_out_reduce_kernel, dim3((unsigned)((n + NTHR - 1) / NTHR)), dim3(NTHR), 0, s,
                      part, splits, B, N, bias, y);
