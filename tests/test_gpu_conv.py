@@ -641,3 +641,82 @@ def test_model3d_bf16_storage_train_step_tracks_the_fp32_grade_one(pkg):
     assert abs(l1 - l0) < 2e-2 * abs(l0), (l0, l1)
     cos = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
     assert cos > 0.98 and bool(torch.isfinite(g1).all()), cos
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 8, 8, 64, 128), (1, 6, 10, 96, 64), (3, 4, 4, 256, 256)])
+def test_deconv_planes_fwd_dgrad_wgrad_vs_torch_fp64(pkg, B, H, W, Cin, Cout):
+    """ConvTranspose2d(4, 2, 1) on the planes GEMM: forward as four 2x2-tap gathers stored in place per output parity, data
+    gradient as the gathered 4x4 stride-2 convolution, weight gradient with the roles of x and dy exchanged -- against
+    torch's conv_transpose2d in fp64."""
+    cv = importlib.import_module("3d_poseestimation_amd.conv")
+    L = pkg.lib()
+    g = torch.Generator().manual_seed(B + 7 * H + Cin + 3 * Cout)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(Cin, Cout, 4, 4, generator=g) * 0.05            # torch's ConvTranspose2d layout
+    dy = torch.randn(B, 2 * H, 2 * W, Cout, generator=g)
+    xd, wd, dyd = x.to(DEV), w.to(DEV), dy.to(DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    xp, dyp = cv._planes_of(xd, 1.0), cv._planes_of(dyd, 1.0)
+    wsub = cv._planes_of(cv.deconv_subkernels(wd), 16.0)
+    y = torch.full((B, 2 * H, 2 * W, Cout), float("nan"), device=DEV)
+    rc = L.pl_deconv4x4s2_planes_fwd(3, xp.data_ptr(), x.numel(), B, H, W, Cin, wsub.data_ptr(), wsub.numel(), Cout,
+                                     y.data_ptr(), 1.0 / 16.0, None, s)
+    assert rc == 0, L.pl_last_error()
+    x64 = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    ref = F.conv_transpose2d(x64, w64, stride=2, padding=1)
+    ref.backward(dy.double().permute(0, 3, 1, 2))
+    want = ref.detach().permute(0, 2, 3, 1)
+    assert float((y.cpu().double() - want).abs().max()) <= 3e-6 * float(want.abs().max()) * (4 * Cin) ** 0.5
+    # dx = C dy: the OHWI kernel [Cin][4][4][Cout], stride 2, pad 1
+    wc = cv._planes_of(wd.permute(0, 2, 3, 1), 16.0)
+    dx = torch.full((B, H, W, Cin), float("nan"), device=DEV)
+    rc = L.pl_conv2d_planes_fwd(3, dyp.data_ptr(), dy.numel(), B, 2 * H, 2 * W, Cout, wc.data_ptr(), w.numel(), Cin, 4, 4, 2, 1,
+                                dx.data_ptr(), 1.0 / 16.0, None, None, s)
+    assert rc == 0, L.pl_last_error()
+    wantx = x64.grad.permute(0, 2, 3, 1)
+    assert float((dx.cpu().double() - wantx).abs().max()) <= 3e-6 * float(wantx.abs().max()) * (16 * Cout) ** 0.5
+    if (B * H * W) % 32 == 0:
+        n = Cin * 16 * Cout
+        splits = L.pl_gemm_planes_splits(Cin, 16 * Cout, B * H * W)
+        slabs = torch.empty(splits * n, device=DEV) if splits > 1 else None
+        dwc = torch.full((Cin, 4, 4, Cout), float("nan"), device=DEV)
+        rc = L.pl_conv2d_planes_wgrad(3, xp.data_ptr(), x.numel(), dyp.data_ptr(), dy.numel(), B, 2 * H, 2 * W, Cout, Cin, 4, 4,
+                                      2, 1, dwc.data_ptr(), 1.0, None, slabs.data_ptr() if slabs is not None else None, s)
+        assert rc == 0, L.pl_last_error()
+        wantw = w64.grad.permute(0, 2, 3, 1)                         # [Cin][4][4][Cout]
+        assert float((dwc.cpu().double() - wantw).abs().max()) <= 3e-6 * float(wantw.abs().max()) * (B * H * W) ** 0.5
+
+
+def test_softargmax_bwd_planes_and_colsum_planes_match_the_fp32_forms(pkg):
+    """The head's last link: dlogits written as fp16 operand planes (scaled by the bound-derived power of two) carry the
+    fp32 gradient to 2^-21 of the bound, and their column sums are the bias gradient."""
+    heads = importlib.import_module("3d_poseestimation_amd.heads")
+    L = pkg.lib()
+    B, J, H, W = 3, 17, 8, 8
+    g = torch.Generator().manual_seed(5)
+    logits = (torch.randn(B, H, W, J * 64, generator=g) * 2).to(DEV)
+    gc = (torch.randn(B * J, 3, generator=g) * 1e-3).to(DEV)
+    coords = torch.empty(B * J, 3, device=DEV); stats = torch.empty(B * J, 5, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    assert L.pl_softargmax3d_nhwc_fwd(logits.data_ptr(), B, J, H, W, coords.data_ptr(), stats.data_ptr(), s) == 0
+    dl = torch.empty_like(logits)
+    assert L.pl_softargmax3d_nhwc_bwd(logits.data_ptr(), stats.data_ptr(), gc.data_ptr(), B, J, H, W, dl.data_ptr(), s) == 0
+    scale = heads._pow2_scale_for_bound(2.0 * gc.abs().sum(1).max())
+    bound = float(2.0 * gc.abs().sum(1).max())
+    assert 2 ** 13 <= bound * float(scale[0]) < 2 ** 14 and float(scale[0] * scale[1]) == 1.0
+    carrier = torch.empty_like(logits)
+    rc = L.pl_softargmax3d_nhwc_bwd_ex(logits.data_ptr(), stats.data_ptr(), gc.data_ptr(), B, J, H, W, None, carrier.data_ptr(),
+                                       3, scale.data_ptr(), s)
+    assert rc == 0, L.pl_last_error()
+    n = logits.numel()
+    pl16 = carrier.reshape(-1).view(torch.float16)
+    back = (pl16[:n].float() + pl16[n:].float() / 2048.0) * scale[1]
+    assert float((back - dl.reshape(-1)).abs().max()) <= bound * 2.0 ** -21
+    rows, cols = B * H * W, J * 64
+    db = torch.empty(cols, device=DEV)
+    scratch = torch.empty(L.pl_colsum_scratch_bytes(rows, cols), dtype=torch.uint8, device=DEV)
+    rc = L.pl_colsum_planes(carrier.data_ptr(), 3, rows, cols, scale[1:].data_ptr(), db.data_ptr(), scratch.data_ptr(), s)
+    assert rc == 0, L.pl_last_error()
+    want = dl.reshape(rows, cols).double().sum(0)
+    assert float((db.double() - want).abs().max()) <= 1e-5 * float(want.abs().max()) + bound * rows * 2.0 ** -21
