@@ -57,6 +57,11 @@ class PLAdamWPlanes(ctypes.Structure):
                 ("reserved", ctypes.c_int32), ("seg", PLAdamWSeg * ADAMW_MAX_SEGS)]
 
 
+class PLPlanesEpilogue(ctypes.Structure):
+    _fields_ = [("bias", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("resid", ctypes.c_void_p),
+                ("relu", ctypes.c_int32), ("reserved", ctypes.c_int32), ("y_planes", ctypes.c_void_p)]
+
+
 _c = ctypes
 _P = ctypes.c_void_p
 _D = ctypes.POINTER(PLDesc)
@@ -117,6 +122,7 @@ SIGNATURES = {
     "pl_bn_train_bwd": (_c.c_int, [_P, _P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _P, _P, _P, _P, _P]),
     "pl_add_relu_fwd": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P, _P]),
     "pl_mask_by_bits": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P]),
+    "pl_conv_act_plane_scale": (_c.c_float, []),
     "pl_planes_split": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_float, _P, _P]),
     "pl_bn_train_fwd_ex": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _c.c_float, _c.c_float, _P, _P, _P, _c.c_int,
                                       _P, _P, _P, _P, _P, _P, _c.c_int, _P, _P]),
@@ -158,6 +164,11 @@ SIGNATURES = {
     "pl_colsum_planes": (_c.c_int, [_P, _c.c_int, _c.c_int64, _c.c_int64, _P, _P, _P, _P]),
     "pl_deconv4x4s2_planes_fwd": (_c.c_int, [_c.c_int, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P,
                                              _c.c_int64, _c.c_int64, _P, _c.c_float, _P, _P]),
+    "pl_conv2d_planes_fwd_ep": (_c.c_int, [_c.c_int, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P,
+                                           _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_float,
+                                           _c.POINTER(PLPlanesEpilogue), _P]),
+    "pl_deconv4x4s2_planes_fwd_ep": (_c.c_int, [_c.c_int, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P,
+                                                _c.c_int64, _c.c_int64, _P, _c.c_float, _c.POINTER(PLPlanesEpilogue), _P]),
     "pl_conv2d_planes_wgrad": (_c.c_int, [_c.c_int, _P, _c.c_int64, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64,
                                           _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_float,
                                           _P, _P, _P]),

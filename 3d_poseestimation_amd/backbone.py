@@ -81,8 +81,47 @@ class ResNet(nn.Module):
                     f[name] = conv.to_ohwi(m.weight.detach().float())
                 elif isinstance(m, nn.BatchNorm2d):
                     f[name] = conv.fold_bn(m)
-            self._cache = (v, {k: (tuple(t.detach() for t in x) if isinstance(x, tuple) else x) for k, x in f.items()})
+            f = {k: (tuple(t.detach() for t in x) if isinstance(x, tuple) else x) for k, x in f.items()}
+            if self.compute_dtype in ("f16x3", "bf16p") and next(self.parameters()).is_cuda:
+                # eval mode on the planes GEMM: the kernels' operand planes, split once per set of weights
+                mode = conv._lib.PL_F16X3 if self.compute_dtype == "f16x3" else conv._lib.PL_BF16
+                for name in [k for k, x in f.items() if not isinstance(x, tuple) and k != "conv1"]:
+                    f[name + "@p"] = conv._planes_of(f[name], conv.WEIGHT_PLANE_SCALE, mode)
+            self._cache = (v, f)
         return self._cache[1]
+
+    def _forward_eval_planes(self, x_nhwc):
+        """Eval mode with every convolution but the stem on the planes GEMM (conv.conv2d_planes_eval): the folded BatchNorm /
+        ReLU / residual epilogue writes the next convolution's operand planes directly; only the block outputs exist in fp32 as
+        well (the next join adds them).  Returns (x fp32, carrier of x's planes).  Resnet.py:135-142, :65-93 under eval()."""
+        f = self._folded()
+        mode = conv._lib.PL_F16X3 if self.compute_dtype == "f16x3" else conv._lib.PL_BF16
+        cpe = conv.conv2d_planes_eval
+        with torch.no_grad():
+            s, b = f["bn1"]
+            x = conv.conv2d_nhwc(x_nhwc.float(), f["conv1"], 2, 3, s, b, relu=1, arith=self.compute_dtype)
+            x = conv.maxpool3x3s2_nhwc(x)
+            xp = conv._planes_of(x, conv.ACT_PLANE_SCALE, mode)
+            for li in (1, 2, 3, 4):
+                for bi, blk in enumerate(getattr(self, f"layer{li}")):
+                    p = f"layer{li}.{bi}"
+                    identity = x
+                    if blk.downsample is not None:
+                        s, b = f[p + ".downsample.1"]
+                        identity, _ = cpe(xp, f[p + ".downsample.0@p"], f[p + ".downsample.0"].shape, blk.stride, 0, s, b, mode=mode)
+                    s, b = f[p + ".bn1"]
+                    _, o = cpe(xp, f[p + ".conv1@p"], f[p + ".conv1"].shape, 1, 0, s, b, relu=1, want_f32=False, want_planes=True, mode=mode)
+                    s, b = f[p + ".bn2"]
+                    _, o = cpe(o, f[p + ".conv2@p"], f[p + ".conv2"].shape, blk.stride, 1, s, b, relu=1, want_f32=False, want_planes=True, mode=mode)
+                    s, b = f[p + ".bn3"]
+                    x, xp = cpe(o, f[p + ".conv3@p"], f[p + ".conv3"].shape, 1, 0, s, b, relu=2, resid=identity, want_planes=True, mode=mode)
+        return x, xp
+
+    def _planes_eval_ok(self, x_nhwc):
+        """Maps large enough for the planes path in every stage (32-bit offsets inside a tensor are the only upper limit)."""
+        B, H, W, _ = x_nhwc.shape
+        return (self.compute_dtype in ("f16x3", "bf16p") and x_nhwc.is_cuda and H % 32 == 0 and W % 32 == 0 and
+                B * (H // 4) * (W // 4) * 256 * 4 < (1 << 31))
 
     def _forward_train(self, x, want_planes=False):
         """Training mode: batch statistics, running statistics updated, differentiable (Resnet.py:135-142, :65-93)."""
@@ -155,6 +194,8 @@ class ResNet(nn.Module):
         """x [B, H, W, 3] fp32 (NHWC, as the phase4 loader delivers frames, Model.py:88) -> [B, H/32, W/32, 2048]."""
         if self.training:
             return self._forward_train(x_nhwc)
+        if self._planes_eval_ok(x_nhwc):
+            return self._forward_eval_planes(x_nhwc)[0]
         f = self._folded()
         ar = self.compute_dtype
         with torch.no_grad():
@@ -205,12 +246,28 @@ class _HeatmapNet(nn.Module):
                 f[i] = conv.deconv_subkernels(self.deconv_layers[i].weight.detach().float())
                 f[i + 1] = tuple(t.detach() for t in conv.fold_bn(self.deconv_layers[i + 1]))
             f["final"] = conv.to_ohwi(self.final_layer.weight.detach().float())
+            if self.compute_dtype in ("f16x3", "bf16p") and self.final_layer.weight.is_cuda:
+                mode = conv._lib.PL_F16X3 if self.compute_dtype == "f16x3" else conv._lib.PL_BF16
+                for i in (0, 3, 6):
+                    f[f"{i}@p"] = conv._planes_of(f[i], conv.WEIGHT_PLANE_SCALE, mode)
+                f["final@p"] = conv._planes_of(f["final"], conv.WEIGHT_PLANE_SCALE, mode)
             self._cache = (v, f)
         return self._cache[1]
 
     def heatmap_logits_nhwc(self, x_nhwc):
         """[B, 256, 256, 3] -> [B, 64, 64, J*depth]: everything in front of the soft-argmax, in the path's layout."""
         f = self._folded()
+        if not self.training and self.preact._planes_eval_ok(x_nhwc) and "final@p" in f and f["final"].shape[0] % 8 == 0:
+            # the whole eval forward on the planes GEMM: the head's transposed convolutions and final convolution as well
+            mode = conv._lib.PL_F16X3 if self.compute_dtype == "f16x3" else conv._lib.PL_BF16
+            with torch.no_grad():
+                _, outp = self.preact._forward_eval_planes(x_nhwc)
+                for i in (0, 3, 6):
+                    _, outp = conv.deconv_planes_eval(outp, f[f"{i}@p"], f[i].shape[1], f[i + 1][0], f[i + 1][1], relu=1,
+                                                      want_f32=False, want_planes=True, mode=mode)
+                y, _ = conv.conv2d_planes_eval(outp, f["final@p"], f["final"].shape, 1, 0, bias=self.final_layer.bias.detach(),
+                                               mode=mode)
+                return y
         x0 = self.preact(x_nhwc)
         with torch.no_grad():
             out = x0

@@ -432,7 +432,7 @@ def nhwc_to_nchw_autograd(x):
 # (ResNet._forward_train wires producer to consumer directly); every gradient that reaches torch code is real fp32.
 #   reference: phase4_joined/Resnet.py:56-63, 65-93 (the Bottleneck's conv1 / conv3 / downsample and their autograd)
 # ---------------------------------------------------------------------------------------------
-ACT_PLANE_SCALE = 1.0        # csrc/pl_internal.h kActPlaneScale
+ACT_PLANE_SCALE = 1.0 / 64   # csrc/pl_internal.h kConvActPlaneScale (pl_conv_act_plane_scale(): checked by the host-logic test)
 WEIGHT_PLANE_SCALE = 16.0    # kWeightPlaneScale
 
 
@@ -851,3 +851,56 @@ def conv1x1_bias_planes(xp, weight_oihw, bias, link):
     cout, cin = weight_oihw.shape[0], weight_oihw.shape[1]
     y = _ConvBiasPlanesFn.apply(xp.reshape(-1, cin), weight_oihw.float().reshape(cout, cin), bias.float(), link)
     return y.reshape(*shape[:-1], cout)
+
+
+# ---------------------------------------------------------------------------------------------
+# Eval mode on the planes GEMM: conv2d_nhwc / deconv4x4s2_nhwc with planes in (and, optionally, out)
+# ---------------------------------------------------------------------------------------------
+def _epilogue(scale, shift, bias, relu, resid, y_planes):
+    ep = _lib.PLPlanesEpilogue()
+    ep.bias = bias.data_ptr() if bias is not None else None
+    ep.scale = scale.data_ptr() if scale is not None else None
+    ep.shift = shift.data_ptr() if shift is not None else None
+    ep.resid = resid.data_ptr() if resid is not None else None
+    ep.relu = int(relu)
+    ep.y_planes = y_planes.data_ptr() if y_planes is not None else None
+    return ep
+
+
+def conv2d_planes_eval(xp, wp, w_shape, stride=1, padding=0, scale=None, shift=None, bias=None, relu=0, resid=None,
+                       want_f32=True, want_planes=False, mode=_lib.PL_F16X3):
+    """conv2d_nhwc with the input as a carrier of its planes [B,H,W,Cin] and the OHWI kernel's planes wp (w_shape):
+    returns (y fp32 or None, carrier of y's planes or None)."""
+    import ctypes
+    B, H, W, cin = xp.shape
+    cout, kh, kw, _ = w_shape
+    ho, wo = (H + 2 * padding - kh) // stride + 1, (W + 2 * padding - kw) // stride + 1
+    y = torch.empty(B, ho, wo, cout, device=xp.device) if want_f32 else None
+    yp = torch.empty(B, ho, wo, cout, device=xp.device) if want_planes else None
+    opt = [_opt(scale, "scale", cout), _opt(shift, "shift", cout), _opt(bias, "bias", cout),
+           _opt(resid, "resid", B * ho * wo * cout)]
+    ep = _epilogue(opt[0], opt[1], opt[2], relu, opt[3], yp)
+    with torch.cuda.device(xp.device):
+        rc = _lib.lib().pl_conv2d_planes_fwd_ep(mode, xp.data_ptr(), B * H * W * cin, B, H, W, cin, wp.data_ptr(),
+                                                cout * kh * kw * cin, cout, kh, kw, stride, padding,
+                                                y.data_ptr() if y is not None else None,
+                                                1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), ctypes.byref(ep),
+                                                _lib.current_stream_ptr())
+    _lib.check(rc, "pl_conv2d_planes_fwd_ep")
+    return y, yp
+
+
+def deconv_planes_eval(xp, wsubp, cout, scale=None, shift=None, relu=0, want_f32=True, want_planes=False, mode=_lib.PL_F16X3):
+    """deconv4x4s2_nhwc the same way: wsubp = planes of deconv_subkernels(weight)."""
+    import ctypes
+    B, H, W, cin = xp.shape
+    y = torch.empty(B, 2 * H, 2 * W, cout, device=xp.device) if want_f32 else None
+    yp = torch.empty(B, 2 * H, 2 * W, cout, device=xp.device) if want_planes else None
+    ep = _epilogue(_opt(scale, "scale", cout), _opt(shift, "shift", cout), None, relu, None, yp)
+    with torch.cuda.device(xp.device):
+        rc = _lib.lib().pl_deconv4x4s2_planes_fwd_ep(mode, xp.data_ptr(), B * H * W * cin, B, H, W, cin, wsubp.data_ptr(),
+                                                     16 * cout * cin, cout, y.data_ptr() if y is not None else None,
+                                                     1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), ctypes.byref(ep),
+                                                     _lib.current_stream_ptr())
+    _lib.check(rc, "pl_deconv4x4s2_planes_fwd_ep")
+    return y, yp

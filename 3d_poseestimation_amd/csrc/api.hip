@@ -883,6 +883,67 @@ extern "C" int pl_conv2d_planes_fwd(int mode, const void* x_planes, int64_t x_pl
   return launch_gemm_planes(kNT, g, (hipStream_t)stream);
 }
 
+// the folded eval-mode epilogue and the planes output of a planes convolution (PLPlanesEpilogue)
+static int apply_planes_epilogue(GemmArgs& e, int mode, const PLPlanesEpilogue* ep, int64_t n_out, const char* who) {
+  if (!ep) return PL_OK;
+  if ((ep->scale != nullptr) != (ep->shift != nullptr)) PL_FAIL(PL_EINVAL, "%s: scale without shift", who);
+  if (ep->relu < 0 || ep->relu > 2) PL_FAIL(PL_EINVAL, "%s: relu %d", who, ep->relu);
+  e.bias = ep->bias; e.col_scale = ep->scale; e.col_shift = ep->shift; e.resid = ep->resid; e.relu = ep->relu;
+  if (ep->y_planes) {
+    if ((reinterpret_cast<uintptr_t>(ep->y_planes) & 15) || (n_out & 7)) PL_FAIL(PL_EINVAL, "%s: y_planes misaligned", who);
+    e.cpl_h = static_cast<unsigned short*>(ep->y_planes);
+    e.cpl_l = e.cpl_h + n_out;
+    e.cpl_scale = kConvActPlaneScale;
+    e.cpl_kind = mode == PL_F16X3 ? 2 : 1;
+  }
+  return PL_OK;
+}
+
+extern "C" int pl_conv2d_planes_fwd_ep(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W,
+                                       int64_t Cin, const void* w_planes, int64_t w_plane, int64_t Cout, int KH, int KW,
+                                       int stride, int pad, float* y, float out_scale, const PLPlanesEpilogue* ep, void* stream) {
+  if (mode != PL_F16X3 && mode != PL_BF16) PL_FAIL(PL_EDTYPE, "pl_conv2d_planes_fwd_ep: mode %d", mode);
+  if (!x_planes || !w_planes || (!y && !(ep && ep->y_planes)) || Cout <= 0) PL_FAIL(PL_EINVAL, "pl_conv2d_planes_fwd_ep: null pointer");
+  PlanesGemmArgs g = {};
+  int64_t Ho, Wo;
+  PL_TRY(conv_planes_geom(g.e, B, H, W, Cin, KH, KW, stride, pad, &Ho, &Wo, "pl_conv2d_planes_fwd_ep"));
+  const int64_t K = (int64_t)KH * KW * Cin;
+  g.A = static_cast<const unsigned short*>(x_planes); g.B = static_cast<const unsigned short*>(w_planes);
+  g.a_plane = x_plane; g.b_plane = w_plane; g.lda = 0; g.ldb = (int)K;
+  g.mode = mode == PL_F16X3 ? 2 : 0;
+  g.out_scale = mode == PL_F16X3 ? out_scale : 1.0f;
+  g.e.C = y; g.e.M = (int)(B * Ho * Wo); g.e.N = (int)Cout; g.e.K = (int)K; g.e.ldc = (int)Cout; g.e.split_k = 1;
+  PL_TRY(apply_planes_epilogue(g.e, mode, ep, B * Ho * Wo * Cout, "pl_conv2d_planes_fwd_ep"));
+  return launch_gemm_planes(kNT, g, (hipStream_t)stream);
+}
+
+extern "C" int pl_deconv4x4s2_planes_fwd_ep(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W,
+                                            int64_t Cin, const void* wsub_planes, int64_t wsub_plane, int64_t Cout, float* y,
+                                            float out_scale, const PLPlanesEpilogue* ep, void* stream) {
+  if (mode != PL_F16X3 && mode != PL_BF16) PL_FAIL(PL_EDTYPE, "pl_deconv4x4s2_planes_fwd_ep: mode %d", mode);
+  if (!x_planes || !wsub_planes || (!y && !(ep && ep->y_planes)) || Cout <= 0) PL_FAIL(PL_EINVAL, "pl_deconv4x4s2_planes_fwd_ep: null pointer");
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || B * H * W > INT32_MAX) PL_FAIL(PL_ESHAPE, "pl_deconv4x4s2_planes_fwd_ep: bad geometry");
+  if (ep && ep->resid) PL_FAIL(PL_EINVAL, "pl_deconv4x4s2_planes_fwd_ep: no residual on a transposed convolution");
+  const int64_t K = 4 * Cin, nsub = Cout * K;
+  for (int ph = 0; ph < 2; ++ph)
+    for (int pw = 0; pw < 2; ++pw) {
+      PlanesGemmArgs g = {};
+      g.e.conv_cin = (int)Cin; g.e.conv_h = (int)H; g.e.conv_w = (int)W; g.e.conv_ho = (int)H; g.e.conv_wo = (int)W;
+      g.e.conv_kw = 2; g.e.conv_stride = 1;
+      g.e.conv_pad_h = ph ? 0 : 1; g.e.conv_pad_w = pw ? 0 : 1;
+      g.e.scat_on = 1; g.e.scat_ph = ph; g.e.scat_pw = pw;
+      g.A = static_cast<const unsigned short*>(x_planes);
+      g.B = static_cast<const unsigned short*>(wsub_planes) + (size_t)(ph * 2 + pw) * nsub;
+      g.a_plane = x_plane; g.b_plane = wsub_plane; g.lda = 0; g.ldb = (int)K;
+      g.mode = mode == PL_F16X3 ? 2 : 0;
+      g.out_scale = mode == PL_F16X3 ? out_scale : 1.0f;
+      g.e.C = y; g.e.M = (int)(B * H * W); g.e.N = (int)Cout; g.e.K = (int)K; g.e.ldc = (int)Cout; g.e.split_k = 1;
+      PL_TRY(apply_planes_epilogue(g.e, mode, ep, B * 4 * H * W * Cout, "pl_deconv4x4s2_planes_fwd_ep"));
+      PL_TRY(launch_gemm_planes(kNT, g, (hipStream_t)stream));
+    }
+  return PL_OK;
+}
+
 // nn.ConvTranspose2d(4, 2, 1, bias=False) forward on the planes GEMM: four 2x2-tap convolutions at the INPUT resolution,
 // one per output parity (no zero insertion), each storing straight into its pixels of y [B][2H][2W][Cout].
 // wsub_planes: planes of conv.deconv_subkernels(weight) = [4 parities][Cout][2][2][Cin].

@@ -1527,6 +1527,8 @@ int pl::plane_out_of(int mode, void* planes, int64_t n, float scale, const float
   return PL_OK;
 }
 
+extern "C" float pl_conv_act_plane_scale(void) { return kConvActPlaneScale; }
+
 extern "C" int pl_planes_split(const float* x, int64_t n, int mode, float scale, void* planes, void* stream) {
   if (!x || !planes || n <= 0 || !(scale > 0.f)) PL_FAIL(PL_EINVAL, "pl_planes_split: bad arguments");
   PlaneOut po;
@@ -1549,7 +1551,7 @@ extern "C" int pl_bn_train_fwd_ex(const float* z, int64_t rows, int64_t C, const
                                   int planes_mode, const float* gemm_stat, void* stream) {
   if (!z || !gamma || !beta || (!y && !y_planes) || !bits || !mean || !rstd || !scratch) PL_FAIL(PL_EINVAL, "pl_bn_train_fwd: null pointer");
   PlaneOut ypo;
-  PL_TRY(plane_out_of(planes_mode, y_planes, rows * C, kActPlaneScale, nullptr, &ypo, "pl_bn_train_fwd_ex"));
+  PL_TRY(plane_out_of(planes_mode, y_planes, rows * C, kConvActPlaneScale, nullptr, &ypo, "pl_bn_train_fwd_ex"));
   if (rows < 2 || rows > INT32_MAX || C <= 0 || (C & 3)) PL_FAIL(rows < 2 ? PL_EBATCH : PL_ESHAPE, "pl_bn_train_fwd: rows=%lld C=%lld (C %% 4 == 0, rows >= 2)", (long long)rows, (long long)C);
   hipStream_t s = (hipStream_t)stream;
   const int R = bn_replicas(rows, C);
@@ -1635,7 +1637,7 @@ extern "C" int pl_add_relu_fwd_ex(const float* a, const float* b, int64_t rows, 
   if (!a || !b || !out || !bits) PL_FAIL(PL_EINVAL, "pl_add_relu_fwd: null pointer");
   if (rows <= 0 || rows > INT32_MAX || C <= 0 || (C & 3)) PL_FAIL(PL_ESHAPE, "pl_add_relu_fwd: rows=%lld C=%lld", (long long)rows, (long long)C);
   PlaneOut po;
-  PL_TRY(plane_out_of(planes_mode, out_planes, rows * C, kActPlaneScale, nullptr, &po, "pl_add_relu_fwd_ex"));
+  PL_TRY(plane_out_of(planes_mode, out_planes, rows * C, kConvActPlaneScale, nullptr, &po, "pl_add_relu_fwd_ex"));
   const int strips = ((int)C + 255) / 256;
   dim3 grid(strips, stream_rows_grid((int)rows, strips));
   hipLaunchKernelGGL(add_relu_kernel, grid, dim3(NTHR), 0, (hipStream_t)stream, a, b, out, bits, (int)rows, (int)C, po);

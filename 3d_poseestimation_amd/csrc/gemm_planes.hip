@@ -10,6 +10,7 @@
 #include "gemm_epilogue.h"
 #include "gemm_planes16.h"
 #include "pl_internal.h"
+#include "plane_store.h"
 
 namespace pl {
 namespace {
@@ -84,6 +85,7 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
       }
     }
   }
+  const PlaneDst cpd = {e.cpl_h, e.cpl_l, e.cpl_scale, plain ? 0 : e.cpl_kind};      // the result as the next GEMM's operand planes
   if (EDGE && e.scat_on) {                       // one output parity of a transposed convolution (GemmArgs::scat_*)
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
@@ -92,13 +94,17 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
       const int c = m % e.conv_wo, t = m / e.conv_wo;
       const int a = t % e.conv_ho, b = t / e.conv_ho;
       const size_t orow = ((size_t)b * 2 * e.conv_ho + 2 * a + e.scat_ph) * 2 * e.conv_wo + 2 * c + e.scat_pw;
-      *reinterpret_cast<float4*>(C + orow * e.ldc + col0) = v[it];
+      if (C) *reinterpret_cast<float4*>(C + orow * e.ldc + col0) = v[it];
+      if (cpd.kind) store_planes4(cpd, orow * e.ldc + col0, v[it]);
     }
     return;
   }
 #pragma unroll
   for (int it = 0; it < 16; ++it)
-    if (ok(it)) *reinterpret_cast<float4*>(C + o0 + (size_t)it * 4 * e.ldc) = v[it];
+    if (ok(it)) {
+      if (C) *reinterpret_cast<float4*>(C + o0 + (size_t)it * 4 * e.ldc) = v[it];
+      if (cpd.kind) store_planes4(cpd, o0 + (size_t)it * 4 * e.ldc, v[it]);
+    }
   if (plain) return;
   if (e.stat_sum) {
     // training-mode BatchNorm partial statistics of this 64-row block (sum and M2 about the block's own mean); lanes l,
@@ -213,7 +219,7 @@ __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block
           if constexpr (MODE == plp::kF16x3) v = fmaf(acc[1][rt][ct][r], 1.0f / plp::kF16LoScale, v) * os;
           ldsw[(rt * 16 + 4 * q + r) * 68 + ct * 16 + c] = v;
         }
-    float* C = k.e.C + (k.e.split_k > 1 ? (size_t)slice * k.e.M * k.e.ldc : 0);
+    float* C = k.e.C ? k.e.C + (k.e.split_k > 1 ? (size_t)slice * k.e.M * k.e.ldc : 0) : nullptr;
     staged_epilogue<EDGE>(k, C, ldsw, m0, n0, wm, wn, lane);
   } else {
     f32x16 acc[plp::ModeCfg<MODE>::NACC][2][2];
@@ -312,10 +318,14 @@ bool is_edge(const PlanesGemmArgs& a) { return (a.e.M % 128) != 0 || (a.e.N % 12
 
 // whole 128x128 tiles, every K slice a whole number of 32-k tiles, 16-byte aligned plane rows, and every byte
 // offset the DMA's 32-bit scalar offset has to hold below 2^31
+static int splits_of(const GemmArgs& e) { return e.split_k > 1 ? e.split_k : 1; }
 bool planes_gemm_ok(GemmLayout layout, const PlanesGemmArgs& a) {
   const GemmArgs& e = a.e;
   if (a.mode != plp::kBf16 && a.mode != plp::kF16x3) return false;
-  if (!a.A || !a.B || !e.C || e.M <= 0 || e.N <= 0 || e.K <= 0) return false;
+  if (!a.A || !a.B || (!e.C && !e.cpl_kind) || e.M <= 0 || e.N <= 0 || e.K <= 0) return false;
+  if (e.cpl_kind && (!mfma16_shape() || splits_of(e) > 1 || !e.cpl_h || (e.cpl_kind == 2 && !e.cpl_l) ||
+                     ((reinterpret_cast<uintptr_t>(e.cpl_h) | reinterpret_cast<uintptr_t>(e.cpl_l)) & 7)))
+    return false;
   const int splits = e.split_k > 1 ? e.split_k : 1;
   if (e.K % (32 * splits)) return false;
   if (e.conv_cin) {
@@ -330,8 +340,7 @@ bool planes_gemm_ok(GemmLayout layout, const PlanesGemmArgs& a) {
     if (xb >= 0x7fffffe0ll) return false;
     (void)npl_;
     if (layout == kNT && ((e.conv_cin & 31) || e.K % e.conv_cin)) return false;
-    if (e.scat_on && (layout != kNT || e.split_k > 1 || e.bias || e.addend || e.resid || e.col_scale || e.relu || e.stat_sum))
-      return false;
+    if (e.scat_on && (layout != kNT || e.split_k > 1 || e.addend || e.resid || e.relu == 2 || e.stat_sum)) return false;
     if (layout == kTN && ((e.conv_cin & 7) || e.N % e.conv_cin)) return false;
   }
   if (e.M % 128 || e.N % 128) {

@@ -72,6 +72,9 @@ struct GemmArgs {
   float* bnr_part_dy;       // [M/64][N]
   float* bnr_part_dyz;      // [M/64][N]
   float* bnr_amax;          // [(M/64) * (N/64)][2] or NULL
+  // planes GEMM (staged epilogue): the result ALSO (C != NULL) or ONLY (C == NULL) as operand planes of the next GEMM --
+  // cpl_kind 0 none, 1 one bf16 plane, 2 fp16 pair (h, l) of cpl_scale * value; addressed like C (row * ldc + col)
+  unsigned short* cpl_h; unsigned short* cpl_l; float cpl_scale; int cpl_kind;
   // planes convolution launches only: row m = (b, a, c) of a conv_ho x conv_wo grid is stored at pixel
   // (b, 2a + scat_ph, 2c + scat_pw) of a [B][2 conv_ho][2 conv_wo][ldc] map (one output parity of a 4x4 stride-2
   // transposed convolution); plain stores only
@@ -105,6 +108,10 @@ struct PlaneOut {
 };
 constexpr float kActPlaneScale = 1.0f;      // activations: fp16 covers 6e-5 .. 65504 in h, the remainder in l
 constexpr float kWeightPlaneScale = 16.0f;  // weights (|w| ~ 0.03 at init): 3.8e-6 .. 4094
+// conv path: eval-mode feature maps of an unnormalised network reach 1e5 (seeded test weights: 6.7e4 after the first
+// transposed convolution) -- 1/64 keeps h finite up to 4.2e6; below |x| = 4e-3 h goes subnormal and l carries the value to
+// an absolute 1e-9 (relative 2^-22 above)
+constexpr float kConvActPlaneScale = 1.0f / 64.0f;
 
 struct PlanesGemmArgs {
   GemmArgs e;                 // M, N, K, C, ldc, split_k and the epilogue fields (A, B, lda, ldb, arith unused)

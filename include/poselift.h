@@ -256,14 +256,16 @@ int pl_mask_by_bits(const float* g, const uint64_t* bits, int64_t rows, int64_t 
  * lifter's 1024-wide Linears: the kernel that produces a tensor also writes it as 16-bit planes, the GEMM stages them by
  * LDS-DMA).  planes of an n-element tensor: planes_mode PL_F16X3 -> [2][n] fp16 (h = fp16(S x), l = fp16((S x - h) 2048)),
  * PL_BF16 -> [n] bf16; 16-byte aligned, n % 8 == 0; NULL = none.  Replaces the same reference code as the plain forms.
- *   pl_planes_split     : planes of an fp32 tensor with the static scale S (weights: 16; activations: 1)
- *   pl_bn_train_fwd_ex  : y may be NULL when only the planes are wanted (S = 1); gemm_stat (optional): the batch statistics
+ *   pl_planes_split     : planes of an fp32 tensor with the static scale S (weights: 16; conv-path activations:
+ *                         pl_conv_act_plane_scale() = 1/64 -- eval-mode maps of an unnormalised network reach 1e5)
+ *   pl_bn_train_fwd_ex  : y may be NULL when only the planes are wanted (S = pl_conv_act_plane_scale()); gemm_stat (optional): the batch statistics
  *                         as the producing GEMM's epilogue left them -- [2][pl_gemm_stat_groups(rows)][C]: per 64-row group
  *                         the column sums, then the sums of squares about the group mean -- instead of a pass over z
  *   pl_bn_train_bwd_ex  : dz may be NULL; PL_F16X3 planes hold S dz with S a power of two chosen on the device from a range
  *                         bound of dz; dz_scale (device, 2 floats) receives {S, 1/S} -- pass dz_scale + 1 as dyn_inv below
- *   pl_add_relu_fwd_ex  : out (fp32, the next join reads it) AND its planes (S = 1)
+ *   pl_add_relu_fwd_ex  : out (fp32, the next join reads it) AND its planes (S = pl_conv_act_plane_scale())
  *   pl_mask_add_by_bits : dx = (g + g2) masked (g2 may be NULL): the join's backward with the gradient sum folded in */
+float pl_conv_act_plane_scale(void);   /* S of every activation-plane output of the conv-path entries below (1/64) */
 int pl_planes_split(const float* x, int64_t n, int planes_mode, float scale, void* planes, void* stream);
 int pl_bn_train_fwd_ex(const float* z, int64_t rows, int64_t C, const float* gamma, const float* beta, float eps,
                        float momentum, float* running_mean, float* running_var, int64_t* batches, int relu,
@@ -465,6 +467,25 @@ int pl_colsum_planes(const void* planes, int planes_mode, int64_t rows, int64_t 
 int pl_deconv4x4s2_planes_fwd(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W, int64_t Cin,
                               const void* wsub_planes, int64_t wsub_plane, int64_t Cout, float* y, float out_scale,
                               const float* dyn_inv, void* stream);
+/* Eval-mode forms of the two: the Bottleneck's / the head's folded epilogue (BatchNorm on running statistics as
+ * scale / shift, bias, ReLU, residual: pl_conv2d_nhwc_fwd's) applied to the convolution's result, which is written as fp32 (y,
+ * may be NULL) and / or as operand planes for the next convolution (ep->y_planes, scale pl_conv_act_plane_scale(); NULL = none).
+ * relu: 0 none, 1 ReLU then + resid, 2 + resid then ReLU.  Reference: Resnet.py:65-93, Model.py:47-69 under model.eval(). */
+typedef struct PLPlanesEpilogue {
+  const float* bias;      /* [Cout] or NULL */
+  const float* scale;     /* [Cout] or NULL (with shift) */
+  const float* shift;
+  const float* resid;     /* [pixels][Cout] fp32 or NULL */
+  int32_t relu;
+  int32_t reserved;
+  void* y_planes;         /* planes of the result (mode as the call's), or NULL */
+} PLPlanesEpilogue;
+int pl_conv2d_planes_fwd_ep(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W, int64_t Cin,
+                            const void* w_planes, int64_t w_plane, int64_t Cout, int KH, int KW, int stride, int pad,
+                            float* y, float out_scale, const PLPlanesEpilogue* ep, void* stream);
+int pl_deconv4x4s2_planes_fwd_ep(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W,
+                                 int64_t Cin, const void* wsub_planes, int64_t wsub_plane, int64_t Cout, float* y,
+                                 float out_scale, const PLPlanesEpilogue* ep, void* stream);
 int pl_conv2d_planes_wgrad(int mode, const void* dz_planes, int64_t dz_plane, const void* x_planes, int64_t x_plane,
                            int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH, int KW, int stride,
                            int pad, float* dw, float out_scale, const float* dyn_inv, float* slabs, void* stream);

@@ -2,6 +2,7 @@
 include/poselift.h, the Python arena layout agrees with the C one, the module mirrors the
 reference's interface (names, order, shapes), and nothing computes without a GPU."""
 import ctypes
+import importlib
 import os
 import re
 
@@ -27,6 +28,8 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(raw, name), f"{name} declared in include/poselift.h but not exported"
     assert declared == set(pkg._lib.SIGNATURES), "ctypes signature table out of sync with the header"
     assert pkg.lib().pl_version() == 102
+    conv = importlib.import_module("3d_poseestimation_amd.conv")
+    assert pkg.lib().pl_conv_act_plane_scale() == conv.ACT_PLANE_SCALE      # one constant on both sides of the C ABI
 
 
 def test_entry_points_reject_bad_arguments_before_touching_a_device(pkg):
