@@ -737,9 +737,13 @@ def conv_planes(xp, weight_oihw, stride, pad, link):
 
 
 def planes_convk_supported(B, H, W, cin, cout, k, stride, pad):
+    """Whole 32-k tiles in every contraction (Cin per tap forward, Cout per tap for the data gradient, output pixels for the
+    weight gradient) and gathered tensors -- x, and the (zero-spread, for stride 2) dz map of the data gradient -- whose
+    planes stay below the DMA descriptor's 2 GiB."""
     ho, wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    big = max(B * H * W * cin, B * (H + 2) * (W + 2) * cout)
-    return cin % 32 == 0 and cout % 32 == 0 and (B * ho * wo) % 32 == 0 and big * 4 < (1 << 31)
+    hu, wu = (ho, wo) if stride == 1 else (H + 2 * pad - k + 1, W + 2 * pad - k + 1)
+    big = max(B * H * W * cin, B * hu * wu * cout)
+    return cin % 32 == 0 and cout % 32 == 0 and (B * ho * wo) % 32 == 0 and big * 2 < (1 << 31) - 64
 
 
 class _DeconvPlanesFn(torch.autograd.Function):
