@@ -186,8 +186,8 @@ class ResNet(nn.Module):
                 l1, l2, l3 = PlaneLink(), PlaneLink(), PlaneLink()
                 out = bnp(conv.conv1x1_planes(xp, blk.conv1.weight, l1), blk.bn1, True, True, l1)
                 out = bnp(conv.conv_planes(out, blk.conv2.weight, st, 1, l2), blk.bn2, True, True, l2)
-                out = bnp(conv.conv1x1_planes(out, blk.conv3.weight, l3), blk.bn3, False, False, l3)
-                x, xp = conv.add_relu_planes(out, identity, mode)
+                # bn3 and the residual join in one pass: bn3's output is never materialised
+                x, xp = conv.bn_join_planes(conv.conv1x1_planes(out, blk.conv3.weight, l3), identity, blk.bn3, l3)
         return x, xp
 
     def forward(self, x_nhwc):

@@ -559,7 +559,7 @@ class _BNPlanesFn(torch.autograd.Function):
                                       running_mean.data_ptr(), running_var.data_ptr(), batches.data_ptr(), int(relu),
                                       None if out_planes else y.data_ptr(), bits.data_ptr(), mean.data_ptr(),
                                       rstd.data_ptr(), scratch.data_ptr(), y.data_ptr() if out_planes else None,
-                                      mode, gstat.data_ptr() if gstat is not None else None, _lib.current_stream_ptr())
+                                      mode, gstat.data_ptr() if gstat is not None else None, None, _lib.current_stream_ptr())
         _lib.check(rc, "pl_bn_train_fwd_ex")
         ctx.save_for_backward(z2, bits, mean, rstd, gamma)
         ctx.shape, ctx.link = shape, link
@@ -908,3 +908,65 @@ def deconv_planes_eval(xp, wsubp, cout, scale=None, shift=None, relu=0, want_f32
                                                      _lib.current_stream_ptr())
     _lib.check(rc, "pl_deconv4x4s2_planes_fwd_ep")
     return y, yp
+
+
+
+class _BNJoinPlanesFn(torch.autograd.Function):
+    """bn3 and the residual join of a Bottleneck in ONE pass: x = relu(bn(z) + identity) as fp32 (the next join's identity) AND
+    as a carrier of its planes (the next block's convolutions) -- bn3's output is never materialised.  backward: the masked
+    sum of the two incoming gradients (pl_mask_add_by_bits) IS both the identity's gradient and bn3's dy; dz leaves as a
+    carrier of its planes (link).  Resnet.py:81-91."""
+
+    @staticmethod
+    def forward(ctx, z, identity, gamma, beta, running_mean, running_var, batches, eps, momentum, link):
+        shape = z.shape
+        C = shape[-1]
+        z2, id2 = z.contiguous().reshape(-1, C), identity.contiguous().reshape(-1, C)
+        rows = z2.shape[0]
+        dev, L = z2.device, _lib.lib()
+        x, xp = torch.empty_like(z2), torch.empty_like(z2)
+        bits = torch.empty(rows, 4 * ((C + 255) // 256), dtype=torch.int64, device=dev)
+        mean, rstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        scratch = torch.empty(L.pl_bn_train_scratch_bytes(rows, C), dtype=torch.uint8, device=dev)
+        gstat, link.stat = link.stat, None
+        with torch.cuda.device(dev):
+            rc = L.pl_bn_train_fwd_ex(z2.data_ptr(), rows, C, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
+                                      running_mean.data_ptr(), running_var.data_ptr(), batches.data_ptr(), 1, x.data_ptr(),
+                                      bits.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scratch.data_ptr(), xp.data_ptr(),
+                                      link.mode, gstat.data_ptr() if gstat is not None else None, id2.data_ptr(),
+                                      _lib.current_stream_ptr())
+        _lib.check(rc, "pl_bn_train_fwd_ex")
+        ctx.save_for_backward(z2, bits, mean, rstd, gamma)
+        ctx.shape, ctx.link = shape, link
+        return x.reshape(shape), xp.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, g, gp):
+        z2, bits, mean, rstd, gamma = ctx.saved_tensors
+        rows, C = z2.shape
+        dev, L, link = z2.device, _lib.lib(), ctx.link
+        if g is None:
+            g, gp = gp, None
+        g2 = g.contiguous().reshape(rows, C)
+        gp2 = gp.contiguous().reshape(rows, C) if gp is not None else None
+        dx = torch.empty_like(g2)                    # masked sum: the identity's gradient and bn3's dy
+        dz, dgamma, dbeta = torch.empty_like(z2), torch.empty(C, device=dev), torch.empty(C, device=dev)
+        scratch = torch.empty(L.pl_bn_train_scratch_bytes(rows, C), dtype=torch.uint8, device=dev)
+        link.dz_scale = torch.empty(2, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.pl_mask_add_by_bits(g2.data_ptr(), gp2.data_ptr() if gp2 is not None else None, bits.data_ptr(), rows, C,
+                                       dx.data_ptr(), _lib.current_stream_ptr())
+            _lib.check(rc, "pl_mask_add_by_bits")
+            # (dy = dx where the join's bitmap is set: masking the masked sum again changes nothing)
+            rc = L.pl_bn_train_bwd_ex(dx.data_ptr(), bits.data_ptr(), z2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                      gamma.data_ptr(), rows, C, None, dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(),
+                                      dz.data_ptr(), link.mode, link.dz_scale.data_ptr(), _lib.current_stream_ptr())
+        _lib.check(rc, "pl_bn_train_bwd_ex")
+        return dz.reshape(ctx.shape), dx.reshape(ctx.shape), dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_join_planes(z, identity, bn, link):
+    if bn.momentum is None:
+        raise NotImplementedError("cumulative moving average (momentum=None)")
+    return _BNJoinPlanesFn.apply(z, identity, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                 float(bn.eps), float(bn.momentum), link)

@@ -311,7 +311,10 @@ __global__ __launch_bounds__(NTHR) void mask_by_bits_kernel(const float* __restr
 __device__ __forceinline__ void bn_apply_rows(
     const float* __restrict__ z, const float4 sc, const float4 sh, const float* resid, float* act,
     uint64_t* __restrict__ bits, int B, int H, int mode, bool norelu, uint32_t thr, float kscale, uint32_t k0,
-    uint32_t k1, uint32_t c3, uint32_t layer, const uint64_t* __restrict__ inject, const PlaneDst& pd) {
+    uint32_t k1, uint32_t c3, uint32_t layer, const uint64_t* __restrict__ inject, const PlaneDst& pd,
+    bool resid_first = false) {
+  // resid_first: resid joins BEFORE the ReLU -- relu(bn(z) + resid), the Bottleneck's join (Resnet.py:90-91) -- instead of
+  // after it (the lifter's block: x + relu(bn(z)))
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int strip = blockIdx.x;
   const int c = strip * 256 + lane * 4;
@@ -325,6 +328,10 @@ __device__ __forceinline__ void bn_apply_rows(
       const float4 v = ld4(z + off);
       y[0] = fmaf(v.x, sc.x, sh.x); y[1] = fmaf(v.y, sc.y, sh.y);
       y[2] = fmaf(v.z, sc.z, sh.z); y[3] = fmaf(v.w, sc.w, sh.w);
+      if (resid_first && resid) {
+        const float4 rv = ld4(resid + off);
+        y[0] += rv.x; y[1] += rv.y; y[2] += rv.z; y[3] += rv.w;
+      }
       if (mode == 1) {
         const uint64_t g = ((uint64_t)r * (uint64_t)H + (uint64_t)c) >> 2;
         const Philox4 u = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), layer, c3, k0, k1);
@@ -354,7 +361,7 @@ __device__ __forceinline__ void bn_apply_rows(
     if (lane < 4) bits[(size_t)r * wpr + strip * 4 + lane] = word;
     if (active) {
       float4 out = make_float4(o[0], o[1], o[2], o[3]);
-      if (resid) {
+      if (resid && !resid_first) {
         const float4 rv = ld4(resid + off);
         out.x += rv.x; out.y += rv.y; out.z += rv.z; out.w += rv.w;
       }
@@ -379,12 +386,12 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(
   }
   // Hc: real columns behind the H virtual ones (bn_colstats_kernel); Hc == H for the lifter
   // mode: 0 keep all, 1 philox, 2 injected bitmap, 3 drop all; + 8: no ReLU (BatchNorm alone; bitmap all ones)
-  const bool norelu = (mode & 8) != 0;
+  const bool norelu = (mode & 8) != 0, resid_first = (mode & 32) != 0;      // + 32: the residual joins before the ReLU
   mode &= 7;
   const int c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < H && scale) { sc = ld4(scale + c % Hc); sh = ld4(shift + c % Hc); }
-  bn_apply_rows(z, sc, sh, resid, act, bits, B, H, mode, norelu, thr, kscale, k0, k1, c3, layer, inject, pd);
+  bn_apply_rows(z, sc, sh, resid, act, bits, B, H, mode, norelu, thr, kscale, k0, k1, c3, layer, inject, pd, resid_first);
 }
 
 // -------------------------------------------------------------------------------------
@@ -1541,14 +1548,14 @@ extern "C" int pl_bn_train_fwd(const float* z, int64_t rows, int64_t C, const fl
                                float* y, uint64_t* bits, float* mean, float* rstd, void* scratch, void* stream) {
   if (!y) PL_FAIL(PL_EINVAL, "pl_bn_train_fwd: null pointer");
   return pl_bn_train_fwd_ex(z, rows, C, gamma, beta, eps, momentum, running_mean, running_var, batches, relu, y, bits, mean,
-                            rstd, scratch, nullptr, 0, nullptr, stream);
+                            rstd, scratch, nullptr, 0, nullptr, nullptr, stream);
 }
 
 // + y_planes (optional): the output also / only (y == NULL) as operand planes of the next 1x1 convolution's planes GEMM
 extern "C" int pl_bn_train_fwd_ex(const float* z, int64_t rows, int64_t C, const float* gamma, const float* beta, float eps,
                                   float momentum, float* running_mean, float* running_var, int64_t* batches, int relu,
                                   float* y, uint64_t* bits, float* mean, float* rstd, void* scratch, void* y_planes,
-                                  int planes_mode, const float* gemm_stat, void* stream) {
+                                  int planes_mode, const float* gemm_stat, const float* join, void* stream) {
   if (!z || !gamma || !beta || (!y && !y_planes) || !bits || !mean || !rstd || !scratch) PL_FAIL(PL_EINVAL, "pl_bn_train_fwd: null pointer");
   PlaneOut ypo;
   PL_TRY(plane_out_of(planes_mode, y_planes, rows * C, kConvActPlaneScale, nullptr, &ypo, "pl_bn_train_fwd_ex"));
@@ -1586,8 +1593,11 @@ extern "C" int pl_bn_train_fwd_ex(const float* z, int64_t rows, int64_t C, const
   }
   const int strips = (H + 255) / 256;
   dim3 grid(strips, stream_rows_grid(B, strips));
-  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NTHR), 0, s, z, scale, shift, (const float*)nullptr, y, bits, B, H,
-                     relu ? 0 : 8, 0u, 1.0f, 0u, 0u, 0u, 0u, (const uint64_t*)nullptr, Hc, ypo, (const uint64_t*)nullptr, 0u);
+  // join (optional): y = relu(bn(z) + join) in this one pass -- the Bottleneck's bn3 and residual join (needs relu != 0)
+  if (join && !relu) PL_FAIL(PL_EINVAL, "pl_bn_train_fwd_ex: a join without its ReLU");
+  hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NTHR), 0, s, z, scale, shift, join, y, bits, B, H,
+                     (relu ? 0 : 8) | (join ? 32 : 0), 0u, 1.0f, 0u, 0u, 0u, 0u, (const uint64_t*)nullptr, Hc, ypo,
+                     (const uint64_t*)nullptr, 0u);
   PL_CHECK_LAUNCH("bn_apply");
   return PL_OK;
 }

@@ -261,6 +261,8 @@ int pl_mask_by_bits(const float* g, const uint64_t* bits, int64_t rows, int64_t 
  *   pl_bn_train_fwd_ex  : y may be NULL when only the planes are wanted (S = pl_conv_act_plane_scale()); gemm_stat (optional): the batch statistics
  *                         as the producing GEMM's epilogue left them -- [2][pl_gemm_stat_groups(rows)][C]: per 64-row group
  *                         the column sums, then the sums of squares about the group mean -- instead of a pass over z
+ *                         join (optional, relu != 0): y = relu(bn(z) + join) in the same pass -- the Bottleneck's bn3 and
+ *                         residual join (Resnet.py:81-91); bits then is the join's ReLU bitmap
  *   pl_bn_train_bwd_ex  : dz may be NULL; PL_F16X3 planes hold S dz with S a power of two chosen on the device from a range
  *                         bound of dz; dz_scale (device, 2 floats) receives {S, 1/S} -- pass dz_scale + 1 as dyn_inv below
  *   pl_add_relu_fwd_ex  : out (fp32, the next join reads it) AND its planes (S = pl_conv_act_plane_scale())
@@ -270,7 +272,7 @@ int pl_planes_split(const float* x, int64_t n, int planes_mode, float scale, voi
 int pl_bn_train_fwd_ex(const float* z, int64_t rows, int64_t C, const float* gamma, const float* beta, float eps,
                        float momentum, float* running_mean, float* running_var, int64_t* batches, int relu,
                        float* y, uint64_t* bits, float* mean, float* rstd, void* scratch, void* y_planes,
-                       int planes_mode, const float* gemm_stat, void* stream);
+                       int planes_mode, const float* gemm_stat, const float* join, void* stream);
 int pl_bn_train_bwd_ex(const float* dy, const uint64_t* bits, const float* z, const float* mean, const float* rstd,
                        const float* gamma, int64_t rows, int64_t C, float* dz, float* dgamma, float* dbeta,
                        void* scratch, void* dz_planes, int planes_mode, float* dz_scale, void* stream);
