@@ -421,7 +421,7 @@ def main():
                            "fp32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)",
                            "bf16": "bf16 MFMA (v_mfma_f32_32x32x16_bf16), operands rounded to bf16, fp32 accumulate",
                            "bf16x6": "bf16 MFMA, three-way operand split x 6 products (fp32-grade), fp32 accumulate and storage",
-                           "f16x3": "fp16 MFMA (v_mfma_f32_32x32x16_f16), operands as two fp16 planes (22-23 bits) x 3 "
+                           "f16x3": "fp16 MFMA (v_mfma_f32_16x16x32_f16), operands as two fp16 planes (22-23 bits) x 3 "
                                     "products on two fp32 accumulators (fp32-grade); planes staged by LDS-DMA"}[a.dtype]},
             "step_tflops": round(value * FLOP_PER_POSE / 1e12, 2),
             "step_frac_of_matrix_peak": round(value * FLOP_PER_POSE / 1e12 / (
