@@ -15,7 +15,9 @@
 // mid-step barrier A[0,1] and B of tile kt+1 are read under the MFMAs of A[2,3].
 // (Tried: the loader waves, idle after their last DMA issue, touching every line the dX epilogue will load -- skip
 //  gradient, saved z, bitmap -- two K tiles ahead, as the youngest loads of their queue: 0.6175 / 0.6156 ms per step
-//  against 0.6104 / 0.6197 without, same box.  The epilogue is not waiting on HBM latency; not kept.)
+//  against 0.6104 / 0.6197 without, same box.  The epilogue is not waiting on HBM latency; not kept.  The other end of the
+//  main loop -- every computing wave touching its block's lines BEFORE the loop, by LDS-DMA into a scratch KiB (no register,
+//  no wait), so that the burst would find them in the memory-side cache: 0.6395 / 0.6349 against 0.6269 / 0.6221: worse.)
 #pragma once
 #include "gemm_planes.h"
 
