@@ -282,6 +282,81 @@ def test_two_rank_rccl_on_two_gpus():
     assert sorted(q.get(timeout=5) for _ in range(2)) == [0, 1]
 
 
+def _rccl_one_rank_worker(port, q):
+    """Every torch.distributed call the data-parallel step makes, on the REAL RCCL backend with a one-rank group (what a
+    1-GPU box can run): communicator creation with device_id, async all-reduce of arena slices launched between the
+    backward's layer ranges, wait(), in-place all_gather_into_tensor of the SyncBN slabs, broadcast, barrier."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import importlib
+    import torch.distributed as dist
+    pkg = importlib.import_module("3d_poseestimation_amd")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+
+    class PretendPeer(pkg.dp.GradSync):
+        """reports a second rank so that backward takes the bucketed route; the sum over one rank is the identity"""
+        launched = 0
+
+        def world(self):
+            return 2
+
+        def launch_bucket(self, flat_slice):
+            PretendPeer.launched += 1
+            super().launch_bucket(flat_slice)
+
+        def __call__(self, model):
+            super().__call__(model)
+            return 1.0
+
+    xs, ys = pkg.synth.synthetic_batch(512, 21, dev)
+
+    def run(sync):
+        torch.manual_seed(0)
+        m = pkg.LinearModel(34, 51, linear_size=1024, p_dropout=0.5).to(dev).train()
+        m.manual_seed(7)
+        pkg.dp.broadcast_model(m)
+        opt = pkg.FlatAdamW(m, lr=1e-3)
+        m.set_grad_sync(sync)
+        for _ in range(3):
+            pkg.train_step(m, opt, xs, ys, grad_sync=sync)
+        # and the autograd route (backward launches the buckets from pl_lifter_bwd_layers)
+        opt.zero_grad()
+        pkg.mse_loss(m(xs).reshape(-1, 17, 3), ys).backward()
+        opt.step(grad_scale=sync(m) if sync is not None else 1.0)
+        torch.cuda.synchronize()
+        return m.flat_params.clone()
+
+    a = run(PretendPeer(overlap=True))
+    assert PretendPeer.launched >= 8, PretendPeer.launched      # 4 steps x (at least) 2 buckets
+    b = run(PretendPeer(overlap=False))
+    c = run(None)
+    assert torch.equal(a, c) and torch.equal(b, c), "RCCL buckets on arena slices changed the single-rank result"
+    slabs = torch.arange(2048, dtype=torch.float32, device=dev).view(1, 2048).clone()
+    keep = slabs.clone()
+    pkg.dp.all_gather_slabs(slabs)                     # in place: input is slab `rank` of the output
+    torch.cuda.synchronize()
+    assert torch.equal(slabs, keep)
+    t = torch.ones(18, device=dev)
+    dist.all_reduce(t)
+    dist.barrier()
+    assert float(t.sum()) == 18.0
+    dist.destroy_process_group()
+    q.put(0)
+
+
+def test_one_rank_rccl_api_on_one_gpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_one_rank_worker, args=(_free_port(), q))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0
+    assert q.get(timeout=5) == 0
+
+
 def test_two_rank_rehearsal_on_one_gpu():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -1,7 +1,7 @@
 import importlib, sys, time, torch
 sys.path.insert(0, "/root/repo")
 pkg = importlib.import_module("3d_poseestimation_amd")
-for dt in ("bf16x6", "bf16"):
+for dt in ("f16x3", "bf16"):
     torch.manual_seed(0)
     m = pkg.LinearModel(34, 51, compute_dtype=dt).cuda().train()
     opt = pkg.FlatAdamW(m, lr=1e-4)
