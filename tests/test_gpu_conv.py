@@ -138,6 +138,51 @@ def test_g9_resnet50_eval_forward_vs_reference(pkg):
     assert np.abs(cm - g["channel_mean"]).max() < 2e-4 * scale
 
 
+@pytest.mark.parametrize("dtype", ["f16x3", "bf16x6"])
+def test_g11_resnet50_training_pass_vs_reference(pkg, dtype):
+    """ONE training-mode forward + backward of the phase4 backbone against phase4_joined/Resnet.py imported and run
+    as-is in float64 (golden g11: 4 frames of 128 x 128, loss = mean(features^2)): features, every parameter's gradient,
+    the BatchNorm running statistics after the pass.  Tolerances: the fixture carries, per tensor, how far the
+    REFERENCE'S OWN float32 run is from the float64 one ("floor": 1e-5 at the top of the stack, 1-2 % below the
+    BatchNorm layers, whose backward leaves what survives a cancellation); this library's fp32-grade arithmetic gets
+    1.5 x that + 1e-4 (measured: a twentieth of it).  Running statistics and features do not cancel: 1e-5 / 3 x floor."""
+    from conftest import load_golden
+    g = load_golden("g11_resnet50_train.npz")
+    net = pkg.ResNet("resnet50", compute_dtype=dtype).train()
+    net.load_state_dict(pkg.synth.seeded_state(net.state_dict(), int(g["weight_seed"])))
+    net = net.to(DEV)
+    n, size = (int(v) for v in g["frames"])
+    frames = pkg.synth.seeded_frames(n, int(g["frame_seed"]), size).to(DEV)
+    feat = net(frames)                                        # NHWC
+    loss = feat.pow(2).mean()
+    loss.backward()
+    nchw = feat.detach().permute(0, 3, 1, 2).contiguous().cpu().double()
+    assert tuple(nchw.shape) == tuple(g["feat_shape"])
+    fs = g["feat_sample"]
+    assert np.abs(nchw.reshape(-1)[::7].numpy() - fs).max() < 3 * float(g["feat_floor"]) * np.abs(fs).max() + 1e-6
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-4 * abs(float(g["loss"]))
+    worst = []
+    for k, p in net.named_parameters():
+        want = g["gsample:" + k]
+        got = p.grad.detach().cpu().double().reshape(-1)
+        assert abs(float(got.norm()) - float(g["gnorm:" + k])) <= (1.5 * float(g["gfloor:" + k]) + 1e-4) * float(g["gnorm:" + k]), k
+        stride = max(1, got.numel() // 64)
+        # the 64 samples carry 64 / numel of the squared norm on average: scale the bound by the samples' own share
+        tol = (1.5 * float(g["gfloor:" + k]) + 1e-4) * float(g["gnorm:" + k]) * max(1.0, (64.0 / got.numel()) ** 0.5 * 8)
+        err = float(np.abs(got[::stride][:64].numpy() - want).max())
+        worst.append((err / tol, k))
+        assert err <= tol, (k, err, tol)
+    if os.environ.get("POSELIFT_TEST_VERBOSE"):
+        print("g11 worst sample error / tolerance:", sorted(worst)[-4:])
+    for k, v in net.state_dict().items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            want = g["stat:" + k]
+            got = v.detach().cpu().double().reshape(-1)[::max(1, v.numel() // 32)][:32].numpy()
+            assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max()), k
+        elif k.endswith("num_batches_tracked"):
+            assert int(v) == int(g["stat:" + k]), k
+
+
 def test_model3d_eval_forward_vs_torch_cpu(pkg):
     """Model_3D.forward (phase4_joined/Model.py:83-137) end to end -- backbone, three deconvolutions, final
     1x1 convolution, integral soft-argmax -- against the same stock nn modules run by PyTorch on the CPU plus
