@@ -703,17 +703,41 @@ class _ConvKxKPlanesFn(torch.autograd.Function):
         npl = 2 if mode == _lib.PL_F16X3 else 1
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wf = _planes_of(w.flip(1, 2).permute(3, 1, 2, 0), WEIGHT_PLANE_SCALE, mode)    # [Cin][KH][KW][Cout]
-            if stride == 1:
-                src, shape = dzp, (B, ho, wo, cout)
+            even = stride == 2 and H % 2 == 0 and W % 2 == 0 and 2 * ho == H and 2 * wo == W
+            if even and kh == 1 and kw == 1 and pad == 0 and planes_conv_supported(B * ho * wo, cin, cout):
+                # 1x1 stride 2 (the downsample): dz W at the output resolution, placed on the even pixels of a zero map
+                wtp = _planes_of(w.reshape(cout, cin).t(), WEIGHT_PLANE_SCALE, mode)
+                low = _gemm_planes_raw(0, dzp, (B * ho * wo, cout), wtp, (cin, cout), B * ho * wo, cin, cout,
+                                       1.0 / WEIGHT_PLANE_SCALE, inv, mode)
+                dx = torch.empty(B, H, W, cin, device=dzp.device)
+                with torch.cuda.device(dzp.device):
+                    rc = _lib.lib().pl_upsample2x_zero_nhwc(low.data_ptr(), B, ho, wo, cin, dx.data_ptr(), _lib.current_stream_ptr())
+                _lib.check(rc, "pl_upsample2x_zero_nhwc")
+            elif even and kh == 3 and kw == 3 and pad == 1 and planes_deconv_supported(B, ho, wo, cout, cin):
+                # 3x3 stride 2 pad 1: its transpose is ConvTranspose2d(4, 2, 1) with this filter in the top-left 3x3 of a
+                # zero 4x4 one (ih = 2 oh - 1 + kh) -- four 2x2-tap gathers at the OUTPUT resolution, 4 taps per input
+                # pixel instead of the 9 of the stride-1 gather over a zero-spread map (and no map to fill)
+                w4 = torch.zeros(cout, cin, 4, 4, device=w.device)
+                w4[:, :, :3, :3] = w.permute(0, 3, 1, 2)
+                wsub = _planes_of(deconv_subkernels(w4), WEIGHT_PLANE_SCALE, mode)
+                dx = torch.empty(B, H, W, cin, device=dzp.device)
+                with torch.cuda.device(dzp.device):
+                    rc = _lib.lib().pl_deconv4x4s2_planes_fwd(mode, dzp.data_ptr(), B * ho * wo * cout, B, ho, wo, cout,
+                                                              wsub.data_ptr(), wsub.numel(), cin, dx.data_ptr(),
+                                                              1.0 / WEIGHT_PLANE_SCALE, inv.data_ptr(), _lib.current_stream_ptr())
+                _lib.check(rc, "pl_deconv4x4s2_planes_fwd")
+            elif stride == 1:
+                wf = _planes_of(w.flip(1, 2).permute(3, 1, 2, 0), WEIGHT_PLANE_SCALE, mode)    # [Cin][KH][KW][Cout]
+                dx = _conv_planes_fwd(dzp, (B, ho, wo, cout), wf, (cin, kh, kw, cout), 1, kh - 1 - pad, 1.0 / WEIGHT_PLANE_SCALE, inv, mode)
             else:
+                wf = _planes_of(w.flip(1, 2).permute(3, 1, 2, 0), WEIGHT_PLANE_SCALE, mode)
                 # dz at the even pixels of a zero map the size the stride-1 gradient expects (planes are 16-bit: as int16)
                 hu, wu = H + 2 * pad - kh + 1, W + 2 * pad - kw + 1
                 up = torch.zeros(2, B, hu, wu, cout, dtype=torch.int16, device=dzp.device)
                 up[:npl, :, ::stride, ::stride][:, :, :ho, :wo] = \
                     dzp.reshape(-1).view(torch.int16)[:npl * B * ho * wo * cout].reshape(npl, B, ho, wo, cout)
                 src, shape = up.reshape(-1).view(torch.float32).reshape(B, hu, wu, cout), (B, hu, wu, cout)
-            dx = _conv_planes_fwd(src, shape, wf, (cin, kh, kw, cout), 1, kh - 1 - pad, 1.0 / WEIGHT_PLANE_SCALE, inv, mode)
+                dx = _conv_planes_fwd(src, shape, wf, (cin, kh, kw, cout), 1, kh - 1 - pad, 1.0 / WEIGHT_PLANE_SCALE, inv, mode)
         if ctx.needs_input_grad[1]:
             L = _lib.lib()
             n = cout * kh * kw * cin

@@ -602,6 +602,48 @@ def _planes(pkg, t, scale=1.0):
     return cv._planes_of(t, scale)
 
 
+@pytest.mark.parametrize("mode", ["f16x3", "bf16p"])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,K,pad,route", [
+    (2, 16, 24, 32, 128, 3, 1, "transposed 4x4"),     # layer2.0 / 3.0 / 4.0 conv2 in small
+    (2, 8, 8, 128, 96, 1, 0, "low-res GEMM"),          # the stride-2 downsample
+    (2, 7, 7, 64, 64, 1, 0, "zero-spread map"),        # odd maps (2 Ho != H): the general route
+    (2, 7, 7, 32, 64, 3, 1, "zero-spread map"),
+])
+def test_conv_planes_stride2_autograd_vs_torch_fp64(pkg, mode, B, H, W, Cin, Cout, K, pad, route):
+    """Backward of a stride-2 planes convolution through its autograd node (conv._ConvKxKPlanesFn): dz arrives as a carrier of
+    planes, the data gradient takes one of three routes -- ConvTranspose2d(4, 2, 1) gathers with the 3x3 filter in a zero
+    4x4 one, a GEMM at the output resolution spread over the even pixels (1x1), or the stride-1 gather over a zero-spread
+    map (everything else) -- and all three, with the weight gradient, match torch's conv2d in fp64."""
+    from importlib import import_module
+    cv = import_module("3d_poseestimation_amd.conv")
+    lib_mode = {"f16x3": pkg._lib.PL_F16X3, "bf16p": pkg._lib.PL_BF16}[mode]
+    g = torch.Generator().manual_seed(B * 7 + H * 31 + Cin + Cout + K)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) * 0.05                        # the nn.Conv2d parameter
+    Ho, Wo = (H + 2 * pad - K) // 2 + 1, (W + 2 * pad - K) // 2 + 1
+    dz = torch.randn(B, Ho, Wo, Cout, generator=g)
+    link = cv.PlaneLink(lib_mode)
+    link.dz_scale = torch.tensor([1.0, 1.0, 1.0], device=DEV)                    # {S, 1/S}: dz planes unscaled here
+    xp = cv._planes_of(x.to(DEV), cv.ACT_PLANE_SCALE, lib_mode).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    z = cv.conv_planes(xp, wd, 2, pad, link)
+    z.backward(cv._planes_of(dz.to(DEV), 1.0, lib_mode))
+    x64 = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    ref = F.conv2d(x64, w64, stride=2, padding=pad)
+    ref.backward(dz.double().permute(0, 3, 1, 2))
+    # bf16 storage: operands carry 8 bits; fp32-grade: the bound of an fp32 evaluation
+    tol = 2e-2 if mode == "bf16p" else 3e-6
+    nterm = (K * K * Cout) ** 0.5
+    assert float((z.detach().cpu().double() - ref.detach().permute(0, 2, 3, 1)).abs().max()) <= tol * float(ref.abs().max()) * 4
+    want = x64.grad.permute(0, 2, 3, 1)
+    got = xp.grad.cpu().double()
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= tol * float(want.abs().max()) * nterm, route
+    wantw = w64.grad
+    assert float((wd.grad.cpu().double() - wantw).abs().max()) <= tol * float(wantw.abs().max()) * (B * Ho * Wo) ** 0.5, route
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,K,stride,pad", [
     (2, 16, 16, 64, 64, 3, 1, 1),        # layer1's conv2 in small: a 64-wide tile hanging over N
     (2, 16, 24, 32, 128, 3, 2, 1),       # stride 2, one 32-k tile per tap
