@@ -504,10 +504,13 @@ class _Conv1x1PlanesFn(torch.autograd.Function):
         ctx.save_for_backward(xp, w)
         ctx.link = link
         ctx.mark_non_differentiable(stat)
+        ctx.set_materialize_grads(False)       # (no zero tensor the size of `stat` per backward)
         return z, stat
 
     @staticmethod
     def backward(ctx, dzp, _gstat):
+        if dzp is None:
+            return None, None, None
         xp, w = ctx.saved_tensors
         rows, cin = xp.shape
         cout = w.shape[0]
@@ -616,6 +619,7 @@ class _AddReLUPlanesFn(torch.autograd.Function):
         _lib.check(rc, "pl_add_relu_fwd_ex")
         ctx.save_for_backward(bits)
         ctx.shape = a.shape
+        ctx.set_materialize_grads(False)       # an unused output's gradient arrives as None, not as a zero map
         return out.reshape(a.shape), outp.reshape(a.shape)
 
     @staticmethod
@@ -624,6 +628,8 @@ class _AddReLUPlanesFn(torch.autograd.Function):
         C = ctx.shape[-1]
         if g is None:
             g, gp = gp, None
+        if g is None:
+            return None, None, None
         g2 = g.contiguous().reshape(-1, C)
         gp2 = gp.contiguous().reshape(-1, C) if gp is not None else None
         dx = torch.empty_like(g2)
@@ -689,10 +695,13 @@ class _ConvKxKPlanesFn(torch.autograd.Function):
         ctx.save_for_backward(xp, w)
         ctx.geom, ctx.link = (stride, pad), link
         ctx.mark_non_differentiable(stat)
+        ctx.set_materialize_grads(False)
         return z, stat
 
     @staticmethod
     def backward(ctx, dzp, _gstat):
+        if dzp is None:
+            return None, None, None, None, None
         xp, w = ctx.saved_tensors
         stride, pad = ctx.geom
         B, H, W, cin = xp.shape
@@ -962,6 +971,7 @@ class _BNJoinPlanesFn(torch.autograd.Function):
         _lib.check(rc, "pl_bn_train_fwd_ex")
         ctx.save_for_backward(z2, bits, mean, rstd, gamma)
         ctx.shape, ctx.link = shape, link
+        ctx.set_materialize_grads(False)
         return x.reshape(shape), xp.reshape(shape)
 
     @staticmethod
@@ -971,6 +981,8 @@ class _BNJoinPlanesFn(torch.autograd.Function):
         dev, L, link = z2.device, _lib.lib(), ctx.link
         if g is None:
             g, gp = gp, None
+        if g is None:
+            return (None,) * 10
         g2 = g.contiguous().reshape(rows, C)
         gp2 = gp.contiguous().reshape(rows, C) if gp is not None else None
         dx = torch.empty_like(g2)                    # masked sum: the identity's gradient and bn3's dy
