@@ -180,8 +180,9 @@ class ResNet(nn.Module):
                 identity = x
                 if blk.downsample is not None:
                     lk = PlaneLink()
-                    zd = (conv.conv1x1_planes(xp, blk.downsample[0].weight, lk) if st == 1 else
-                          conv.conv_planes(xp, blk.downsample[0].weight, st, 0, lk))
+                    xd = conv.planes_twin(x, xp)     # the same planes; the gradient goes to x (conv._PlanesTwinFn)
+                    zd = (conv.conv1x1_planes(xd, blk.downsample[0].weight, lk) if st == 1 else
+                          conv.conv_planes(xd, blk.downsample[0].weight, st, 0, lk))
                     identity = bnp(zd, blk.downsample[1], False, False, lk)
                 l1, l2, l3 = PlaneLink(), PlaneLink(), PlaneLink()
                 out = bnp(conv.conv1x1_planes(xp, blk.conv1.weight, l1), blk.bn1, True, True, l1)

@@ -676,6 +676,26 @@ def _conv_planes_fwd(xp, x_shape, wp, w_shape, stride, pad, out_scale, dyn_inv=N
     return y
 
 
+class _PlanesTwinFn(torch.autograd.Function):
+    """xp (the carrier of x's planes) presented as a function of x, the fp32 twin the same kernel wrote.  A block with a
+    downsample branch reads its input's planes twice (conv1, downsample[0]) and its fp32 twin not at all: routing the
+    downsample's input gradient to x instead of xp hands the producing join's backward its two gradients separately -- it
+    adds them inside its masked pass (pl_mask_add_by_bits) -- where autograd would otherwise sum two maps for xp with a
+    pass of its own (1 GB each at layer2.0, B = 256)."""
+
+    @staticmethod
+    def forward(ctx, x, xp):
+        return xp.view_as(xp)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def planes_twin(x, xp):
+    return _PlanesTwinFn.apply(x, xp.detach()) if x.requires_grad else xp
+
+
 class _ConvKxKPlanesFn(torch.autograd.Function):
     """KxK convolution (the Bottleneck's conv2, the stride-2 downsample) on the planes GEMM with the input gathered by the
     loader waves: xp carrier of x's planes [B][H][W][Cin], w OHWI fp32 -> z [B][Ho][Wo][Cout] fp32.  backward takes dz as a
