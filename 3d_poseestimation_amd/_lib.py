@@ -130,6 +130,7 @@ SIGNATURES = {
     "pl_bn_train_bwd_ex": (_c.c_int, [_P, _P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _P, _P, _P, _P, _P, _c.c_int, _P, _P]),
     "pl_add_relu_fwd_ex": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P, _P, _c.c_int, _P]),
     "pl_mask_add_by_bits": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _P, _P]),
+    "pl_bn_join_bwd": (_c.c_int, [_P, _P, _P, _P, _P, _P, _P, _c.c_int64, _c.c_int64, _P, _P, _P, _P, _P, _P, _c.c_int, _P, _P]),
     "pl_maxpool3x3s2_nhwc": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P]),
     "pl_maxpool3x3s2_nhwc_bwd": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P]),
     "pl_maxpool3x3s2_nhwc_idx": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _P]),

@@ -1010,14 +1010,22 @@ class _BNJoinPlanesFn(torch.autograd.Function):
         scratch = torch.empty(L.pl_bn_train_scratch_bytes(rows, C), dtype=torch.uint8, device=dev)
         link.dz_scale = torch.empty(2, device=dev)
         with torch.cuda.device(dev):
-            rc = L.pl_mask_add_by_bits(g2.data_ptr(), gp2.data_ptr() if gp2 is not None else None, bits.data_ptr(), rows, C,
-                                       dx.data_ptr(), _lib.current_stream_ptr())
-            _lib.check(rc, "pl_mask_add_by_bits")
-            # (dy = dx where the join's bitmap is set: masking the masked sum again changes nothing)
-            rc = L.pl_bn_train_bwd_ex(dx.data_ptr(), bits.data_ptr(), z2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                      gamma.data_ptr(), rows, C, None, dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(),
-                                      dz.data_ptr(), link.mode, link.dz_scale.data_ptr(), _lib.current_stream_ptr())
-        _lib.check(rc, "pl_bn_train_bwd_ex")
+            if C >= 256:
+                # one pass writes the masked sum and takes BatchNorm-backward's column sums of it (pl_bn_join_bwd)
+                rc = L.pl_bn_join_bwd(g2.data_ptr(), gp2.data_ptr() if gp2 is not None else None, bits.data_ptr(), z2.data_ptr(),
+                                      mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), rows, C, dx.data_ptr(), None,
+                                      dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(), dz.data_ptr(), link.mode,
+                                      link.dz_scale.data_ptr(), _lib.current_stream_ptr())
+                _lib.check(rc, "pl_bn_join_bwd")
+            else:
+                rc = L.pl_mask_add_by_bits(g2.data_ptr(), gp2.data_ptr() if gp2 is not None else None, bits.data_ptr(), rows, C,
+                                           dx.data_ptr(), _lib.current_stream_ptr())
+                _lib.check(rc, "pl_mask_add_by_bits")
+                # (dy = dx where the join's bitmap is set: masking the masked sum again changes nothing)
+                rc = L.pl_bn_train_bwd_ex(dx.data_ptr(), bits.data_ptr(), z2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                          gamma.data_ptr(), rows, C, None, dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(),
+                                          dz.data_ptr(), link.mode, link.dz_scale.data_ptr(), _lib.current_stream_ptr())
+                _lib.check(rc, "pl_bn_train_bwd_ex")
         return dz.reshape(ctx.shape), dx.reshape(ctx.shape), dgamma, dbeta, None, None, None, None, None, None
 
 

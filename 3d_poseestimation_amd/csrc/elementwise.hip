@@ -397,10 +397,13 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(
 // -------------------------------------------------------------------------------------
 // BN backward pass 1: per-block partial column sums of dy and dy*zhat.
 // -------------------------------------------------------------------------------------
+// join_g2 / join_dx (the Bottleneck's bn3 + residual join, pl_bn_join_bwd): the incoming gradient is g + join_g2 (join_g2 may be
+// NULL) and the masked value is also stored to join_dx -- the residual join's backward (mask_by_bits_kernel) folded into this pass.
 __global__ __launch_bounds__(NTHR) void bn_bwd_reduce_kernel(
     const float* __restrict__ g, const uint64_t* __restrict__ bits, const float* __restrict__ z,
     const float* __restrict__ mean, const float* __restrict__ rstd, float kscale, int B, int H,
-    float* __restrict__ part_dy, float* __restrict__ part_dyz, int Hc, float* __restrict__ part_amax) {
+    float* __restrict__ part_dy, float* __restrict__ part_dyz, int Hc, float* __restrict__ part_amax,
+    const float* __restrict__ join_g2, float* __restrict__ join_dx) {
   __shared__ float4 sm[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int strip = blockIdx.x;
@@ -413,12 +416,15 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_reduce_kernel(
   for (int r = blockIdx.y * 4 + wave; r < B; r += gridDim.y * 4) {
     if (!active) continue;
     const size_t off = (size_t)r * H + c;
-    const float4 gv = ld4(g + off), zv = ld4(z + off);
+    float4 gv = ld4(g + off);
+    const float4 zv = ld4(z + off);
+    if (join_g2) { const float4 u = ld4(join_g2 + off); gv.x += u.x; gv.y += u.y; gv.z += u.z; gv.w += u.w; }
     const uint64_t* bw = bits + (size_t)r * wpr + strip * 4;
     const float d0 = ((bw[0] >> lane) & 1ull) ? gv.x * kscale : 0.f;
     const float d1 = ((bw[1] >> lane) & 1ull) ? gv.y * kscale : 0.f;
     const float d2 = ((bw[2] >> lane) & 1ull) ? gv.z * kscale : 0.f;
     const float d3 = ((bw[3] >> lane) & 1ull) ? gv.w * kscale : 0.f;
+    if (join_dx) st4(join_dx + off, make_float4(d0, d1, d2, d3));
     s1.x += d0; s1.y += d1; s1.z += d2; s1.w += d3;
     const float z0 = (zv.x - mu.x) * rs.x, z1 = (zv.y - mu.y) * rs.y, z2 = (zv.z - mu.z) * rs.z, z3 = (zv.w - mu.w) * rs.w;
     s2.x = fmaf(d0, z0, s2.x);
@@ -1137,10 +1143,11 @@ int bwd_row_chunks(int B, int H) {
 
 int launch_bn_bwd_reduce(const float* g, const uint64_t* bits, const float* z, const float* mean,
                          const float* rstd, float keep_scale, int B, int H, float* part_dy,
-                         float* part_dyz, hipStream_t s, int Hc, float* part_amax, int rc) {
+                         float* part_dyz, hipStream_t s, int Hc, float* part_amax, int rc, const float* join_g2,
+                         float* join_dx) {
   dim3 grid((H + 255) / 256, rc > 0 ? rc : bwd_row_chunks(B, H));
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(NTHR), 0, s, g, bits, z, mean, rstd, keep_scale, B,
-                     H, part_dy, part_dyz, Hc > 0 ? Hc : H, part_amax);
+                     H, part_dy, part_dyz, Hc > 0 ? Hc : H, part_amax, join_g2, join_dx);
   PL_CHECK_LAUNCH("bn_bwd_reduce");
   return PL_OK;
 }
@@ -1634,6 +1641,34 @@ extern "C" int pl_bn_train_bwd_ex(const float* dy, const uint64_t* bits, const f
   PL_TRY(launch_bn_bwd_finalize(part, RC, R, R > 1 ? -1 : 0, B, Hc, gamma, rstd, coef, dgamma, dbeta, s,
                                 scaled ? amax : nullptr, n_amax, scaled ? dz_scale : nullptr));
   return launch_bn_bwd_dz(dy, bits, z, mean, rstd, coef, 1.0f, 1, B, H, dz, part_db, s, Hc, dz_planes ? &po : nullptr);
+}
+
+// Backward of the Bottleneck's bn3 + residual join (pl_bn_train_fwd_ex with `join`; Resnet.py:81-91) in three launches: dx = (g + g2)
+// where the join's bitmap is set (the identity's gradient AND bn3's dy; g2 may be NULL) written by the same pass that takes
+// BatchNorm-backward's column sums of it (no separate pl_mask_add_by_bits pass and no re-read of dx for the sums), the finalize,
+// then dz (fp32 and / or planes as pl_bn_train_bwd_ex).  C >= 256 (no column replication: the bitmap is per (row, channel)).
+extern "C" int pl_bn_join_bwd(const float* g, const float* g2, const uint64_t* bits, const float* z, const float* mean,
+                              const float* rstd, const float* gamma, int64_t rows, int64_t C, float* dx, float* dz, float* dgamma,
+                              float* dbeta, void* scratch, void* dz_planes, int planes_mode, float* dz_scale, void* stream) {
+  if (!g || !bits || !z || !mean || !rstd || !gamma || !dx || (!dz && !dz_planes) || !dgamma || !dbeta || !scratch)
+    PL_FAIL(PL_EINVAL, "pl_bn_join_bwd: null pointer");
+  if (rows < 2 || rows > INT32_MAX || C <= 0 || (C & 3)) PL_FAIL(PL_ESHAPE, "pl_bn_join_bwd: rows=%lld C=%lld", (long long)rows, (long long)C);
+  if (bn_replicas(rows, C) != 1) PL_FAIL(PL_ESHAPE, "pl_bn_join_bwd: C=%lld is narrower than one 256-column strip", (long long)C);
+  const bool scaled = dz_planes && planes_mode == PL_F16X3;
+  if (scaled && !dz_scale) PL_FAIL(PL_EINVAL, "pl_bn_join_bwd: fp16 planes of dz need dz_scale");
+  PlaneOut po;
+  PL_TRY(plane_out_of(planes_mode, dz_planes, rows * C, 1.0f, scaled ? dz_scale : nullptr, &po, "pl_bn_join_bwd"));
+  hipStream_t s = (hipStream_t)stream;
+  const int B = (int)rows, H = (int)C, RC = bwd_row_chunks(B, H);
+  float* part = static_cast<float*>(scratch);
+  float* coef = part + (size_t)2 * RC * H;
+  float* part_db = coef + 3 * (size_t)H;
+  float* amax = part_db + (size_t)RC * H;
+  const int n_amax = ((H + 255) / 256) * RC;
+  PL_TRY(launch_bn_bwd_reduce(g, bits, z, mean, rstd, 1.0f, B, H, part, part + (size_t)RC * H, s, H, scaled ? amax : nullptr, 0, g2, dx));
+  PL_TRY(launch_bn_bwd_finalize(part, RC, 1, 0, B, H, gamma, rstd, coef, dgamma, dbeta, s, scaled ? amax : nullptr, n_amax,
+                                scaled ? dz_scale : nullptr));
+  return launch_bn_bwd_dz(dx, bits, z, mean, rstd, coef, 1.0f, 1, B, H, dz, part_db, s, H, dz_planes ? &po : nullptr);
 }
 
 extern "C" int pl_add_relu_fwd(const float* a, const float* b, int64_t rows, int64_t C, float* out, uint64_t* bits,

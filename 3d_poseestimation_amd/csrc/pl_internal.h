@@ -173,7 +173,8 @@ int bwd_row_chunks(int B, int H);
 // part_amax (optional): [strips * RC][2] per-workgroup maxima of |dy| and |zhat| (the dz range bound, below)
 int launch_bn_bwd_reduce(const float* g, const uint64_t* bits, const float* z, const float* mean,
                          const float* rstd, float keep_scale, int B, int H, float* part_dy,
-                         float* part_dyz, hipStream_t s, int Hc = 0, float* part_amax = nullptr, int rc = 0);
+                         float* part_dyz, hipStream_t s, int Hc = 0, float* part_amax = nullptr, int rc = 0,
+                         const float* join_g2 = nullptr, float* join_dx = nullptr);
 
 // dz_scale (optional, with part_amax of n_amax workgroups): {S, 1/S}, S the power of two that maps the bound
 // max|c0| max|dy| (2 + max|zhat|) >= max|dz| to at most 2^14 (fp16 planes of dz, PL_F16X3)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PL_VERSION 102 /* 0.1.2: operand-plane outputs of the BatchNorm / join kernels, pl_gemm_planes_raw */
+#define PL_VERSION 103 /* 0.1.3: + pl_bn_join_bwd (0.1.2: operand-plane outputs of the BatchNorm / join kernels, pl_gemm_planes_raw) */
 
 typedef enum PLStatus {
   PL_OK = 0,
@@ -280,6 +280,12 @@ int pl_add_relu_fwd_ex(const float* a, const float* b, int64_t rows, int64_t C, 
                        void* out_planes, int planes_mode, void* stream);
 int pl_mask_add_by_bits(const float* g, const float* g2, const uint64_t* bits, int64_t rows, int64_t C, float* dx,
                         void* stream);
+/* Backward of bn3 + residual join in one go (Resnet.py:81-91 under autograd): dx = (g + g2) where the join's bitmap is set
+ * (g2 may be NULL) -- the identity's gradient and bn3's dy -- written by the pass that also takes BatchNorm-backward's column
+ * sums; then the finalize and dz as pl_bn_train_bwd_ex (same scratch, same dz / dz_planes / dz_scale meaning).  C >= 256. */
+int pl_bn_join_bwd(const float* g, const float* g2, const uint64_t* bits, const float* z, const float* mean,
+                   const float* rstd, const float* gamma, int64_t rows, int64_t C, float* dx, float* dz, float* dgamma,
+                   float* dbeta, void* scratch, void* dz_planes, int planes_mode, float* dz_scale, void* stream);
 
 /* nn.MaxPool2d(kernel_size=3, stride=2, padding=1)  phase4_joined/Resnet.py:119.  x [B][H][W][C], C % 4 == 0;
  * y [B][(H-1)/2+1][(W-1)/2+1][C]. */

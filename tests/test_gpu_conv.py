@@ -602,6 +602,54 @@ def _planes(pkg, t, scale=1.0):
     return cv._planes_of(t, scale)
 
 
+@pytest.mark.parametrize("rows,C,two", [(1000, 320, True), (4096, 256, False), (777, 1024, True)])
+def test_bn_join_bwd_is_the_masked_sum_plus_batchnorm_backward_bit_for_bit(pkg, rows, C, two):
+    """pl_bn_join_bwd (bn3 + residual join backward, the masked sum written by the pass that takes the BatchNorm-backward column
+    sums) against the two calls it replaces, pl_mask_add_by_bits + pl_bn_train_bwd_ex: dx, the dz planes, their scale, dgamma
+    and dbeta identical bit for bit."""
+    L = pkg.lib()
+    s = torch.cuda.current_stream().cuda_stream
+    gen = torch.Generator().manual_seed(rows + C)
+    z = torch.randn(rows, C, generator=gen).to(DEV)
+    ident = torch.randn(rows, C, generator=gen).to(DEV)
+    g = torch.randn(rows, C, generator=gen).to(DEV)
+    g2 = torch.randn(rows, C, generator=gen).to(DEV) if two else None
+    gamma, beta = (torch.rand(C, generator=gen) + 0.5).to(DEV), torch.randn(C, generator=gen).to(DEV)
+    rm, rv, nb = torch.zeros(C, device=DEV), torch.ones(C, device=DEV), torch.zeros((), dtype=torch.int64, device=DEV)
+    x, xp = torch.empty_like(z), torch.empty_like(z)
+    bits = torch.empty(rows, 4 * ((C + 255) // 256), dtype=torch.int64, device=DEV)
+    mean, rstd = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    scratch = torch.empty(L.pl_bn_train_scratch_bytes(rows, C), dtype=torch.uint8, device=DEV)
+    rc = L.pl_bn_train_fwd_ex(z.data_ptr(), rows, C, gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(),
+                              nb.data_ptr(), 1, x.data_ptr(), bits.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scratch.data_ptr(),
+                              xp.data_ptr(), 3, None, ident.data_ptr(), s)
+    assert rc == 0, L.pl_last_error()
+    out = []
+    for fused in (False, True):
+        dx = torch.full_like(z, float("nan"))
+        dz = torch.full_like(z, float("nan"))                     # carrier of the dz planes
+        dgam, dbet, dzs = torch.empty(C, device=DEV), torch.empty(C, device=DEV), torch.empty(2, device=DEV)
+        sc = torch.empty(L.pl_bn_train_scratch_bytes(rows, C), dtype=torch.uint8, device=DEV)
+        g2p = g2.data_ptr() if g2 is not None else None
+        if fused:
+            rc = L.pl_bn_join_bwd(g.data_ptr(), g2p, bits.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                  rows, C, dx.data_ptr(), None, dgam.data_ptr(), dbet.data_ptr(), sc.data_ptr(), dz.data_ptr(), 3,
+                                  dzs.data_ptr(), s)
+        else:
+            rc = L.pl_mask_add_by_bits(g.data_ptr(), g2p, bits.data_ptr(), rows, C, dx.data_ptr(), s)
+            assert rc == 0, L.pl_last_error()
+            rc = L.pl_bn_train_bwd_ex(dx.data_ptr(), bits.data_ptr(), z.data_ptr(), mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(),
+                                      rows, C, None, dgam.data_ptr(), dbet.data_ptr(), sc.data_ptr(), dz.data_ptr(), 3, dzs.data_ptr(), s)
+        assert rc == 0, L.pl_last_error()
+        torch.cuda.synchronize()
+        out.append((dx, dz.view(torch.int32), dgam, dbet, dzs))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    mask = x > 0
+    want = torch.where(mask, g + (g2 if g2 is not None else 0), torch.zeros_like(g))
+    assert torch.equal(out[1][0], want)
+
+
 @pytest.mark.parametrize("mode", ["f16x3", "bf16p"])
 @pytest.mark.parametrize("B,H,W,Cin,Cout,K,pad,route", [
     (2, 16, 24, 32, 128, 3, 1, "transposed 4x4"),     # layer2.0 / 3.0 / 4.0 conv2 in small
