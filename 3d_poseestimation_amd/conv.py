@@ -29,14 +29,12 @@ def deconv_subkernels(weight_iohw):
     w = weight_iohw
     if w.dim() != 4 or w.shape[2] != 4 or w.shape[3] != 4:
         raise ValueError("deconv_subkernels expects a [Cin][Cout][4][4] ConvTranspose2d weight")
-    subs = []
-    for ph in (0, 1):
-        for pw in (0, 1):
-            kh = [2, 0] if ph else [3, 1]
-            kw = [2, 0] if pw else [3, 1]
-            sub = w[:, :, kh][:, :, :, kw]                     # [Cin][Cout][2][2]
-            subs.append(sub.permute(1, 2, 3, 0))               # [Cout][2][2][Cin]
-    return torch.stack(subs).contiguous()
+    # tap a of parity ph is kh = 3 - (2a + ph): on the flipped filter the tap index IS 2a + ph, so a reshape of each 4 into
+    # (a, ph) and one permuted copy build all four sub-kernels (no index tensors: nothing here touches the host, the whole
+    # training step can be captured in a hipGraph)
+    cin, cout = w.shape[0], w.shape[1]
+    wf = w.flip(2, 3).reshape(cin, cout, 2, 2, 2, 2)           # [Cin][Cout][a][ph][b][pw]
+    return wf.permute(3, 5, 1, 2, 4, 0).reshape(4, cout, 2, 2, cin).contiguous()
 
 
 def fold_bn(bn):

@@ -186,6 +186,80 @@ class GraphedTrainStep:
         return self.loss, self.y_hat
 
 
+class GraphedModuleStep:
+    """A whole training step of the conv models -- phase4_joined/train.py:69-89: zero_grad, Model_3D forward, loss, backward,
+    Adam -- captured ONCE as a hipGraph and replayed.  The step is ~1,100 launches driven from Python autograd nodes; at the
+    reference's own batch (8 frames, train.py:187) the host needs 14-17 ms to issue what the GPU finishes in less, and a replay is
+    one launch.  Same kernels in the same order: results are bit-identical to the eager step's.
+
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+        step = GraphedModuleStep(model, opt, torch.nn.functional.mse_loss, frames_example, target_example)
+        loss = step(frames, target)         # a device scalar, overwritten by the next call
+
+    Construction runs `warmup` eager steps on the example batch (every kernel loaded, the allocator's pool sized) and then
+    puts parameters, buffers and optimizer state back exactly as they were, so the first replay is the model's first step.
+    Fixed shapes; single process; the optimizer must keep its step state on the device (torch: capturable=True; give lr as
+    a tensor to change it between replays).  forward(*inputs) is whatever the module's forward takes; loss_fn(output,
+    target)."""
+
+    def __init__(self, model, optimizer, loss_fn, inputs, target, warmup=2):
+        inputs = tuple(inputs) if isinstance(inputs, (tuple, list)) else (inputs,)
+        dev = target.device
+        if dev.type != "cuda" or any(t.device != dev for t in inputs):
+            raise _lib.PoseliftError("GraphedModuleStep: inputs and target must sit on one GPU")
+        if not model.training:
+            raise _lib.PoseliftError("GraphedModuleStep captures a TRAINING step: call model.train() first")
+        for gr in optimizer.param_groups:
+            if not gr.get("capturable", False):
+                raise _lib.PoseliftError("GraphedModuleStep: the optimizer must be built with capturable=True "
+                                         "(its step counter has to live on the device)")
+        self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
+        self._in = tuple(t.detach().clone() for t in inputs)
+        self._target = target.detach().clone()
+        with torch.cuda.device(dev):
+            torch.cuda.synchronize(dev)
+            state = [t for t in model.state_dict().values()]
+            snap = [t.detach().clone() for t in state]
+            had = {p: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in optimizer.state.get(p, {}).items()}
+                   for gr in optimizer.param_groups for p in gr["params"]}
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(max(1, int(warmup))):
+                    self._step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            with torch.no_grad():
+                for dst, src in zip(state, snap):
+                    dst.copy_(src)
+                for p, old in had.items():                                   # optimizer state: back to what it was, IN PLACE
+                    for k, v in optimizer.state.get(p, {}).items():          # (a fresh optimizer: zeros, step 0)
+                        if torch.is_tensor(v):
+                            v.copy_(old[k]) if k in old else v.zero_()
+            optimizer.zero_grad(set_to_none=True)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.loss = self._step()
+        self.replays = 0
+
+    def _step(self):
+        self.opt.zero_grad(set_to_none=True)
+        loss = self.loss_fn(self.model(*self._in), self._target)
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
+    def __call__(self, inputs, target):
+        inputs = tuple(inputs) if isinstance(inputs, (tuple, list)) else (inputs,)
+        for dst, src in zip(self._in, inputs):
+            dst.copy_(src)
+        self._target.copy_(target)
+        self.graph.replay()
+        self.replays += 1
+        return self.loss
+
+
 @torch.no_grad()
 def predict_flip_tta(model, y1, out_dims=3):
     """(flip_pose(model(flip_pose(y1))) + model(y1)) / 2 for a model in eval mode, as ONE forward

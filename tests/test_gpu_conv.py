@@ -602,6 +602,53 @@ def _planes(pkg, t, scale=1.0):
     return cv._planes_of(t, scale)
 
 
+@pytest.mark.parametrize("dtype", ["f16x3", "bf16p"])
+def test_graphed_module_step_replays_the_eager_step_bit_for_bit(pkg, dtype):
+    """train.GraphedModuleStep: the phase4 step (train.py:69-89: zero_grad, Model_3D forward, MSE, backward, Adam) captured
+    once as a hipGraph.  Three replays on three different batches == three eager steps from the same start: losses,
+    parameters, BatchNorm buffers and Adam state identical bit for bit; construction (its warm-up steps run for real) leaves
+    the model and a fresh optimizer exactly as they were."""
+    frames = [pkg.synth.seeded_frames(2, 40 + i, 64).to(DEV) for i in range(3)]
+    targets = [torch.randn(2, 51, generator=torch.Generator().manual_seed(50 + i)).to(DEV) for i in range(3)]
+
+    def build():
+        m = pkg.Model_3D(compute_dtype=dtype).train()
+        m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 31))
+        with torch.no_grad():
+            m.final_layer.weight.mul_(1e-3)
+        m = m.to(DEV)
+        return m, torch.optim.Adam(m.parameters(), lr=1e-3, capturable=True)
+
+    m0, o0 = build()
+    eager = []
+    for x, t in zip(frames, targets):
+        o0.zero_grad(set_to_none=True)
+        loss = F.mse_loss(m0(x), t)
+        loss.backward()
+        o0.step()
+        eager.append(loss.detach().clone())
+    m1, o1 = build()
+    before = {k: v.detach().clone() for k, v in m1.state_dict().items()}
+    step = pkg.GraphedModuleStep(m1, o1, F.mse_loss, frames[2], targets[2])
+    torch.cuda.synchronize()
+    for k, v in m1.state_dict().items():
+        assert torch.equal(v, before[k]), f"construction changed {k}"
+    for p in m1.parameters():
+        st = o1.state[p]
+        assert float(st["step"]) == 0.0 and not bool(st["exp_avg"].any()) and not bool(st["exp_avg_sq"].any())
+    for i, (x, t) in enumerate(zip(frames, targets)):
+        loss = step(x, t)
+        assert torch.equal(loss, eager[i]), (i, float(loss), float(eager[i]))
+    assert step.replays == 3
+    for (k, a), (_, b) in zip(m0.state_dict().items(), m1.state_dict().items()):
+        assert torch.equal(a, b), k
+    for p0, p1 in zip(m0.parameters(), m1.parameters()):
+        for key in ("step", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(o0.state[p0][key], o1.state[p1][key]), key
+    with pytest.raises(pkg.PoseliftError, match="capturable"):
+        pkg.GraphedModuleStep(m1, torch.optim.Adam(m1.parameters(), lr=1e-3), F.mse_loss, frames[0], targets[0])
+
+
 @pytest.mark.parametrize("rows,C,two", [(1000, 320, True), (4096, 256, False), (777, 1024, True)])
 def test_bn_join_bwd_is_the_masked_sum_plus_batchnorm_backward_bit_for_bit(pkg, rows, C, two):
     """pl_bn_join_bwd (bn3 + residual join backward, the masked sum written by the pass that takes the BatchNorm-backward column

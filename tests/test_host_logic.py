@@ -253,3 +253,18 @@ def test_feeder_epoch_indices_partition_the_table():
     assert len(dropped) == N // (bs * world) and all(t.numel() == bs for t in dropped)
     plain = data.epoch_indices(10, 4, shuffle=False)
     assert [t.tolist() for t in plain] == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9]]
+
+
+def test_deconv_subkernels_match_their_definition():
+    """conv.deconv_subkernels (one flip + one permuted copy, nothing on the host: capturable in a hipGraph) against the
+    definition it replaces: output row 2a + ph of ConvTranspose2d(4, 2, 1) takes kh = [3, 1][a] (ph = 0) or [2, 0][a]."""
+    import torch
+    cv = importlib.import_module("3d_poseestimation_amd.conv")
+    w = torch.randn(5, 7, 4, 4, generator=torch.Generator().manual_seed(4))
+    subs = []
+    for ph in (0, 1):
+        for pw in (0, 1):
+            kh = [2, 0] if ph else [3, 1]
+            kw = [2, 0] if pw else [3, 1]
+            subs.append(w[:, :, kh][:, :, :, kw].permute(1, 2, 3, 0))
+    assert torch.equal(torch.stack(subs).contiguous(), cv.deconv_subkernels(w))

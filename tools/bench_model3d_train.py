@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--B", type=int, default=32); ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--skip-eager", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="also time train.GraphedModuleStep (the step as one hipGraph)")
     a = ap.parse_args()
     m = pkg.Model_3D().train()
     m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 31))
@@ -64,6 +65,15 @@ def main():
     ours.compute_dtype = ours.preact.compute_dtype = "bf16p"
     t = timed(step_ours, a.iters)
     print(f"B={a.B} this library (bf16 operand storage, planes)   : {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
+    if a.graph:                                                       # the same steps replayed from one hipGraph each
+        for dt, label in (("f16x3", "fp32-grade, planes, hipGraph replay "), ("bf16p", "bf16 storage, planes, hipGraph replay")):
+            gm = copy.deepcopy(m).to("cuda")
+            gm.compute_dtype = gm.preact.compute_dtype = dt
+            gstep = pkg.GraphedModuleStep(gm, torch.optim.Adam(gm.parameters(), lr=1e-3, capturable=True), F.mse_loss,
+                                          frames, target)
+            t = timed(lambda: gstep(frames, target), a.iters)
+            print(f"B={a.B} this library ({label}): {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
+            del gstep, gm
     if a.skip_eager:
         return
     ours.compute_dtype = ours.preact.compute_dtype = "bf16"
