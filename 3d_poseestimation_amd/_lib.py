@@ -207,8 +207,36 @@ def check(rc, what):
         raise PoseliftError(f"{what} failed (status {rc}): {msg}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def current_stream_ptr():
+    """hipStream_t of torch's current stream on the current device.  (torch.cuda.current_stream().cuda_stream builds a Stream
+    object per call: 9 us, 170 times per conv training step.)"""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def on_device(dev):
+    """`with on_device(t.device):` -- torch.cuda.device(dev), minus its cost when dev already is the current device (the
+    one-process-per-GPU case: always)."""
+    idx = dev.index if isinstance(dev, torch.device) else dev
+    if _cur_device is not None and (idx is None or idx == _cur_device()):
+        return _NO_SWITCH
+    return torch.cuda.device(dev)
 
 
 def require_device_tensor(t, name, dtype=torch.float32):

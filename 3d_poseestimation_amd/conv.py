@@ -78,7 +78,7 @@ def conv2d_nhwc(x, w_ohwi, stride=1, padding=0, scale=None, shift=None, bias=Non
     nbytes = L.pl_conv2d_nhwc_scratch_bytes_ex(B, H, W, Cin, Cout, KH, KW, stride, padding, int(bias is not None),
                                                int(resid is not None), int(relu))
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = L.pl_conv2d_nhwc_fwd(x.data_ptr(), B, H, W, Cin, w.data_ptr(), Cout, KH, KW, stride, padding,
                                   ptr[0], ptr[1], ptr[2], relu, ptr[3], y.data_ptr(), ARITH[arith],
                                   scratch.data_ptr() if nbytes else None, nbytes, _lib.current_stream_ptr())
@@ -101,7 +101,7 @@ def conv2d_nhwc_wgrad(x, dy, kernel_size, stride=1, padding=0, arith="bf16x6"):
     L = _lib.lib()
     nbytes = L.pl_conv2d_nhwc_wgrad_scratch_bytes(B, H, W, Cin, Cout, KH, KW, stride, padding)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device) if nbytes else None
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = L.pl_conv2d_nhwc_wgrad(x.data_ptr(), B, H, W, Cin, dy.data_ptr(), Cout, KH, KW, stride, padding,
                                     dw.data_ptr(), ARITH[arith], scratch.data_ptr() if nbytes else None, nbytes,
                                     _lib.current_stream_ptr())
@@ -127,7 +127,7 @@ def conv2d_nhwc_dgrad(dy, w_ohwi, in_hw, stride=1, padding=0, arith="bf16x6"):
         B, Ho, Wo, _ = dy.shape
         t = conv2d_nhwc(dy, w_ohwi.reshape(Cout, Cin).t().contiguous().reshape(Cin, 1, 1, Cout), 1, 0, arith=arith)
         dx = torch.empty(B, H, W, Cin, dtype=torch.float32, device=dy.device)
-        with torch.cuda.device(dy.device):
+        with _lib.on_device(dy.device):
             rc = _lib.lib().pl_upsample2x_zero_nhwc(t.data_ptr(), B, Ho, Wo, Cin, dx.data_ptr(), _lib.current_stream_ptr())
         _lib.check(rc, "pl_upsample2x_zero_nhwc")
         return dx
@@ -145,7 +145,7 @@ def maxpool3x3s2_nhwc(x):
     _lib.require_device_tensor(x, "x")
     B, H, W, C = x.shape
     y = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = _lib.lib().pl_maxpool3x3s2_nhwc(x.data_ptr(), B, H, W, C, y.data_ptr(), _lib.current_stream_ptr())
     _lib.check(rc, "pl_maxpool3x3s2_nhwc")
     return y
@@ -165,7 +165,7 @@ def deconv4x4s2_nhwc(x, w_sub, scale=None, shift=None, relu=0, arith="bf16x6"):
     L = _lib.lib()
     nbytes = L.pl_deconv4x4s2_nhwc_scratch_bytes(B, Hi, Wi, Cout)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = L.pl_deconv4x4s2_nhwc_fwd(x.data_ptr(), B, Hi, Wi, Cin, w.data_ptr(), Cout,
                                        scale.data_ptr() if scale is not None else None,
                                        shift.data_ptr() if shift is not None else None, relu, y.data_ptr(), ARITH[arith],
@@ -180,7 +180,7 @@ def nhwc_to_nchw(x):
     _lib.require_device_tensor(x, "x")
     B, H, W, C = x.shape
     y = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         rc = _lib.lib().pl_nhwc_to_nchw(x.data_ptr(), B, H * W, C, y.data_ptr(), _lib.current_stream_ptr())
     _lib.check(rc, "pl_nhwc_to_nchw")
     return y
@@ -231,7 +231,7 @@ class _BNReLUFn(torch.autograd.Function):
         bits = torch.empty(rows, 4 * ((C + 255) // 256), dtype=torch.int64, device=dev)
         mean, rstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
         scratch = torch.empty(L.pl_bn_train_scratch_bytes(rows, C), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = L.pl_bn_train_fwd(z2.data_ptr(), rows, C, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
                                    running_mean.data_ptr(), running_var.data_ptr(), batches.data_ptr(), int(relu),
                                    y.data_ptr(), bits.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scratch.data_ptr(),
@@ -249,7 +249,7 @@ class _BNReLUFn(torch.autograd.Function):
         dev, L = z2.device, _lib.lib()
         dz, dgamma, dbeta = torch.empty_like(z2), torch.empty(C, device=dev), torch.empty(C, device=dev)
         scratch = torch.empty(L.pl_bn_train_scratch_bytes(rows, C), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = L.pl_bn_train_bwd(dy2.data_ptr(), bits.data_ptr(), z2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                    gamma.data_ptr(), rows, C, dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                    scratch.data_ptr(), _lib.current_stream_ptr())
@@ -278,7 +278,7 @@ class _AddReLUFn(torch.autograd.Function):
         rows = a2.shape[0]
         out = torch.empty_like(a2)
         bits = torch.empty(rows, 4 * ((C + 255) // 256), dtype=torch.int64, device=a2.device)
-        with torch.cuda.device(a2.device):
+        with _lib.on_device(a2.device):
             rc = _lib.lib().pl_add_relu_fwd(a2.data_ptr(), b2.data_ptr(), rows, C, out.data_ptr(), bits.data_ptr(),
                                             _lib.current_stream_ptr())
         _lib.check(rc, "pl_add_relu_fwd")
@@ -292,7 +292,7 @@ class _AddReLUFn(torch.autograd.Function):
         C = ctx.shape[-1]
         g2 = g.contiguous().reshape(-1, C)
         dx = torch.empty_like(g2)
-        with torch.cuda.device(g2.device):
+        with _lib.on_device(g2.device):
             rc = _lib.lib().pl_mask_by_bits(g2.data_ptr(), bits.data_ptr(), g2.shape[0], C, dx.data_ptr(),
                                             _lib.current_stream_ptr())
         _lib.check(rc, "pl_mask_by_bits")
@@ -315,7 +315,7 @@ class _MaxPoolFn(torch.autograd.Function):
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         y = torch.empty(B, Ho, Wo, C, dtype=torch.float32, device=x.device)
         idx = torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             rc = _lib.lib().pl_maxpool3x3s2_nhwc_idx(x.data_ptr(), B, H, W, C, y.data_ptr(), idx.data_ptr(),
                                                      _lib.current_stream_ptr())
         _lib.check(rc, "pl_maxpool3x3s2_nhwc_idx")
@@ -329,7 +329,7 @@ class _MaxPoolFn(torch.autograd.Function):
         dy = dy.contiguous()
         B, H, W, C = ctx.in_shape
         dx = torch.empty(B, H, W, C, dtype=torch.float32, device=dy.device)
-        with torch.cuda.device(dy.device):
+        with _lib.on_device(dy.device):
             rc = _lib.lib().pl_maxpool3x3s2_nhwc_bwd_idx(idx.data_ptr(), dy.data_ptr(), B, H, W, C, dx.data_ptr(),
                                                          _lib.current_stream_ptr())
         _lib.check(rc, "pl_maxpool3x3s2_nhwc_bwd_idx")
@@ -388,7 +388,7 @@ class _ConvBiasFn(torch.autograd.Function):
             db = torch.empty(C, dtype=torch.float32, device=dy.device)
             L = _lib.lib()
             scratch = torch.empty(L.pl_colsum_scratch_bytes(rows, C), dtype=torch.uint8, device=dy.device)
-            with torch.cuda.device(dy.device):
+            with _lib.on_device(dy.device):
                 rc = L.pl_colsum(dy.data_ptr(), rows, C, db.data_ptr(), scratch.data_ptr(), _lib.current_stream_ptr())
             _lib.check(rc, "pl_colsum")
         return dx, dw, db, None, None, None
@@ -408,7 +408,7 @@ class _ToNCHWFn(torch.autograd.Function):
         g = g.contiguous()
         B, C, H, W = g.shape
         out = torch.empty(B, H, W, C, dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):   # [B][C][P] -> [B][P][C]: the same tiled transpose with the roles swapped
+        with _lib.on_device(g.device):   # [B][C][P] -> [B][P][C]: the same tiled transpose with the roles swapped
             rc = _lib.lib().pl_nhwc_to_nchw(g.data_ptr(), B, C, H * W, out.data_ptr(), _lib.current_stream_ptr())
         _lib.check(rc, "pl_nhwc_to_nchw")
         return out
@@ -450,7 +450,7 @@ def _planes_of(t, scale, mode=_lib.PL_F16X3):
     carrier uses the first half of its bytes."""
     t = t.contiguous()
     out = torch.empty_like(t)
-    with torch.cuda.device(t.device):
+    with _lib.on_device(t.device):
         rc = _lib.lib().pl_planes_split(t.data_ptr(), t.numel(), mode, float(scale), out.data_ptr(),
                                         _lib.current_stream_ptr())
     _lib.check(rc, "pl_planes_split")
@@ -469,7 +469,7 @@ def _gemm_planes_raw(layout, a, a_rows_cols, b, b_rows_cols, M, N, K, out_scale,
     C = torch.empty(M, N, device=dev)
     splits = L.pl_gemm_planes_splits(M, N, K)
     slabs = torch.empty(splits * M * N, device=dev) if splits > 1 else None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = L.pl_gemm_planes_raw(layout, mode, a.data_ptr(), a_rows_cols[0] * a_rows_cols[1], a_rows_cols[1],
                                   b.data_ptr(), b_rows_cols[0] * b_rows_cols[1], b_rows_cols[1], C.data_ptr(), M, N, K,
                                   None, float(out_scale), dyn_inv.data_ptr() if dyn_inv is not None else None,
@@ -555,7 +555,7 @@ class _BNPlanesFn(torch.autograd.Function):
         gstat = link.stat if link is not None else None
         if link is not None:
             link.stat = None
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = L.pl_bn_train_fwd_ex(z2.data_ptr(), rows, C, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
                                       running_mean.data_ptr(), running_var.data_ptr(), batches.data_ptr(), int(relu),
                                       None if out_planes else y.data_ptr(), bits.data_ptr(), mean.data_ptr(),
@@ -577,7 +577,7 @@ class _BNPlanesFn(torch.autograd.Function):
         link = ctx.link
         if link is not None:
             link.dz_scale = torch.empty(2, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = L.pl_bn_train_bwd_ex(dy2.data_ptr(), bits.data_ptr(), z2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                       gamma.data_ptr(), rows, C, None if link is not None else dz.data_ptr(),
                                       dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(),
@@ -611,7 +611,7 @@ class _AddReLUPlanesFn(torch.autograd.Function):
         rows = a2.shape[0]
         out, outp = torch.empty_like(a2), torch.empty_like(a2)
         bits = torch.empty(rows, 4 * ((C + 255) // 256), dtype=torch.int64, device=a2.device)
-        with torch.cuda.device(a2.device):
+        with _lib.on_device(a2.device):
             rc = _lib.lib().pl_add_relu_fwd_ex(a2.data_ptr(), b2.data_ptr(), rows, C, out.data_ptr(), bits.data_ptr(),
                                                outp.data_ptr(), mode, _lib.current_stream_ptr())
         _lib.check(rc, "pl_add_relu_fwd_ex")
@@ -631,7 +631,7 @@ class _AddReLUPlanesFn(torch.autograd.Function):
         g2 = g.contiguous().reshape(-1, C)
         gp2 = gp.contiguous().reshape(-1, C) if gp is not None else None
         dx = torch.empty_like(g2)
-        with torch.cuda.device(g2.device):
+        with _lib.on_device(g2.device):
             rc = _lib.lib().pl_mask_add_by_bits(g2.data_ptr(), gp2.data_ptr() if gp2 is not None else None, bits.data_ptr(),
                                                 g2.shape[0], C, dx.data_ptr(), _lib.current_stream_ptr())
         _lib.check(rc, "pl_mask_add_by_bits")
@@ -665,7 +665,7 @@ def _conv_planes_fwd(xp, x_shape, wp, w_shape, stride, pad, out_scale, dyn_inv=N
     cout, kh, kw, _ = w_shape
     ho, wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
     y = torch.empty(B, ho, wo, cout, device=xp.device)
-    with torch.cuda.device(xp.device):
+    with _lib.on_device(xp.device):
         rc = _lib.lib().pl_conv2d_planes_fwd(mode, xp.data_ptr(), B * H * W * cin, B, H, W, cin, wp.data_ptr(),
                                              cout * kh * kw * cin, cout, kh, kw, stride, pad, y.data_ptr(), float(out_scale),
                                              dyn_inv.data_ptr() if dyn_inv is not None else None,
@@ -737,7 +737,7 @@ class _ConvKxKPlanesFn(torch.autograd.Function):
                 low = _gemm_planes_raw(0, dzp, (B * ho * wo, cout), wtp, (cin, cout), B * ho * wo, cin, cout,
                                        1.0 / WEIGHT_PLANE_SCALE, inv, mode)
                 dx = torch.empty(B, H, W, cin, device=dzp.device)
-                with torch.cuda.device(dzp.device):
+                with _lib.on_device(dzp.device):
                     rc = _lib.lib().pl_upsample2x_zero_nhwc(low.data_ptr(), B, ho, wo, cin, dx.data_ptr(), _lib.current_stream_ptr())
                 _lib.check(rc, "pl_upsample2x_zero_nhwc")
             elif even and kh == 3 and kw == 3 and pad == 1 and planes_deconv_supported(B, ho, wo, cout, cin):
@@ -748,7 +748,7 @@ class _ConvKxKPlanesFn(torch.autograd.Function):
                 w4[:, :, :3, :3] = w.permute(0, 3, 1, 2)
                 wsub = _planes_of(deconv_subkernels(w4), WEIGHT_PLANE_SCALE, mode)
                 dx = torch.empty(B, H, W, cin, device=dzp.device)
-                with torch.cuda.device(dzp.device):
+                with _lib.on_device(dzp.device):
                     rc = _lib.lib().pl_deconv4x4s2_planes_fwd(mode, dzp.data_ptr(), B * ho * wo * cout, B, ho, wo, cout,
                                                               wsub.data_ptr(), wsub.numel(), cin, dx.data_ptr(),
                                                               1.0 / WEIGHT_PLANE_SCALE, inv.data_ptr(), _lib.current_stream_ptr())
@@ -771,7 +771,7 @@ class _ConvKxKPlanesFn(torch.autograd.Function):
             splits = L.pl_gemm_planes_splits(cout, kh * kw * cin, B * ho * wo)
             slabs = torch.empty(splits * n, device=dzp.device) if splits > 1 else None
             dw = torch.empty(cout, kh, kw, cin, device=dzp.device)
-            with torch.cuda.device(dzp.device):
+            with _lib.on_device(dzp.device):
                 rc = L.pl_conv2d_planes_wgrad(mode, dzp.data_ptr(), B * ho * wo * cout, xp.data_ptr(), B * H * W * cin,
                                               B, H, W, cin, cout, kh, kw, stride, pad, dw.data_ptr(), 1.0 / ACT_PLANE_SCALE,
                                               inv.data_ptr(), slabs.data_ptr() if slabs is not None else None,
@@ -809,7 +809,7 @@ class _DeconvPlanesFn(torch.autograd.Function):
         cout = weight.shape[1]
         wsub = _planes_of(deconv_subkernels(weight.float()), WEIGHT_PLANE_SCALE, link.mode)
         y = torch.empty(B, 2 * H, 2 * W, cout, device=xp.device)
-        with torch.cuda.device(xp.device):
+        with _lib.on_device(xp.device):
             rc = _lib.lib().pl_deconv4x4s2_planes_fwd(link.mode, xp.data_ptr(), xp.numel(), B, H, W, cin, wsub.data_ptr(),
                                                       wsub.numel(), cout, y.data_ptr(),
                                                       1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), None,
@@ -836,7 +836,7 @@ class _DeconvPlanesFn(torch.autograd.Function):
             splits = L.pl_gemm_planes_splits(cin, 16 * cout, B * H * W)
             slabs = torch.empty(splits * n, device=dyp.device) if splits > 1 else None
             dwc = torch.empty(cin, 4, 4, cout, device=dyp.device)
-            with torch.cuda.device(dyp.device):
+            with _lib.on_device(dyp.device):
                 rc = L.pl_conv2d_planes_wgrad(mode, xp.data_ptr(), xp.numel(), dyp.data_ptr(), dyp.numel(), B, 2 * H, 2 * W,
                                               cout, cin, 4, 4, 2, 1, dwc.data_ptr(), 1.0 / ACT_PLANE_SCALE, inv.data_ptr(),
                                               slabs.data_ptr() if slabs is not None else None, _lib.current_stream_ptr())
@@ -868,7 +868,7 @@ class _ConvBiasPlanesFn(torch.autograd.Function):
         wp = _planes_of(w, WEIGHT_PLANE_SCALE, mode)
         L = _lib.lib()
         y = torch.empty(rows, cout, device=xp.device)
-        with torch.cuda.device(xp.device):
+        with _lib.on_device(xp.device):
             rc = L.pl_gemm_planes_raw(0, mode, xp.data_ptr(), rows * cin, cin, wp.data_ptr(), cout * cin, cin, y.data_ptr(), rows,
                                       cout, cin, bias.data_ptr(), 1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), None, None, None,
                                       _lib.current_stream_ptr())
@@ -894,7 +894,7 @@ class _ConvBiasPlanesFn(torch.autograd.Function):
             L = _lib.lib()
             db = torch.empty(cout, device=dyp.device)
             scratch = torch.empty(L.pl_colsum_scratch_bytes(rows, cout), dtype=torch.uint8, device=dyp.device)
-            with torch.cuda.device(dyp.device):
+            with _lib.on_device(dyp.device):
                 rc = L.pl_colsum_planes(dyp.data_ptr(), mode, rows, cout, inv.data_ptr(), db.data_ptr(), scratch.data_ptr(),
                                         _lib.current_stream_ptr())
             _lib.check(rc, "pl_colsum_planes")
@@ -935,7 +935,7 @@ def conv2d_planes_eval(xp, wp, w_shape, stride=1, padding=0, scale=None, shift=N
     opt = [_opt(scale, "scale", cout), _opt(shift, "shift", cout), _opt(bias, "bias", cout),
            _opt(resid, "resid", B * ho * wo * cout)]
     ep = _epilogue(opt[0], opt[1], opt[2], relu, opt[3], yp)
-    with torch.cuda.device(xp.device):
+    with _lib.on_device(xp.device):
         rc = _lib.lib().pl_conv2d_planes_fwd_ep(mode, xp.data_ptr(), B * H * W * cin, B, H, W, cin, wp.data_ptr(),
                                                 cout * kh * kw * cin, cout, kh, kw, stride, padding,
                                                 y.data_ptr() if y is not None else None,
@@ -952,7 +952,7 @@ def deconv_planes_eval(xp, wsubp, cout, scale=None, shift=None, relu=0, want_f32
     y = torch.empty(B, 2 * H, 2 * W, cout, device=xp.device) if want_f32 else None
     yp = torch.empty(B, 2 * H, 2 * W, cout, device=xp.device) if want_planes else None
     ep = _epilogue(_opt(scale, "scale", cout), _opt(shift, "shift", cout), None, relu, None, yp)
-    with torch.cuda.device(xp.device):
+    with _lib.on_device(xp.device):
         rc = _lib.lib().pl_deconv4x4s2_planes_fwd_ep(mode, xp.data_ptr(), B * H * W * cin, B, H, W, cin, wsubp.data_ptr(),
                                                      16 * cout * cin, cout, y.data_ptr() if y is not None else None,
                                                      1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), ctypes.byref(ep),
@@ -980,7 +980,7 @@ class _BNJoinPlanesFn(torch.autograd.Function):
         mean, rstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
         scratch = torch.empty(L.pl_bn_train_scratch_bytes(rows, C), dtype=torch.uint8, device=dev)
         gstat, link.stat = link.stat, None
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = L.pl_bn_train_fwd_ex(z2.data_ptr(), rows, C, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
                                       running_mean.data_ptr(), running_var.data_ptr(), batches.data_ptr(), 1, x.data_ptr(),
                                       bits.data_ptr(), mean.data_ptr(), rstd.data_ptr(), scratch.data_ptr(), xp.data_ptr(),
@@ -1007,7 +1007,7 @@ class _BNJoinPlanesFn(torch.autograd.Function):
         dz, dgamma, dbeta = torch.empty_like(z2), torch.empty(C, device=dev), torch.empty(C, device=dev)
         scratch = torch.empty(L.pl_bn_train_scratch_bytes(rows, C), dtype=torch.uint8, device=dev)
         link.dz_scale = torch.empty(2, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             if C >= 256:
                 # one pass writes the masked sum and takes BatchNorm-backward's column sums of it (pl_bn_join_bwd)
                 rc = L.pl_bn_join_bwd(g2.data_ptr(), gp2.data_ptr() if gp2 is not None else None, bits.data_ptr(), z2.data_ptr(),

@@ -109,7 +109,7 @@ class PoseFeeder:
         for nb in sizes:
             oa = torch.empty((nb,) + self.shape_a, dtype=torch.float32, device=self.device)
             ob = torch.empty((nb,) + self.shape_b, dtype=torch.float32, device=self.device)
-            with torch.cuda.device(self.device):
+            with _lib.on_device(self.device):
                 _lib.check(L.pl_gather_rows2(self.a.data_ptr(), self.wa, self.b.data_ptr(), self.wb,
                                              idx_all[at:at + nb].data_ptr(), nb, self.n, oa.data_ptr(), ob.data_ptr(),
                                              _lib.current_stream_ptr()), "pl_gather_rows2")

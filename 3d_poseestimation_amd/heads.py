@@ -16,7 +16,7 @@ class _SoftArgmaxFn(torch.autograd.Function):
         _lib.require_device_tensor(logits, "heat-map logits")
         coords = torch.empty(BJ, ncoord, dtype=torch.float32, device=logits.device)
         stats = torch.empty(BJ, 5, dtype=torch.float32, device=logits.device)
-        with torch.cuda.device(logits.device):
+        with _lib.on_device(logits.device):
             rc = _lib.lib().pl_softargmax_fwd(logits.data_ptr(), BJ, D, H, W, ncoord, centred, coords.data_ptr(),
                                               stats.data_ptr(), _lib.current_stream_ptr())
         _lib.check(rc, "pl_softargmax_fwd")
@@ -30,7 +30,7 @@ class _SoftArgmaxFn(torch.autograd.Function):
         BJ, D, H, W, ncoord, centred = ctx.dims
         g = g.contiguous()
         dl = torch.empty_like(logits)
-        with torch.cuda.device(logits.device):
+        with _lib.on_device(logits.device):
             rc = _lib.lib().pl_softargmax_bwd(logits.data_ptr(), stats.data_ptr(), g.data_ptr(), BJ, D, H, W, ncoord,
                                               centred, dl.data_ptr(), _lib.current_stream_ptr())
         _lib.check(rc, "pl_softargmax_bwd")
@@ -72,7 +72,7 @@ class _SoftArgmax3dNHWCFn(torch.autograd.Function):
         B, H, W, _ = x.shape
         coords = torch.empty(B * num_joints, 3, dtype=torch.float32, device=x.device)
         stats = torch.empty(B * num_joints, 5, dtype=torch.float32, device=x.device)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             rc = _lib.lib().pl_softargmax3d_nhwc_fwd(x.data_ptr(), B, num_joints, H, W, coords.data_ptr(),
                                                      stats.data_ptr(), _lib.current_stream_ptr())
         _lib.check(rc, "pl_softargmax3d_nhwc_fwd")
@@ -91,13 +91,13 @@ class _SoftArgmax3dNHWCFn(torch.autograd.Function):
             # the final convolution runs on the planes GEMM (conv.py): dlogits leave as a carrier of their planes, fp16 ones
             # scaled by a power of two from the bound |dlogit| <= 2 max_(b,j) sum_c |g_c| (softmax weights <= 1)
             link.dz_scale = _pow2_scale_for_bound(2.0 * g.reshape(-1, 3).abs().sum(1).max())
-            with torch.cuda.device(x.device):
+            with _lib.on_device(x.device):
                 rc = _lib.lib().pl_softargmax3d_nhwc_bwd_ex(x.data_ptr(), stats.data_ptr(), g.data_ptr(), B, ctx.num_joints, H, W,
                                                             None, dl.data_ptr(), link.mode, link.dz_scale.data_ptr(),
                                                             _lib.current_stream_ptr())
             _lib.check(rc, "pl_softargmax3d_nhwc_bwd_ex")
             return dl, None, None
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             rc = _lib.lib().pl_softargmax3d_nhwc_bwd(x.data_ptr(), stats.data_ptr(), g.data_ptr(), B, ctx.num_joints,
                                                      H, W, dl.data_ptr(), _lib.current_stream_ptr())
         _lib.check(rc, "pl_softargmax3d_nhwc_bwd")

@@ -42,7 +42,7 @@ class _L1TermsFn(torch.autograd.Function):
             grads += [da, db]
         losses = torch.empty(nt, dtype=torch.float32, device=dev)
         scratch = torch.empty(_lib.lib().pl_l1_scratch_bytes(nt), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.lib().pl_l1_terms_fwd_bwd(terms, nt, 1.0, losses.data_ptr(), scratch.data_ptr(),
                                                 _lib.current_stream_ptr())
         _lib.check(rc, "pl_l1_terms_fwd_bwd")
