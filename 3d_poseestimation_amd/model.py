@@ -539,7 +539,7 @@ class LinearModel(nn.Module):
         _lib.require_device_tensor(self._flat, "parameters")
         if x2.device != self._flat.device:
             raise _lib.PoseliftError(f"x on {x2.device}, parameters on {self._flat.device}")
-        with torch.cuda.device(x2.device):
+        with _lib.on_device(x2.device):
             if self.training:
                 ws = self._acquire_workspace(B)
                 needs_graph = torch.is_grad_enabled() and (

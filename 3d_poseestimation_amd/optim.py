@@ -97,7 +97,7 @@ class FlatAdamW(torch.optim.Optimizer):
         g = self.param_groups[0]
         ranges = self._active_ranges()
         planes = model.adamw_plane_segments() if ranges == [(0, flat.numel())] else None
-        with torch.cuda.device(flat.device):
+        with _lib.on_device(flat.device):
             for lo, hi in ranges:
                 rc = _lib.lib().pl_adamw_flat_planes(
                     flat.data_ptr() + 4 * lo, grads.data_ptr() + 4 * lo, self._m.data_ptr() + 4 * lo,

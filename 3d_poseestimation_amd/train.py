@@ -26,7 +26,7 @@ class _MSEFn(torch.autograd.Function):
         dpred = torch.empty_like(pred) if need else None
         loss = torch.empty((), dtype=torch.float32, device=pred.device)
         scratch = torch.empty(_lib.lib().pl_mse_scratch_bytes(n), dtype=torch.uint8, device=pred.device)
-        with torch.cuda.device(pred.device):
+        with _lib.on_device(pred.device):
             rc = _lib.lib().pl_mse_fwd_bwd(pred.data_ptr(), tgt.data_ptr(), n, 1.0,
                                            dpred.data_ptr() if need else None, loss.data_ptr(),
                                            scratch.data_ptr(), _lib.current_stream_ptr())
@@ -57,7 +57,7 @@ def loss_MPJPE(prediction, target, out=None):
         raise ValueError("loss_MPJPE expects two (B, J, 3) tensors")
     metric = out if out is not None else torch.zeros(J, dtype=torch.float32, device=target.device)
     scratch = torch.empty(_lib.lib().pl_mpjpe_scratch_bytes(B, J), dtype=torch.uint8, device=target.device)
-    with torch.cuda.device(target.device):
+    with _lib.on_device(target.device):
         rc = _lib.lib().pl_mpjpe_accum(prediction.data_ptr(), target.data_ptr(), B, J, metric.data_ptr(),
                                        scratch.data_ptr(), _lib.current_stream_ptr())
     _lib.check(rc, "pl_mpjpe_accum")
@@ -72,7 +72,7 @@ def flip_pose(data):
     if data.dim() != 3 or data.shape[1] != 17 or data.shape[2] not in (2, 3):
         raise ValueError("flip_pose expects (N, 17, 2) or (N, 17, 3)")
     out = torch.empty_like(data)
-    with torch.cuda.device(data.device):
+    with _lib.on_device(data.device):
         rc = _lib.lib().pl_flip_pose(data.data_ptr(), out.data_ptr(), data.shape[0], 17, data.shape[2],
                                      _lib.current_stream_ptr())
     _lib.check(rc, "pl_flip_pose")
@@ -108,7 +108,7 @@ def train_step(model, optimizer, y1, y2, grad_sync=None):
     if _fusable(model, optimizer, y1, y2):
         # the whole step is three library calls: fwd+loss+bwd, [all-reduce], AdamW.  Same kernels,
         # same results as the autograd route below; `zero_grad` is implicit (gradients are overwritten)
-        with torch.cuda.device(y1.device):
+        with _lib.on_device(y1.device):
             loss, y2_hat = model.fused_train_fwd_bwd(y1.reshape(y1.shape[0], -1).contiguous(),
                                                      y2.reshape(y2.shape[0], -1).contiguous(),
                                                      grad_sync if model._grad_sync is grad_sync else None)
@@ -153,7 +153,7 @@ class GraphedTrainStep:
         self._lr = float(optimizer.param_groups[0]["lr"])
         self._lr_dev = torch.full((1,), self._lr, dtype=torch.float32, device=dev)
         optimizer._bind()
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             # one eager step on a snapshot: every kernel is loaded and the workspace sits in the model's pool before
             # anything is captured; the snapshot is then restored (the step must not count)
             snap = [t.clone() for t in (model.flat_params, model._bn_running, model._bn_batches, optimizer._m, optimizer._v)]
@@ -216,7 +216,7 @@ class GraphedModuleStep:
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
         self._in = tuple(t.detach().clone() for t in inputs)
         self._target = target.detach().clone()
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             torch.cuda.synchronize(dev)
             state = [t for t in model.state_dict().values()]
             snap = [t.detach().clone() for t in state]
@@ -274,7 +274,7 @@ def predict_flip_tta(model, y1, out_dims=3):
         raise ValueError("flip TTA expects (B, 17, 2|3) poses")
     B, L = y1.shape[0], _lib.lib()
     xx = torch.empty((2 * B,) + tuple(y1.shape[1:]), dtype=torch.float32, device=y1.device)
-    with torch.cuda.device(y1.device):
+    with _lib.on_device(y1.device):
         _lib.check(L.pl_flip_tta_pack(y1.data_ptr(), xx.data_ptr(), B, 17, y1.shape[2], _lib.current_stream_ptr()),
                    "pl_flip_tta_pack")
         yy = model(xx).reshape(2 * B, 17, out_dims).contiguous()
