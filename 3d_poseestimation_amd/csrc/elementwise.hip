@@ -705,6 +705,20 @@ __global__ __launch_bounds__(NTHR) void reduce_rows_multi_kernel(RowJobs j) {
   }
   if (j.kind[job] == 1) {                    // H % 4 == 0, 16-byte aligned (checked on the host)
     const int n4 = H >> 2;
+    if (R == 4) {
+      // the four split-K slabs of a 1024-wide weight gradient: all four loads in flight, added in slab order (with the
+      // slab count a run-time loop bound every load waited for the one before it)
+      for (int i = blockIdx.x * NTHR + threadIdx.x; i < n4; i += gridDim.x * NTHR) {
+        const float* __restrict__ q = part + 4 * (size_t)i;
+        float4 a = ld4(q);
+        const float4 b1 = ld4(q + (size_t)H), b2 = ld4(q + 2 * (size_t)H), b3 = ld4(q + 3 * (size_t)H);
+        a.x += b1.x; a.y += b1.y; a.z += b1.z; a.w += b1.w;
+        a.x += b2.x; a.y += b2.y; a.z += b2.z; a.w += b2.w;
+        a.x += b3.x; a.y += b3.y; a.z += b3.z; a.w += b3.w;
+        st4(j.out[job] + 4 * (size_t)i, a);
+      }
+      return;
+    }
     for (int i = blockIdx.x * NTHR + threadIdx.x; i < n4; i += gridDim.x * NTHR) {
       float4 a = ld4(part + 4 * (size_t)i);
       for (int sl = 1; sl < R; ++sl) {
