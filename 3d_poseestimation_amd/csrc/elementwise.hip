@@ -308,6 +308,9 @@ __global__ __launch_bounds__(NTHR) void mask_by_bits_kernel(const float* __restr
 //  (128), 0.90 (16): the 128 KB prologue per workgroup costs more than the launch it removes.  Not kept.
 //  Also tried: two rows per trip with both rows' loads issued first (here and in bn_bwd_dz_rows): 0.6543 / 0.6524 ms
 //  against 0.6446 / 0.6446 for one row per trip, same box -- eight short waves per CU already overlap their round trips.)
+// RESID (is there a residual / join operand) is a template parameter for the same reason as bn_bwd_dz_rows' BN: its load leaves
+// with z's instead of after the wait for it.
+template <bool RESID>
 __device__ __forceinline__ void bn_apply_rows(
     const float* __restrict__ z, const float4 sc, const float4 sh, const float* resid, float* act,
     uint64_t* __restrict__ bits, int B, int H, int mode, bool norelu, uint32_t thr, float kscale, uint32_t k0,
@@ -324,14 +327,13 @@ __device__ __forceinline__ void bn_apply_rows(
     const size_t off = (size_t)r * H + c;
     float y[4] = {0.f, 0.f, 0.f, 0.f};
     bool keep[4] = {true, true, true, true};
+    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (active) {
       const float4 v = ld4(z + off);
+      if constexpr (RESID) rv = ld4(resid + off);
       y[0] = fmaf(v.x, sc.x, sh.x); y[1] = fmaf(v.y, sc.y, sh.y);
       y[2] = fmaf(v.z, sc.z, sh.z); y[3] = fmaf(v.w, sc.w, sh.w);
-      if (resid_first && resid) {
-        const float4 rv = ld4(resid + off);
-        y[0] += rv.x; y[1] += rv.y; y[2] += rv.z; y[3] += rv.w;
-      }
+      if (RESID && resid_first) { y[0] += rv.x; y[1] += rv.y; y[2] += rv.z; y[3] += rv.w; }
       if (mode == 1) {
         const uint64_t g = ((uint64_t)r * (uint64_t)H + (uint64_t)c) >> 2;
         const Philox4 u = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), layer, c3, k0, k1);
@@ -361,10 +363,7 @@ __device__ __forceinline__ void bn_apply_rows(
     if (lane < 4) bits[(size_t)r * wpr + strip * 4 + lane] = word;
     if (active) {
       float4 out = make_float4(o[0], o[1], o[2], o[3]);
-      if (resid && !resid_first) {
-        const float4 rv = ld4(resid + off);
-        out.x += rv.x; out.y += rv.y; out.z += rv.z; out.w += rv.w;
-      }
+      if (RESID && !resid_first) { out.x += rv.x; out.y += rv.y; out.z += rv.z; out.w += rv.w; }
       if (act) st4(act + off, out);
       if (pd.kind) store_planes4(pd, off, out);
     }
@@ -391,7 +390,8 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(
   const int c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < H && scale) { sc = ld4(scale + c % Hc); sh = ld4(shift + c % Hc); }
-  bn_apply_rows(z, sc, sh, resid, act, bits, B, H, mode, norelu, thr, kscale, k0, k1, c3, layer, inject, pd, resid_first);
+  if (resid) bn_apply_rows<true>(z, sc, sh, resid, act, bits, B, H, mode, norelu, thr, kscale, k0, k1, c3, layer, inject, pd, resid_first);
+  else bn_apply_rows<false>(z, sc, sh, resid, act, bits, B, H, mode, norelu, thr, kscale, k0, k1, c3, layer, inject, pd, resid_first);
 }
 
 // -------------------------------------------------------------------------------------
@@ -559,9 +559,12 @@ __global__ __launch_bounds__(NTHR) void reduce_rows_kernel(const float* __restri
 // BN backward pass 2: dz = c0*(dy - c1 - zhat*c2) (or dz = dy without BN) + db partials.
 // -------------------------------------------------------------------------------------
 // the row loop of bn_bwd_dz_kernel
+// BN is a template parameter so that the z load sits in the same basic block as the g load: behind a run-time `if (bn)` it was
+// issued only after the wait for g -- two dependent round trips per row.
+template <bool BN>
 __device__ __forceinline__ void bn_bwd_dz_rows(
     const float* __restrict__ g, const uint64_t* __restrict__ bits, const float* __restrict__ z, const float4 mu,
-    const float4 rs, const float4 c0, const float4 c1, const float4 c2, float kscale, int bn, int B, int H,
+    const float4 rs, const float4 c0, const float4 c1, const float4 c2, float kscale, int B, int H,
     float* __restrict__ dz, float* __restrict__ part_db, const PlaneDst& pd, float4 (*sm)[64]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int strip = blockIdx.x;
@@ -573,14 +576,15 @@ __device__ __forceinline__ void bn_bwd_dz_rows(
     if (!active) continue;
     const size_t off = (size_t)r * H + c;
     const float4 gv = ld4(g + off);
+    float4 zv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (BN) zv = ld4(z + off);
     const uint64_t* bw = bits + (size_t)r * wpr + strip * 4;
     float4 d;
     d.x = ((bw[0] >> lane) & 1ull) ? gv.x * kscale : 0.f;
     d.y = ((bw[1] >> lane) & 1ull) ? gv.y * kscale : 0.f;
     d.z = ((bw[2] >> lane) & 1ull) ? gv.z * kscale : 0.f;
     d.w = ((bw[3] >> lane) & 1ull) ? gv.w * kscale : 0.f;
-    if (bn) {
-      const float4 zv = ld4(z + off);
+    if constexpr (BN) {
       d.x = c0.x * (d.x - c1.x - (zv.x - mu.x) * rs.x * c2.x);
       d.y = c0.y * (d.y - c1.y - (zv.y - mu.y) * rs.y * c2.y);
       d.z = c0.z * (d.z - c1.z - (zv.z - mu.z) * rs.z * c2.z);
@@ -608,7 +612,8 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_dz_kernel(
     mu = ld4(mean + cc); rs = ld4(rstd + cc);
     c0 = ld4(coef + cc); c1 = ld4(coef + Hc + cc); c2 = ld4(coef + 2 * Hc + cc);
   }
-  bn_bwd_dz_rows(g, bits, z, mu, rs, c0, c1, c2, kscale, bn, B, H, dz, part_db, pd, sm);
+  if (bn) bn_bwd_dz_rows<true>(g, bits, z, mu, rs, c0, c1, c2, kscale, B, H, dz, part_db, pd, sm);
+  else bn_bwd_dz_rows<false>(g, bits, z, mu, rs, c0, c1, c2, kscale, B, H, dz, part_db, pd, sm);
 }
 
 // -------------------------------------------------------------------------------------
