@@ -40,6 +40,9 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
   const bool cok = !EDGE || col0 < e.N;
   auto ok = [&](int it) { return !EDGE || (cok && lr + 4 * it < nrows); };
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // (Tried: requesting bnr_z's sixteen float4 here, ahead of the addend, so that both arrive in one round trip instead of two in
+  //  a row.  Same-box A/B over five interleaved runs: dual launch 63.1 us against 62.4 us as it is -- the epilogue's burst is
+  //  bandwidth, not latency; more of it in flight at once only lengthens the queue.  Not kept.)
   float4 v[16];
 #pragma unroll
   for (int it = 0; it < 16; ++it) v[it] = *reinterpret_cast<const float4*>(ldsw + (it * 4 + lr) * 68 + lc);

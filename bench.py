@@ -49,6 +49,16 @@ PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
 PEAK_BF16_MATRIX_TFLOPS = 2516.0    # dense bf16 MFMA peak (the 2:1-sparsity figure is NOT used)
 BATCH = 4096
 PROF_EVERY = 7    # HIP events around every 7th GEMM launch (coprime with the launches per step; see poselift.h)
+PROF_SPARSE = 31  # ... every 31st once the timed region is long enough for >= 40 samples: an event pair is two barrier packets
+                  # on the stream, and at every 7th launch the sampling itself cost the step 1 % (0.634 vs 0.627 ms, same box)
+
+
+PROF_NOW = [PROF_EVERY]
+
+
+def prof_every(steps):
+    PROF_NOW[0] = PROF_SPARSE if steps * 8 >= 40 * PROF_SPARSE else PROF_EVERY
+    return PROF_NOW[0]
 
 
 def parse():
@@ -169,7 +179,7 @@ def read_rooflines(pkg, L, dtype, one, traffic):
              "frac": round(ach / peak, 4), "traffic": tr,
              "kernel": kernel, "flop_per_launch": fl.value / n_l.value,
              "avg_launch_us": round(avg_ms * 1e3, 2), "launches_timed": n_l.value,
-             "sampling": f"HIP events around every {PROF_EVERY}th GEMM launch of the timed region"}
+             "sampling": f"HIP events around every {PROF_NOW[0]}th GEMM launch of the timed region"}
         if redundancy > 1:
             r["mfma_issue_frac"] = round(redundancy * ach / peak, 4)
         return r
@@ -213,6 +223,7 @@ def side_measurements(pkg, a, dev, x_eval, y_oracle):
         m = pkg.LinearModel(34, 51, compute_dtype=other).to(dev).train()
         opt = pkg.FlatAdamW(m, lr=1e-4)
         L = pkg.lib()
+        PROF_NOW[0] = PROF_EVERY                            # (60 timed steps: the dense sampling)
         L.pl_prof_enable(PROF_EVERY)
         v = timed(lambda: pkg.train_step(m, opt, xb, yb))
         rl = read_rooflines(pkg, L, other, 2.0 * a.batch * 1024 * 1024, None)
@@ -328,7 +339,7 @@ def main():
         model.flat_grads.zero_()
     run(a.warmup)
     if not a.no_prof:
-        L.pl_prof_enable(PROF_EVERY)
+        L.pl_prof_enable(prof_every(a.steps))
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(a.steps, a.warmup)
