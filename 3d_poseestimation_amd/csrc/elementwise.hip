@@ -324,7 +324,10 @@ __global__ __launch_bounds__(NTHR) void mask_by_bits_kernel(const float* __restr
 //  pass.  Same-box A/B, B = 4096: 0.7095 ms per step unfused against 0.80 (64 rows per workgroup), 0.80 (32), 0.92
 //  (128), 0.90 (16): the 128 KB prologue per workgroup costs more than the launch it removes.  Not kept.
 //  Also tried: two rows per trip with both rows' loads issued first (here and in bn_bwd_dz_rows): 0.6543 / 0.6524 ms
-//  against 0.6446 / 0.6446 for one row per trip, same box -- eight short waves per CU already overlap their round trips.)
+//  against 0.6446 / 0.6446 for one row per trip, same box -- eight short waves per CU already overlap their round trips.
+//  Tried again on the conv path's maps (up to 1 GB, far beyond the caches; bn_apply, bn_bwd_dz and bn_bwd_reduce with two rows'
+//  operands AND bitmap words requested up front): Model_3D step at B = 256 92.9 / 92.8 ms against 91.9 / 91.6 ms for one row per
+//  trip, interleaved on one box -- these passes are not short of requests in flight.)
 // RESID (is there a residual / join operand) is a template parameter for the same reason as bn_bwd_dz_rows' BN: its load leaves
 // with z's instead of after the wait for it.
 template <bool RESID>
