@@ -54,13 +54,7 @@ __global__ __launch_bounds__(NTHR) void skinny_wide_out_kernel(
   const int rg = blockIdx.x / strips4;
   const int c = ((blockIdx.x % strips4) * 4 + wave) * 32 + j;
   const int r_base = rg * RG;
-  for (int e = threadIdx.x; e < RG * K; e += NTHR) {
-    const int r = e / K, k = e - r * K;
-    xs[r * KL + k] = (r_base + r < B) ? X[(size_t)(r_base + r) * K + k] : 0.f;
-  }
-  if (K & 1)
-    for (int r = threadIdx.x; r < RG; r += NTHR) xs[r * KL + K] = 0.f;
-  __syncthreads();
+  // the lane's weight column first: its loads are in flight while the narrow rows are staged (they do not depend on the LDS)
   float wb[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
@@ -68,6 +62,38 @@ __global__ __launch_bounds__(NTHR) void skinny_wide_out_kernel(
     wb[s] = (k < K) ? (WT ? W[(size_t)k * H + c] : W[(size_t)c * K + k]) : 0.f;
   }
   const float b = bias ? bias[c] : 0.f;
+  if (r_base + RG <= B) {
+    // the 64 narrow rows are ONE contiguous run of 64 K floats (16-byte aligned: 64 K * 4 is a multiple of 16): three or four
+    // 16-byte loads per thread, all requested before the first LDS write.  (The element loop below kept one 4-byte load in
+    // flight per thread: nine -- K = 51: thirteen -- dependent round trips before the first MFMA, most of the kernel's time.)
+    constexpr int N4 = RG * K / 4, IT = (N4 + NTHR - 1) / NTHR;
+    static_assert((RG * K) % 4 == 0, "64 rows of K floats are whole float4s");
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(X + (size_t)r_base * K);
+    float4 v[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) v[i] = src[min((int)threadIdx.x + i * NTHR, N4 - 1)];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int idx = threadIdx.x + i * NTHR;
+      if (idx < N4) {
+        const float q[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int e = idx * 4 + jj, r = e / K, k = e - r * K;
+          xs[r * KL + k] = q[jj];
+        }
+      }
+    }
+  } else {
+    for (int e = threadIdx.x; e < RG * K; e += NTHR) {
+      const int r = e / K, k = e - r * K;
+      xs[r * KL + k] = (r_base + r < B) ? X[(size_t)(r_base + r) * K + k] : 0.f;
+    }
+  }
+  if (K & 1)
+    for (int r = threadIdx.x; r < RG; r += NTHR) xs[r * KL + K] = 0.f;
+  __syncthreads();
 #pragma unroll 1
   for (int g2 = 0; g2 < RG / 64; ++g2) {
     const int g0 = r_base + g2 * 64;
