@@ -15,6 +15,10 @@
 // round-robin over four MFMA tiles so that a lane stores 16 bytes on 512-byte row segments: 15.9 / 15.6 us against
 // 13.9 / 11.1 us for this form -- these kernels are bound by the ~3 us of fp32 MFMA issue per wave plus un-overlapped
 // load and store latency at one wave per SIMD, not by the store pattern.  Not kept.)
+// (Also tried after the staging fix in skinny_wide_out_kernel: all 96 loads of a wide_in wave, and all 48 16-byte loads of a
+// narrow_out wave, requested in ONE batch instead of two -- 15.8 / 14.3 / 12.9 us against 13.6 / 11.1 / 12.3 us for two
+// batches: past ~48 requests per wave the queue, not the round trip, is what a wave waits for; and the saved z of the BNR
+// epilogue requested before the staging -- 14.8 against 14.6 us.  Not kept.)
 #include "pl_internal.h"
 
 namespace pl {
