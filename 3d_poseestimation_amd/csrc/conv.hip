@@ -353,13 +353,23 @@ __global__ __launch_bounds__(NTHR) void stem7x7_c3_kernel(const float* __restric
                                                           const float* __restrict__ shift, int relu,
                                                           float* __restrict__ y) {
   __shared__ __attribute__((aligned(16))) float ws[147 * 64];     // [(kh*7 + kw)*3 + ci][co]
-  for (int e = threadIdx.x; e < 147 * 64; e += NTHR) {
-    const int co = e & 63, k = e >> 6;                            // w is OHWI: [co][kh][kw][ci] = [co][k]
-    ws[e] = w[co * 147 + k];
+  // The filter is staged ONCE per workgroup and the workgroup then walks pixel tiles (grid = what fits on the chip): with one
+  // tile per workgroup, 16,384 workgroups at B = 256 each began with this transposing copy -- and as an element loop it kept one
+  // 4-byte load per thread in flight, 37 dependent round trips.  Here: batches of eight loads in flight.
+  for (int e0 = threadIdx.x; e0 < 147 * 64; e0 += 8 * NTHR) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = min(e0 + u * NTHR, 147 * 64 - 1);
+      t[u] = w[(e & 63) * 147 + (e >> 6)];                        // w is OHWI: [co][kh][kw][ci] = [co][k]
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + u * NTHR < 147 * 64) ws[e0 + u * NTHR] = t[u];
   }
   __syncthreads();
-  const int64_t p = (int64_t)blockIdx.x * NTHR + threadIdx.x;
-  if (p >= npix) return;
+  for (int64_t p = (int64_t)blockIdx.x * NTHR + threadIdx.x; p < npix; p += (int64_t)gridDim.x * NTHR) {
   const int ow = (int)(p % Wo);
   const int64_t r = p / Wo;
   const int oh = (int)(r % Ho);
@@ -402,6 +412,7 @@ __global__ __launch_bounds__(NTHR) void stem7x7_c3_kernel(const float* __restric
     }
     out[q] = make_float4(o[0], o[1], o[2], o[3]);
   }
+  }                                                               // (pixel tiles of this workgroup)
 }
 
 // Weight gradient of the stem: dw[co][k] = sum over pixels of dy[p][co] * x_gathered[p][k], k = (kh*7 + kw)*3 + ci
@@ -442,11 +453,34 @@ __global__ __launch_bounds__(NTHR, 2) void stem7x7_c3_wgrad_kernel(const float* 
     const int b = r / Ho, oh = r - b * Ho;
     __syncthreads();
     const float4* src = reinterpret_cast<const float4*>(dy + (size_t)r * Wo * 64);
-    for (int e = threadIdx.x; e < Wo * 16; e += NTHR) reinterpret_cast<float4*>(dys)[e] = src[e];
-    for (int e = threadIdx.x; e < 7 * PW * 3; e += NTHR) {
-      const int kh = e / (PW * 3), q = e - kh * PW * 3;
-      const int px = q / 3, iw = px - 3, ci = q - px * 3, ih = oh * 2 - 3 + kh;
-      xs[e] = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? x[(((size_t)b * H + ih) * W + iw) * 3 + ci] : 0.f;
+    // both copies in batches of eight loads in flight per thread (clamped addresses, the bounds applied to the value): as
+    // element loops they were ~30 dependent memory round trips per output row -- most of this kernel's time
+    const int n16 = Wo * 16;
+    for (int e0 = threadIdx.x; e0 < n16; e0 += 8 * NTHR) {
+      float4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = src[min(e0 + u * NTHR, n16 - 1)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (e0 + u * NTHR < n16) reinterpret_cast<float4*>(dys)[e0 + u * NTHR] = t[u];
+    }
+    const int nx = 7 * PW * 3;
+    for (int e0 = threadIdx.x; e0 < nx; e0 += 8 * NTHR) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = min(e0 + u * NTHR, nx - 1);
+        const int kh = e / (PW * 3), q = e - kh * PW * 3;
+        const int px = q / 3, iw = px - 3, ci = q - px * 3, ih = oh * 2 - 3 + kh;
+        const bool in = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        const float v = x[(((size_t)b * H + min(max(ih, 0), H - 1)) * W + min(max(iw, 0), W - 1)) * 3 + ci];
+        t[u] = in ? v : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (e0 + u * NTHR < nx) xs[e0 + u * NTHR] = t[u];
     }
     __syncthreads();
     for (int ow = wave * 2; ow < Wo; ow += 8) {    // lane half h takes pixel ow + h of the pair
@@ -560,7 +594,8 @@ int conv_core(const float* x, int64_t B, int64_t H, int64_t W, int64_t Cin, cons
   g.arith = arith;
   if (Cin == 3 && KH == 7 && KW == 7 && stride == 2 && pad_h == 3 && pad_w == 3 && Cout == 64 && !bias && !resid &&
       relu != 2) {                                           // the stem: direct fp32 kernel, no im2col
-    hipLaunchKernelGGL(stem7x7_c3_kernel, dim3((unsigned)((M + NTHR - 1) / NTHR)), dim3(NTHR), 0, s, x, (int)H, (int)W,
+    const int64_t tiles = (M + NTHR - 1) / NTHR;                // 256 CUs x 4 workgroups of 37.6 KB LDS each
+    hipLaunchKernelGGL(stem7x7_c3_kernel, dim3((unsigned)(tiles < 1024 ? tiles : 1024)), dim3(NTHR), 0, s, x, (int)H, (int)W,
                        (int)Ho, (int)Wo, M, w, scale, shift, relu, y);
     PL_CHECK_LAUNCH("stem7x7_c3");
     return PL_OK;

@@ -496,8 +496,24 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_finalize_kernel(
     // the extra workgroup: range bound of dz = c0 (dy - c1 - zhat c2), |c1| <= max|dy|, |c2| <= max|dy| (mean |zhat| <= 1):
     //   |dz| <= max|c0| max|dy| (2 + max|zhat|)  ->  S = the power of two that maps the bound into (2^13, 2^14]
     float a = 0.f, b = 0.f, c0 = 0.f;
-    for (int k = threadIdx.x; k < n_amax; k += NTHR) { a = fmaxf(a, part_amax[2 * k]); b = fmaxf(b, part_amax[2 * k + 1]); }
-    for (int k = threadIdx.x; k < H; k += NTHR) c0 = fmaxf(c0, fabsf(gamma[k] * rstd[k]));
+    // (this one workgroup is the kernel's critical path: its loads go out eight at a time, at clamped indices -- a maximum does
+    //  not care about repeats -- instead of one dependent round trip per trip)
+    for (int k0 = threadIdx.x; k0 < n_amax; k0 += 8 * NTHR) {
+      float2 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = reinterpret_cast<const float2*>(part_amax)[min(k0 + u * NTHR, n_amax - 1)];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { a = fmaxf(a, t[u].x); b = fmaxf(b, t[u].y); }
+    }
+    for (int k0 = threadIdx.x; k0 < H; k0 += 4 * NTHR) {
+      float gv[4], rv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int k = min(k0 + u * NTHR, H - 1); gv[u] = gamma[k]; rv[u] = rstd[k]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) c0 = fmaxf(c0, fabsf(gv[u] * rv[u]));
+    }
     float* sm = &red[0][0];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
