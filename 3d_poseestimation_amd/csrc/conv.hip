@@ -173,19 +173,37 @@ __global__ __launch_bounds__(NTHR) void maxpool3x3s2_nhwc_bwd_idx_kernel(const u
   const int iw = (int)(r % W); r /= W;
   const int ih = (int)(r % H);
   const int64_t b = r / H;
+  // a pixel lies in the windows oh in {ih/2, (ih+1)/2} x ow in {iw/2, (iw+1)/2} (one or two per axis): the (at most four)
+  // index words and gradients are requested together, at clamped coordinates, and the window tests applied to the values in
+  // the loops' order -- as nested loops with the tests around the loads every window was its own dependent round trip
   float g[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int oh = max(0, ih / 2); oh <= min(Ho - 1, (ih + 1) / 2); ++oh)
-    for (int ow = max(0, iw / 2); ow <= min(Wo - 1, (iw + 1) / 2); ++ow) {
+  const int ohs[2] = {ih / 2, (ih + 1) / 2}, ows[2] = {iw / 2, (iw + 1) / 2};
+  uchar4 kk[4];
+  float4 gg[4];
+  bool use[4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int oh = ohs[a], ow = ows[c];
       const int kh0 = ih - (oh * 2 - 1), kw0 = iw - (ow * 2 - 1);            // this pixel's tap in that window
-      if (kh0 < 0 || kh0 > 2 || kw0 < 0 || kw0 > 2) continue;
-      const int64_t o = ((b * Ho + oh) * Wo + ow) * c4 + cq;
-      const uchar4 k = idx[o];
-      const float4 gv = *reinterpret_cast<const float4*>(dy + o * 4);
-      const unsigned char mine = (unsigned char)(kh0 * 3 + kw0);
-      if (k.x == mine) g[0] += gv.x;
-      if (k.y == mine) g[1] += gv.y;
-      if (k.z == mine) g[2] += gv.z;
-      if (k.w == mine) g[3] += gv.w;
+      use[a * 2 + c] = oh <= Ho - 1 && ow <= Wo - 1 && (a == 0 || ohs[1] != ohs[0]) && (c == 0 || ows[1] != ows[0]) &&
+                       kh0 >= 0 && kh0 <= 2 && kw0 >= 0 && kw0 <= 2;
+      const int64_t o = ((b * Ho + min(oh, Ho - 1)) * Wo + min(ow, Wo - 1)) * c4 + cq;
+      kk[a * 2 + c] = idx[o];
+      gg[a * 2 + c] = *reinterpret_cast<const float4*>(dy + o * 4);
+    }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int q = a * 2 + c;
+      if (!use[q]) continue;
+      const unsigned char mine = (unsigned char)((ih - (ohs[a] * 2 - 1)) * 3 + (iw - (ows[c] * 2 - 1)));
+      if (kk[q].x == mine) g[0] += gg[q].x;
+      if (kk[q].y == mine) g[1] += gg[q].y;
+      if (kk[q].z == mine) g[2] += gg[q].z;
+      if (kk[q].w == mine) g[3] += gg[q].w;
     }
   *reinterpret_cast<float4*>(dx + t * 4) = make_float4(g[0], g[1], g[2], g[3]);
 }

@@ -677,7 +677,16 @@ __global__ void reduce_slabs_kernel(const float* __restrict__ slabs, int nslab, 
     const int64_t n4 = n >> 2;
     for (; i < n4; i += stride) {
       float4 a = ld4(slabs + 4 * i);
-      for (int s = 1; s < nslab; ++s) {
+      int s = 1;
+      for (; s + 4 <= nslab; s += 4) {                   // four slabs' loads in flight, added in slab order
+        float4 b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) b[u] = ld4(slabs + (size_t)(s + u) * n + 4 * i);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; a.w += b[u].w; }
+      }
+      for (; s < nslab; ++s) {
         const float4 b = ld4(slabs + (size_t)s * n + 4 * i);
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
       }
