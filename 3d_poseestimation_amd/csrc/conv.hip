@@ -365,6 +365,9 @@ __global__ __launch_bounds__(NTHR) void nhwc_to_nchw_vec_kernel(const float* __r
 // B = 64).  Direct form on the vector ALU, exact fp32: one thread = one output pixel x all 64 channels, the
 // 37.6 KB filter in LDS as [tap][ci][64 co] so a tap's 64 weights are 16 broadcast ds_read_b128; 147 x 64 FMAs
 // per pixel (19.7 GFLOP per 64 frames) with BatchNorm + ReLU folded into the store.
+// (Tried: two horizontally adjacent output pixels per thread -- a tap's 16 ds_read_b128 feeding both pixels' FMAs, the two
+//  windows sharing a 9-column strip of the input row.  128 accumulators + the strip need all 256 VGPRs: one wave per SIMD
+//  instead of four, and 530 us against 388 us at B = 64.  Not kept.)
 __global__ __launch_bounds__(NTHR) void stem7x7_c3_kernel(const float* __restrict__ x, int H, int W, int Ho, int Wo,
                                                           int64_t npix, const float* __restrict__ w,
                                                           const float* __restrict__ scale,
