@@ -18,7 +18,8 @@
 // (Also tried after the staging fix in skinny_wide_out_kernel: all 96 loads of a wide_in wave, and all 48 16-byte loads of a
 // narrow_out wave, requested in ONE batch instead of two -- 15.8 / 14.3 / 12.9 us against 13.6 / 11.1 / 12.3 us for two
 // batches: past ~48 requests per wave the queue, not the round trip, is what a wave waits for; and the saved z of the BNR
-// epilogue requested before the staging -- 14.8 against 14.6 us.  Not kept.)
+// epilogue requested before the staging -- 14.8 against 14.6 us; and, again after the staging fix, the workgroup's 64 x 128
+// output block through LDS into 16-byte stores on 512-byte row segments -- 10.3 / 14.9 us against 10.0 / 14.5 us.  Not kept.)
 #include "pl_internal.h"
 
 namespace pl {
