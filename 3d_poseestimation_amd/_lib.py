@@ -124,6 +124,7 @@ SIGNATURES = {
     "pl_mask_by_bits": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _P, _P]),
     "pl_conv_act_plane_scale": (_c.c_float, []),
     "pl_planes_split": (_c.c_int, [_P, _c.c_int64, _c.c_int, _c.c_float, _P, _P]),
+    "pl_planes_split_strided": (_c.c_int, [_P, _P, _P, _c.c_int, _c.c_float, _P, _P]),
     "pl_bn_train_fwd_ex": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _P, _P, _c.c_float, _c.c_float, _P, _P, _P, _c.c_int,
                                       _P, _P, _P, _P, _P, _P, _c.c_int, _P, _P, _P]),
     "pl_gemm_stat_groups": (_c.c_int, [_c.c_int64]),

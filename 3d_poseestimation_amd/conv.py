@@ -445,9 +445,37 @@ class PlaneLink:
         self.mode = mode          # PL_F16X3: two fp16 planes (fp32-grade); PL_BF16: one bf16 plane (bf16 STORAGE of the operands)
 
 
+def _planes_of_strided(base, dims, strides, offset, scale, mode):
+    """Planes of the strided view (dims, signed element strides, element offset) of `base` -- pl_planes_split_strided: the layout
+    change and the split in one launch."""
+    import ctypes
+    nd = len(dims)
+    d4 = (ctypes.c_int64 * 4)(*((1,) * (4 - nd) + tuple(int(v) for v in dims)))
+    s4 = (ctypes.c_int64 * 4)(*((0,) * (4 - nd) + tuple(int(v) for v in strides)))
+    out = torch.empty(tuple(int(v) for v in dims), dtype=torch.float32, device=base.device)
+    with _lib.on_device(base.device):
+        rc = _lib.lib().pl_planes_split_strided(base.data_ptr() + 4 * int(offset), d4, s4, mode, float(scale), out.data_ptr(),
+                                                _lib.current_stream_ptr())
+    _lib.check(rc, "pl_planes_split_strided")
+    return out
+
+
+def _planes_of_flipped_t(w_ohwi, scale, mode):
+    """Planes of w.flip(1, 2).permute(3, 1, 2, 0) -- [Cin][KH][KW][Cout], the stride-1 data gradient's kernel -- straight from
+    the (possibly non-contiguous) OHWI view: the flip is a negative stride."""
+    cout, kh, kw, cin = w_ohwi.shape
+    S = w_ohwi.stride()
+    if cout % 4 or w_ohwi.dtype != torch.float32:
+        return _planes_of(w_ohwi.flip(1, 2).permute(3, 1, 2, 0), scale, mode)
+    return _planes_of_strided(w_ohwi, (cin, kh, kw, cout), (S[3], -S[1], -S[2], S[0]), (kh - 1) * S[1] + (kw - 1) * S[2],
+                              scale, mode)
+
+
 def _planes_of(t, scale, mode=_lib.PL_F16X3):
     """fp32 tensor -> carrier holding its planes (weights: once per step and direction, they are small).  A PL_BF16
     carrier uses the first half of its bytes."""
+    if not t.is_contiguous() and 1 <= t.dim() <= 4 and t.shape[-1] % 4 == 0 and t.dtype == torch.float32 and t.numel() > 0:
+        return _planes_of_strided(t, t.shape, t.stride(), 0, scale, mode)       # (a permuted / transposed weight view)
     t = t.contiguous()
     out = torch.empty_like(t)
     with _lib.on_device(t.device):
@@ -754,10 +782,10 @@ class _ConvKxKPlanesFn(torch.autograd.Function):
                                                               1.0 / WEIGHT_PLANE_SCALE, inv.data_ptr(), _lib.current_stream_ptr())
                 _lib.check(rc, "pl_deconv4x4s2_planes_fwd")
             elif stride == 1:
-                wf = _planes_of(w.flip(1, 2).permute(3, 1, 2, 0), WEIGHT_PLANE_SCALE, mode)    # [Cin][KH][KW][Cout]
+                wf = _planes_of_flipped_t(w, WEIGHT_PLANE_SCALE, mode)                          # [Cin][KH][KW][Cout]
                 dx = _conv_planes_fwd(dzp, (B, ho, wo, cout), wf, (cin, kh, kw, cout), 1, kh - 1 - pad, 1.0 / WEIGHT_PLANE_SCALE, inv, mode)
             else:
-                wf = _planes_of(w.flip(1, 2).permute(3, 1, 2, 0), WEIGHT_PLANE_SCALE, mode)
+                wf = _planes_of_flipped_t(w, WEIGHT_PLANE_SCALE, mode)
                 # dz at the even pixels of a zero map the size the stride-1 gradient expects (planes are 16-bit: as int16)
                 hu, wu = H + 2 * pad - kh + 1, W + 2 * pad - kw + 1
                 up = torch.zeros(2, B, hu, wu, cout, dtype=torch.int16, device=dzp.device)
@@ -782,7 +810,9 @@ class _ConvKxKPlanesFn(torch.autograd.Function):
 
 def conv_planes(xp, weight_oihw, stride, pad, link):
     """xp: carrier [B, H, W, Cin]; weight: the nn.Conv2d parameter [Cout][Cin][KH][KW]."""
-    z, stat = _ConvKxKPlanesFn.apply(xp, to_ohwi(weight_oihw.float()), stride, pad, link)
+    # (the OHWI kernel as a VIEW of the parameter: its planes -- and the flipped / transposed ones of the backward -- are
+    #  gathered by pl_planes_split_strided, no layout copy)
+    z, stat = _ConvKxKPlanesFn.apply(xp, weight_oihw.float().permute(0, 2, 3, 1), stride, pad, link)
     link.stat = stat
     return z
 

@@ -33,6 +33,25 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     store_planes4(d, (size_t)i * 4, ld4(x + 4 * i));
 }
 
+// The same from a STRIDED 4-D view of the source (signed element strides; output contiguous [d0][d1][d2][d3], d3 % 4 == 0): a
+// convolution weight in the layout a GEMM wants -- OIHW -> OHWI, its transpose, its spatial flip -- goes from the parameter
+// to planes in ONE launch instead of a layout copy (+ a flip) + a split.  Weights are small: the gathers do not matter.
+struct Strided4 { int d1, d2, d3; int64_t s0, s1, s2, s3; };
+__global__ __launch_bounds__(256) void split_planes_strided_kernel(const float* __restrict__ x, Strided4 v, int64_t n4, PlaneOut o) {
+  const PlaneDst d = plane_dst(o);
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int q3 = v.d3 >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int i3 = (int)(i % q3) * 4;
+    int64_t r = i / q3;
+    const int i2 = (int)(r % v.d2); r /= v.d2;
+    const int i1 = (int)(r % v.d1);
+    const int64_t i0 = r / v.d1;
+    const float* p = x + i0 * v.s0 + i1 * v.s1 + i2 * v.s2 + (int64_t)i3 * v.s3;
+    store_planes4(d, (size_t)i * 4, make_float4(p[0], p[v.s3], p[2 * v.s3], p[3 * v.s3]));
+  }
+}
+
 // -------------------------------------------------------------------------------------
 // Small fixed-order column reductions.  Shape of all three: block = 256 threads = 16 columns
 // x 16 row-parts, grid = ceil(H/16): every thread sums a strided 1/16 of the partial rows
@@ -1626,6 +1645,26 @@ extern "C" int pl_planes_split(const float* x, int64_t n, int mode, float scale,
   PlaneOut po;
   PL_TRY(plane_out_of(mode, planes, n, scale, nullptr, &po, "pl_planes_split"));
   return launch_split_planes(x, n, po, (hipStream_t)stream);
+}
+
+// planes of a strided 4-D view: element (i0, i1, i2, i3) of the (contiguous) result is x[i0 s0 + i1 s1 + i2 s2 + i3 s3] -- x already
+// points at element (0, 0, 0, 0) of the view, strides in elements and signed (a flipped axis: negative).  dims[3] % 4 == 0.
+extern "C" int pl_planes_split_strided(const float* x, const int64_t* dims, const int64_t* strides, int mode, float scale,
+                                       void* planes, void* stream) {
+  if (!x || !dims || !strides || !planes || !(scale > 0.f)) PL_FAIL(PL_EINVAL, "pl_planes_split_strided: bad arguments");
+  for (int i = 0; i < 4; ++i)
+    if (dims[i] <= 0 || dims[i] > INT32_MAX) PL_FAIL(PL_ESHAPE, "pl_planes_split_strided: dims[%d] = %lld", i, (long long)dims[i]);
+  if (dims[3] & 3) PL_FAIL(PL_ESHAPE, "pl_planes_split_strided: innermost extent %lld is not a multiple of 4", (long long)dims[3]);
+  const int64_t n = dims[0] * dims[1] * dims[2] * dims[3];
+  PlaneOut po;
+  PL_TRY(plane_out_of(mode, planes, n, scale, nullptr, &po, "pl_planes_split_strided"));
+  const Strided4 v = {(int)dims[1], (int)dims[2], (int)dims[3], strides[0], strides[1], strides[2], strides[3]};
+  const int64_t n4 = n >> 2;
+  int blocks = (int)((n4 + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(split_planes_strided_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, v, n4, po);
+  PL_CHECK_LAUNCH("split_planes_strided");
+  return PL_OK;
 }
 
 extern "C" int pl_bn_train_fwd(const float* z, int64_t rows, int64_t C, const float* gamma, const float* beta, float eps,

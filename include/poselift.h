@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PL_VERSION 103 /* 0.1.3: + pl_bn_join_bwd (0.1.2: operand-plane outputs of the BatchNorm / join kernels, pl_gemm_planes_raw) */
+#define PL_VERSION 104 /* 0.1.4: + pl_planes_split_strided; 0.1.3: + pl_bn_join_bwd (0.1.2: operand-plane outputs of the BatchNorm / join kernels, pl_gemm_planes_raw) */
 
 typedef enum PLStatus {
   PL_OK = 0,
@@ -269,6 +269,12 @@ int pl_mask_by_bits(const float* g, const uint64_t* bits, int64_t rows, int64_t 
  *   pl_mask_add_by_bits : dx = (g + g2) masked (g2 may be NULL): the join's backward with the gradient sum folded in */
 float pl_conv_act_plane_scale(void);   /* S of every activation-plane output of the conv-path entries below (1/64) */
 int pl_planes_split(const float* x, int64_t n, int planes_mode, float scale, void* planes, void* stream);
+/* The same from a strided 4-D view of the source (a convolution weight in the layout its GEMM wants -- OIHW -> OHWI, the
+ * transpose, the spatial flip of conv.py's data gradients -- straight from the nn.Conv2d parameter, one launch): element
+ * (i0,i1,i2,i3) of the contiguous result is x[i0 s0 + i1 s1 + i2 s2 + i3 s3]; x points at the view's first element, strides are
+ * in elements and signed (a flipped axis has a negative one); dims[3] % 4 == 0. */
+int pl_planes_split_strided(const float* x, const int64_t* dims, const int64_t* strides, int planes_mode, float scale,
+                            void* planes, void* stream);
 int pl_bn_train_fwd_ex(const float* z, int64_t rows, int64_t C, const float* gamma, const float* beta, float eps,
                        float momentum, float* running_mean, float* running_var, int64_t* batches, int relu,
                        float* y, uint64_t* bits, float* mean, float* rstd, void* scratch, void* y_planes,

@@ -649,6 +649,33 @@ def test_graphed_module_step_replays_the_eager_step_bit_for_bit(pkg, dtype):
         pkg.GraphedModuleStep(m1, torch.optim.Adam(m1.parameters(), lr=1e-3), F.mse_loss, frames[0], targets[0])
 
 
+@pytest.mark.parametrize("mode", ["f16x3", "bf16p"])
+def test_planes_of_strided_views_equal_planes_of_their_copies(pkg, mode):
+    """pl_planes_split_strided (conv._planes_of on a non-contiguous view, conv._planes_of_flipped_t): a convolution weight's
+    OHWI layout, its transpose and the flipped / transposed kernel of the stride-1 data gradient go from the OIHW parameter to
+    operand planes in one launch -- bit-identical to the layout copy followed by pl_planes_split."""
+    from importlib import import_module
+    cv = import_module("3d_poseestimation_amd.conv")
+    lib_mode = {"f16x3": pkg._lib.PL_F16X3, "bf16p": pkg._lib.PL_BF16}[mode]
+    w = (torch.randn(72, 32, 3, 3, generator=torch.Generator().manual_seed(5)) * 0.07).to(DEV)        # OIHW
+    used = 1 if mode == "f16x3" else 2                                       # (a bf16 carrier uses the first half of its bytes)
+    eq = lambda a, b: torch.equal(a.reshape(-1).view(torch.int32)[:a.numel() // used],                # noqa: E731
+                                  b.reshape(-1).view(torch.int32)[:b.numel() // used])
+    ohwi = w.permute(0, 2, 3, 1)
+    assert not ohwi.is_contiguous()
+    got = cv._planes_of(ohwi, 16.0, lib_mode)
+    want = cv._planes_of(ohwi.contiguous(), 16.0, lib_mode)
+    assert got.shape == want.shape and eq(got, want)
+    got = cv._planes_of_flipped_t(ohwi, 16.0, lib_mode)                      # from the view ...
+    want = cv._planes_of(ohwi.contiguous().flip(1, 2).permute(3, 1, 2, 0).contiguous(), 16.0, lib_mode)
+    assert tuple(got.shape) == (32, 3, 3, 72) and eq(got, want)
+    assert eq(cv._planes_of_flipped_t(ohwi.contiguous(), 16.0, lib_mode), want)                       # ... and from a copy
+    m = w.reshape(72, 288)
+    assert eq(cv._planes_of(m.t(), 16.0, lib_mode), cv._planes_of(m.t().contiguous(), 16.0, lib_mode))
+    v = torch.randn(8, 40, device=DEV)[:, ::2]                               # 1-D-ish strided rows, innermost stride 2
+    assert eq(cv._planes_of(v, 1.0, lib_mode), cv._planes_of(v.contiguous(), 1.0, lib_mode))
+
+
 @pytest.mark.parametrize("rows,C,two", [(1000, 320, True), (4096, 256, False), (777, 1024, True)])
 def test_bn_join_bwd_is_the_masked_sum_plus_batchnorm_backward_bit_for_bit(pkg, rows, C, two):
     """pl_bn_join_bwd (bn3 + residual join backward, the masked sum written by the pass that takes the BatchNorm-backward column
