@@ -69,10 +69,21 @@ int sync_gather(const PLDesc* d, float* base, int64_t floats_per_rank, hipStream
 // (PL_BF16X6: fp32 operands split inside the GEMM) -- never a lower precision, never the CPU.
 // PL_BF16 takes the same path with ONE bf16 plane per tensor (kind 1): bf16 STORAGE of the GEMM operands
 // (activations, dz, weight shadow), no scales -- bf16 has fp32's exponent range.
+int tn_splits(int M, int N, int K) {
+  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  int s = 256 / tiles;
+  const int kmax = (K + 127) / 128;
+  if (s > kmax) s = kmax;
+  return s < 1 ? 1 : s;
+}
+
 inline int planes_kind(const PLDesc* d, int64_t B) {       // PlaneOut::kind of the operand planes, 0 = not on that path
   const bool ok = d->bn && sync_world(d) == 1 && d->hidden % 128 == 0 && B % 128 == 0 && d->num_stage >= 1 &&
                   B * (int64_t)d->hidden * 4 < (1ll << 30);
   if (!ok) return 0;
+  // the weight-gradient GEMM splits K = B into tn_splits slices of whole 32-k tiles (H = 512 with B = 128 * 17 would
+  // not): such a batch runs on the round-1 kernels like every other shape off the tile grid
+  if (B % (32 * (int64_t)tn_splits(d->hidden, d->hidden, (int)B)) != 0) return 0;
   return d->dtype == PL_F16X3 ? 2 : (d->dtype == PL_BF16 ? 1 : 0);
 }
 // BatchNorm-backward pass 1 of hidden layer l is folded into the epilogue of the dX GEMM of layer l+1 (which produces
@@ -114,14 +125,6 @@ ParamLayout param_layout(const PLDesc* d) {
   add(d->out_dim);
   p.total = o;
   return p;
-}
-
-int tn_splits(int M, int N, int K) {
-  const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
-  int s = 256 / tiles;
-  const int kmax = (K + 127) / 128;
-  if (s > kmax) s = kmax;
-  return s < 1 ? 1 : s;
 }
 
 // Output layer y = h W^T + b with N = out_dim (51): only ceil(M/128) tiles, so the K = hidden

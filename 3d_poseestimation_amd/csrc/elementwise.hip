@@ -1042,6 +1042,35 @@ __global__ void flip_tta_merge_kernel(const float* __restrict__ yy, float* __res
   y[i] = (v + yy[i]) / 2.0f;
 }
 
+// The training-mode Flip branch of the phase5 cycle step (train_5 copy.py:174-199) composes flip_pose with an average:
+//   y = (flip_pose(a) + b) / 2, and its backward  da = flip_pose'(g) / 2  (x negated, joints swapped: no 1 - x offset).
+// out = (x_offset_if_d0 - / + in[src joint]) [+ addend] ) * scale in ONE pass.
+__global__ void flip_pose_ex_kernel(const float* __restrict__ in, const float* __restrict__ addend, float* __restrict__ out,
+                                    int64_t n, int D, float x_offset, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int d = (int)(i % D);
+  const int64_t bj = i / D;
+  const int j = (int)(bj % 17);
+  const int64_t b = bj / 17;
+  float v = in[(b * 17 + flip_src_joint(j)) * D + d];
+  if (d == 0) v = x_offset - v;
+  if (addend) v += addend[i];
+  out[i] = v * scale;
+}
+
+// torch.flip(frame, (W,)) of NHWC frames (train_5 copy.py:176 flips the NCHW frame along dim 3 = width): one element per
+// thread, writes coalesced, reads reversed in groups of C
+__global__ void flip_w_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t n, int W, int C) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % C);
+  const int64_t p = i / C;
+  const int w = (int)(p % W);
+  const int64_t row = p / W;
+  out[i] = in[(row * W + (W - 1 - w)) * C + c];
+}
+
 // ---- batch gather (data.py PoseFeeder): rows idx[0..n) of two resident row-major tables ----------
 // oa[i][:] = a[idx[i]][:] (wa floats), ob[i][:] = b[idx[i]][:] (wb floats); one thread per output float
 __global__ void gather_rows2_kernel(const float* __restrict__ a, int wa, const float* __restrict__ b, int wb,
@@ -1558,6 +1587,28 @@ extern "C" int pl_flip_tta_merge(const float* yy, float* y, int64_t B, int64_t j
   hipLaunchKernelGGL(flip_tta_merge_kernel, dim3((unsigned)((n + NTHR - 1) / NTHR)), dim3(NTHR), 0,
                      (hipStream_t)stream, yy, y, n, (int)D);
   PL_CHECK_LAUNCH("flip_tta_merge");
+  return PL_OK;
+}
+
+extern "C" int pl_flip_pose_ex(const float* in, const float* addend, float* out, int64_t B, int64_t joints, int64_t D,
+                               float x_offset, float scale, void* stream) {
+  if (!in || !out || in == out || addend == out) PL_FAIL(PL_EINVAL, "pl_flip_pose_ex: null or aliased pointers");
+  if (B <= 0 || joints != 17 || (D != 2 && D != 3)) PL_FAIL(PL_ESHAPE, "pl_flip_pose_ex: expects (B, 17, 2|3)");
+  const int64_t n = B * joints * D;
+  hipLaunchKernelGGL(flip_pose_ex_kernel, dim3((unsigned)((n + NTHR - 1) / NTHR)), dim3(NTHR), 0, (hipStream_t)stream,
+                     in, addend, out, n, (int)D, x_offset, scale);
+  PL_CHECK_LAUNCH("flip_pose_ex");
+  return PL_OK;
+}
+
+extern "C" int pl_flip_w_nhwc(const float* in, float* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream) {
+  if (!in || !out || in == out) PL_FAIL(PL_EINVAL, "pl_flip_w_nhwc: null or aliased pointers");
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || W > (1 << 30) || C > (1 << 30)) PL_FAIL(PL_ESHAPE, "pl_flip_w_nhwc: bad shape");
+  const int64_t n = B * H * W * C;
+  if ((n + NTHR - 1) / NTHR > 0x7fffffffLL) PL_FAIL(PL_ESHAPE, "pl_flip_w_nhwc: tensor too large");
+  hipLaunchKernelGGL(flip_w_nhwc_kernel, dim3((unsigned)((n + NTHR - 1) / NTHR)), dim3(NTHR), 0, (hipStream_t)stream,
+                     in, out, n, (int)W, (int)C);
+  PL_CHECK_LAUNCH("flip_w_nhwc");
   return PL_OK;
 }
 

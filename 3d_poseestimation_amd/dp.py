@@ -200,3 +200,43 @@ class FlatGrads:
         else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.flat.div_(world)
+
+
+class SyncedOptimizer:
+    """An optimizer facade for steps that drive SEVERAL models with one backward (train.cycle_step: Model_2D,
+    Model_3D, lifter, projector -- BASELINE configs[4], phase5 data parallel): zero_grad() / step() as the step calls
+    them, with the gradient average in between.
+
+      * a FlatAdamW (lifter / projector): ONE sum all-reduce of the model's flat gradient arena, the 1/world average
+        folded into the AdamW launch (grad_scale) -- GradSync, no overlap (two lifter calls per graph contribute first);
+      * any torch optimizer over a module with ordinary parameters (the conv models): the module's gradients live in
+        one FlatGrads buffer, zero_grad() zeroes it in place, step() all-reduces it once and steps.
+    Without an initialised process group (or world 1) it is the optimizer itself."""
+
+    def __init__(self, optimizer, module, group=None, bucket_bytes=None):
+        from .optim import FlatAdamW
+        self.optimizer, self.module, self.group = optimizer, module, group
+        self.param_groups = optimizer.param_groups
+        self._flat_adamw = isinstance(optimizer, FlatAdamW)
+        self._sync = GradSync(group, bucket_bytes, overlap=False) if self._flat_adamw else None
+        self._flat = None if self._flat_adamw else FlatGrads(module, group, bucket_bytes)
+
+    def zero_grad(self, set_to_none=False):
+        if self._flat_adamw:
+            self.optimizer.zero_grad()
+        else:
+            if not self._flat.attached():                 # (someone set the grads to None: re-attach the views)
+                self._flat = FlatGrads(self.module, self.group, self._flat.bucket_bytes)
+            self._flat.zero()
+
+    def step(self):
+        if self._flat_adamw:
+            return self.optimizer.step(grad_scale=self._sync(self.module))
+        self._flat.all_reduce_mean()
+        return self.optimizer.step()
+
+    def state_dict(self):
+        return self.optimizer.state_dict()
+
+    def load_state_dict(self, sd):
+        return self.optimizer.load_state_dict(sd)

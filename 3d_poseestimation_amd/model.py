@@ -201,9 +201,9 @@ class LinearModel(nn.Module):
         if self._sync_struct is not None:
             self._desc.sync = ctypes.pointer(self._sync_struct)
         # GEMM operand planes of the 1024-wide weights (PL_F16X3 / PL_BF16), kept across calls: FlatAdamW refreshes them
-        # while it updates the parameters, so the forward has no weight-split pass.  _wplanes_ver = the version of the
-        # parameter arena they were derived from (any in-place torch op on a parameter bumps it: then they are stale
-        # and the next forward refreshes them itself).
+        # while it updates the parameters, so the forward has no weight-split pass.  _wplanes_ver = _planes_key() of the
+        # parameters they were derived from (any in-place torch op on a parameter changes the key: then they are stale
+        # and the next forward refreshes them first).
         self._wplanes, self._wplanes_ver = None, None
         nbytes = 0
         if flat.is_cuda and os.environ.get("POSELIFT_NO_WPLANES") != "1":     # (=1: same-box A/B of the per-call split)
@@ -215,17 +215,29 @@ class LinearModel(nn.Module):
             self._wplanes = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             self._desc.wplanes = self._wplanes.data_ptr()
 
+    def _planes_key(self):
+        """What the persistent weight planes were derived from.  The parameters are attached to the arena with
+        `p.data = view`, so every Parameter keeps its OWN version counter: an in-place torch op on a parameter
+        (load_state_dict, nn.init.*, torch.optim.*.step) bumps p._version, never the arena's -- the key therefore holds
+        every parameter's counter next to the arena's (and the arena's address: .to() / re-flattening)."""
+        return (self._flat.data_ptr(), self._flat._version) + tuple(p._version for p in self._param_list)
+
     def _mark_wplanes(self):
-        """Before a library call that runs a forward: tell it whether the persistent weight planes are current; the
-        call refreshes them when they are not, so afterwards they are."""
+        """Before a library call that runs a forward: make the persistent weight planes current (an explicit
+        pl_wplanes_refresh when any parameter changed since they were written) and say so.  The library itself only
+        re-splits on calls that take the planes path (whole 128-row tiles, local statistics), so "the call will
+        refresh them" is not something the host can assume for an arbitrary batch."""
         if self._wplanes is not None:
-            self._desc.wplanes_valid = int(self._wplanes_ver is not None and self._wplanes_ver == self._flat._version)
-            self._wplanes_ver = self._flat._version
+            self._ensure_wplanes()
+            self._desc.wplanes_valid = 1
 
     def _ensure_wplanes(self):
-        if self._wplanes is not None and self._wplanes_ver != self._flat._version:
+        if self._wplanes is None:
+            return
+        key = self._planes_key()
+        if self._wplanes_ver != key:
             _lib.check(_lib.lib().pl_wplanes_refresh(ctypes.byref(self._desc), _lib.current_stream_ptr()), "pl_wplanes_refresh")
-            self._wplanes_ver = self._flat._version
+            self._wplanes_ver = key
 
     def adamw_plane_segments(self):
         """PLAdamWPlanes for pl_adamw_flat_planes, or None: where the weight planes of each 1024-wide Linear go."""

@@ -106,8 +106,8 @@ class FlatAdamW(torch.optim.Optimizer):
                     t_dev.data_ptr() if t_dev is not None else None, float(grad_scale),
                     _lib.ctypes.byref(planes) if planes is not None else None, _lib.current_stream_ptr())
                 _lib.check(rc, "pl_adamw_flat_planes")
-        # the raw-pointer write does not bump the arena's version counter: say explicitly what the planes now are
-        model._wplanes_ver = flat._version if planes is not None else None
+        # the raw-pointer write bumps no version counter: say explicitly what the planes now are
+        model._wplanes_ver = model._planes_key() if planes is not None else None
 
     # ---- graph replay (train.GraphedTrainStep): the step with t and lr read from device memory ----------------
     def _enqueue_dev(self, lr_dev, t_base, t_dev, grad_scale=1.0):

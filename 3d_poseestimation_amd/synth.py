@@ -57,3 +57,21 @@ def seeded_frames(batch, seed, size=256):
     """[batch, size, size, 3] NHWC frames in [0, 1) (the phase4 loader divides by 256)."""
     g = torch.Generator().manual_seed(int(seed))
     return torch.rand(batch, size, size, 3, generator=g)
+
+
+def structured_frames(batch, seed, size=256):
+    """[batch, size, size, 3] NHWC frames in [0, 1) that DIFFER from each other at low frequency: 30 % noise plus a
+    Gaussian blob whose position, width and colour depend on the frame.  Untrained heat-map networks predict the same
+    pose for every frame of pure noise; the lifter's BatchNorm1d then normalises a batch of near-identical rows and
+    every gradient behind it is amplified round-off (fp32 vs fp64 of stock torch differ by 80 %).  With these frames the
+    predictions spread (2-D: 0.05) and the cycle step is a well-conditioned test problem."""
+    g = torch.Generator().manual_seed(int(seed))
+    frames = torch.rand(batch, size, size, 3, generator=g)
+    lin = torch.linspace(0, 1, size)
+    yy, xx = torch.meshgrid(lin, lin, indexing="ij")
+    for b in range(batch):
+        k = b % 4
+        cx, cy = 0.2 + 0.2 * k + 0.013 * (b // 4), 0.8 - 0.15 * k - 0.011 * (b // 4)
+        blob = torch.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (0.02 + 0.01 * k))
+        frames[b] = 0.3 * frames[b] + 0.7 * blob[..., None] * torch.tensor([1.0, 0.5 + 0.1 * k, 0.2 * k])
+    return frames

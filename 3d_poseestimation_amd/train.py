@@ -4,7 +4,7 @@
   eval_step         /root/reference/phase1_lifting/train_1.py:112-145
   loss_MPJPE        /root/reference/phase1_lifting/train_1.py:19-23
   epoch_mpjpe_mm    /root/reference/phase1_lifting/train_1.py:100-104
-  cycle_step        /root/reference/phase5_loop/train_5 copy.py:147-236 (the Triangle branch, without its Flip pass)
+  cycle_step        /root/reference/phase5_loop/train_5 copy.py:147-236 (the Triangle branch; Flip=True: :174-199)
 All arithmetic is in libposelift.so; tensors must live on the ROCm device.
 """
 import torch
@@ -64,18 +64,69 @@ def loss_MPJPE(prediction, target, out=None):
     return metric
 
 
+def _check_pose(data, what):
+    _lib.require_device_tensor(data, what)
+    if data.dim() != 3 or data.shape[1] != 17 or data.shape[2] not in (2, 3):
+        raise ValueError(f"{what}: expects (N, 17, 2) or (N, 17, 3)")
+
+
+def _flip_ex(src, addend, x_offset, scale):
+    out = torch.empty_like(src)
+    with _lib.on_device(src.device):
+        rc = _lib.lib().pl_flip_pose_ex(src.data_ptr(), addend.data_ptr() if addend is not None else None, out.data_ptr(),
+                                        src.shape[0], 17, src.shape[2], float(x_offset), float(scale),
+                                        _lib.current_stream_ptr())
+    _lib.check(rc, "pl_flip_pose_ex")
+    return out
+
+
+class _FlipAvgFn(torch.autograd.Function):
+    """y = (flip_pose(a) + b) * scale [b optional] with its backward (flip_pose is an affine involution: the gradient is
+    the joint swap with x negated -- no `1 - x` offset)."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        a = a.contiguous()
+        _check_pose(a, "flip_pose input")
+        if b is not None:
+            b = b.contiguous()
+            _check_pose(b, "flip_pose addend")
+            if b.shape != a.shape:
+                raise ValueError(f"flip average: shapes differ: {tuple(a.shape)} vs {tuple(b.shape)}")
+        ctx.scale, ctx.has_b = scale, b is not None
+        return _flip_ex(a, b, 1.0 if a.shape[2] == 2 else 0.0, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        da = _flip_ex(g, None, 0.0, ctx.scale) if ctx.needs_input_grad[0] else None
+        db = g * ctx.scale if (ctx.has_b and ctx.needs_input_grad[1]) else None
+        return da, db, None
+
+
 def flip_pose(data):
     """utils.py:372-396: horizontal flip of (N, 17, 2|3) poses (x -> 1-x or -x, left/right joints
-    swapped).  The flip-TTA of train_1.py:128-134 is `(flip_pose(model(flip_pose(x))) + model(x)) / 2`."""
-    data = data.contiguous()
-    _lib.require_device_tensor(data, "data")
-    if data.dim() != 3 or data.shape[1] != 17 or data.shape[2] not in (2, 3):
-        raise ValueError("flip_pose expects (N, 17, 2) or (N, 17, 3)")
-    out = torch.empty_like(data)
-    with _lib.on_device(data.device):
-        rc = _lib.lib().pl_flip_pose(data.data_ptr(), out.data_ptr(), data.shape[0], 17, data.shape[2],
-                                     _lib.current_stream_ptr())
-    _lib.check(rc, "pl_flip_pose")
+    swapped); differentiable.  The flip-TTA of train_1.py:128-134 is `(flip_pose(model(flip_pose(x))) + model(x)) / 2`."""
+    return _FlipAvgFn.apply(data, None, 1.0)
+
+
+def flip_average(a, b):
+    """(flip_pose(a) + b) / 2 in one pass, differentiable in both: the combination every line of the training-mode Flip
+    branch forms (train_5 copy.py:180-196)."""
+    return _FlipAvgFn.apply(a, b, 0.5)
+
+
+def flip_frames_nhwc(frame_nhwc):
+    """torch.flip(frame, (3,)) of train_5 copy.py:176 (width of the NCHW frame) on the NHWC frames this path keeps."""
+    f = frame_nhwc.contiguous()
+    _lib.require_device_tensor(f, "frames")
+    if f.dim() != 4:
+        raise ValueError("flip_frames_nhwc expects [B, H, W, C]")
+    out = torch.empty_like(f)
+    with _lib.on_device(f.device):
+        rc = _lib.lib().pl_flip_w_nhwc(f.data_ptr(), out.data_ptr(), f.shape[0], f.shape[1], f.shape[2], f.shape[3],
+                                       _lib.current_stream_ptr())
+    _lib.check(rc, "pl_flip_w_nhwc")
     return out
 
 
@@ -171,18 +222,39 @@ class GraphedTrainStep:
                 optimizer._enqueue_dev(self._lr_dev, t0, self._tick)
             self.y_hat = y_hat.reshape(self._out_shape)
             model._step = step0                                              # capturing ran nothing
+        # the graph owns the dropout-stream step and AdamW's t (both = the capture-time base + the device counter):
+        # what __call__ checks the host-side counters against
+        self._step0, self._t0, self._seed0, self.replays = step0, t0, model._seed, 0
+        self._ptrs = self._baked_ptrs()
+
+    def _baked_ptrs(self):
+        return (self.model.flat_params.data_ptr(), self.opt._m.data_ptr() if self.opt._m is not None else 0,
+                self.opt._v.data_ptr() if self.opt._v is not None else 0)
 
     def __call__(self, y1, y2):
         lr = float(self.opt.param_groups[0]["lr"])
         if lr != self._lr:                                                   # ReduceLROnPlateau et al. (train_1.py:106)
             self._lr = lr
             self._lr_dev.fill_(lr)
+        # an eager train_step / optimizer.step() / load_state_dict() between replays moves the host-side counters but
+        # not the device counter the captured launches read: re-seed it when both moved together, refuse otherwise
+        ds, dt = self.model._step - self._step0, self.opt._t - self._t0
+        if self.model._seed != self._seed0 or self._baked_ptrs() != self._ptrs:
+            raise _lib.PoseliftError("GraphedTrainStep: the dropout seed or an arena address changed after capture "
+                                     "(manual_seed, optimizer.load_state_dict, .to()): capture a new GraphedTrainStep")
+        if ds != dt or ds < 0:
+            raise _lib.PoseliftError(f"GraphedTrainStep: the model ran {ds} steps since capture but the optimizer {dt}: "
+                                     "the graph advances both from one device counter -- capture a new one")
+        if ds != self.replays:
+            self._tick.fill_(ds)
+            self.replays = ds
         self._x.copy_(y1.reshape(self._x.shape))
         self._y.copy_(y2.reshape(self._y.shape))
         self.model._ensure_wplanes()         # parameters changed behind the graph's back (load_state_dict, ...)
         self.graph.replay()
         self.model._step += 1
         self.opt._advance_host(1)
+        self.replays += 1
         return self.loss, self.y_hat
 
 
@@ -295,11 +367,17 @@ def eval_step(model, y1, y2, metric_out=None, flip=False):
     return loss, metric, y2_hat
 
 
-def cycle_step(model_2d, model_3d, model_lift, optimizers, frame_nhwc, y1, y2, loss_function, model_proj=None):
-    """One phase5 cycle step (train_5 copy.py:147-236, `Triangle` on, `Flip` off): zero_grad on every optimizer;
+def cycle_step(model_2d, model_3d, model_lift, optimizers, frame_nhwc, y1, y2, loss_function, model_proj=None, Flip=False):
+    """One phase5 cycle step (train_5 copy.py:147-236, `Triangle` on): zero_grad on every optimizer;
     y1^ = model_2d(frame), y2^ = model_3d(frame); the lifter on the predicted AND on the ground-truth 2-D pose (two
     calls in one graph: its input gradient flows back into model_2d); optionally the projector on y2^ and y2;
-    TriangleLoss; ONE backward; every optimizer steps.  frame_nhwc [B, H, W, 3]; y1 [B, 17, 2]; y2 [B, 17, 3].
+    [the Flip branch]; TriangleLoss; ONE backward; every optimizer steps.
+    Flip=True reproduces train_5 copy.py:174-199 literally: every network runs a SECOND training-mode forward (its
+    BatchNorm statistics move twice per step, as in the reference) -- the backbones on the mirrored frames, the lifter
+    on the AVERAGED 2-D prediction (:183 feeds `y1_hat` after :180 has overwritten it with the average; it is not
+    flipped) and on the flipped ground truth (:184), the projector on the averaged 3-D prediction and on flip(y2) -- and
+    each result becomes (flip_pose(second) + first) / 2.
+    frame_nhwc [B, H, W, 3]; y1 [B, 17, 2]; y2 [B, 17, 3].
     Returns (loss, y1_hat, y2_hat) as device tensors (the reference's `.cpu().item()` per step is the caller's choice)."""
     for opt in optimizers:
         opt.zero_grad()
@@ -310,9 +388,25 @@ def cycle_step(model_2d, model_3d, model_lift, optimizers, frame_nhwc, y1, y2, l
     y2_hat = model_3d.predict_nhwc(frame).reshape(B, 17, 3)
     lift_2d_pred = model_lift(y1_hat).reshape(B, 17, 3)
     lift_2d_gt = model_lift(y1).reshape(B, 17, 3)
+    proj_3d_pred = proj_3d_gt = None
+    if model_proj is not None:
+        proj_3d_pred = model_proj(y2_hat).reshape(B, 17, 2)
+        proj_3d_gt = model_proj(y2).reshape(B, 17, 2)
+    if Flip:
+        frame_f = flip_frames_nhwc(frame)                                                    # :176
+        y1_f = flip_pose(y1)                                                                 # :178
+        y1_hat = flip_average(model_2d.predict_nhwc(frame_f).reshape(B, 17, 2), y1_hat)      # :180
+        y2_hat = flip_average(model_3d.predict_nhwc(frame_f).reshape(B, 17, 3), y2_hat)      # :181
+        lift_2d_pred = flip_average(model_lift(y1_hat).reshape(B, 17, 3), lift_2d_pred)      # :184
+        lift_2d_gt = flip_average(model_lift(y1_f).reshape(B, 17, 3), lift_2d_gt)            # :185
+        if model_proj is not None:
+            y2_f = flip_pose(y2)                                                             # :189
+            proj_3d_pred = flip_average(model_proj(y2_hat).reshape(B, 17, 2), proj_3d_pred)  # :191
+            proj_3d_gt = flip_average(model_proj(y2_f).reshape(B, 17, 2), proj_3d_gt)        # :192
+        # (:194, :197-198 flip y2, the frame and y1 back: out of place here, the originals are still y1 / y2 / frame)
     kw = {}
     if model_proj is not None:
-        kw = dict(proj_3d_pred=model_proj(y2_hat).reshape(B, 17, 2), proj_3d_gt=model_proj(y2).reshape(B, 17, 2))
+        kw = dict(proj_3d_pred=proj_3d_pred, proj_3d_gt=proj_3d_gt)
     out = loss_function(predicted_2d=y1_hat, predicted_3d=y2_hat, lift_2d_gt=lift_2d_gt, lift_2d_pred=lift_2d_pred,
                         gt_2d=y1, gt_3d=y2, **kw)
     loss = out[0] if isinstance(out, tuple) else out

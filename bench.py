@@ -78,7 +78,59 @@ def parse():
                     help="N>1 only: BatchNorm statistics over the global batch (10 small all-gathers per step); "
                          "off by default = statistics per shard, the DDP convention")
     ap.add_argument("--no-extras", action="store_true", help="skip the bf16-mode and PyTorch-eager side measurements")
-    return ap.parse_args()
+    ap.add_argument("--workload", choices=["lifter", "cycle"], default="lifter",
+                    help="lifter (default): BASELINE configs[1]/[2], the headline.  cycle: BASELINE configs[4], one phase5 "
+                         "cycle step (Model_2D + Model_3D on 256x256 frames, lifter x2, projector, TriangleLoss, Adam x4) at "
+                         "128 frames per GPU (1024 over 8 GPUs); its own JSON line (frames/s)")
+    ap.add_argument("--flip", action="store_true", help="cycle workload: the training-mode Flip branch (train_5 copy.py:174-199)")
+    a = ap.parse_args()
+    if a.workload == "cycle" and a.batch == BATCH:
+        a.batch = 128                                       # configs[4]: batch 1024 over 8 GPUs
+    if a.workload == "cycle" and a.steps == 200 and a.warmup == 20:
+        a.steps, a.warmup = 10, 3                           # a cycle step is ~0.1 s: defaults that finish in minutes
+    return a
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks here, one process per GPU, and relay rank 0's
+    JSON line.  The parent never touches the GPU (torch.cuda.device_count() does not initialise it on this image);
+    any rank that fails takes the job down with a non-zero exit -- an `n_gpus: 1` line for a `--gpus 8` request
+    can not happen."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    backend = os.environ.get("POSELIFT_DIST_BACKEND")
+    if have < a.gpus and backend != "gloo":
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} GPU(s) visible (POSELIFT_DIST_BACKEND=gloo rehearses "
+                         f"more ranks than devices, all folded onto the visible ones)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile("w+") as out0:
+        for r in range(a.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        failed = False
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs):         # one rank died: the others would wait in a collective
+                failed = True
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()
+                break
+            time.sleep(0.2)
+        rcs = [p.wait() for p in procs]
+        out0.seek(0)
+        line = out0.read()
+    if failed or any(rcs):
+        raise SystemExit(f"bench.py --gpus {a.gpus}: a rank failed (exit codes {rcs}); no result line")
+    sys.stdout.write(line)
+    sys.stdout.flush()
 
 
 def host_cores():
@@ -298,14 +350,154 @@ def batch64_latency(pkg, a, dev, warm=20, steps=50):
             "how": f"median of {steps} synchronised steps after {warm} warm-ups (host launch latency included)"}
 
 
+def conv_macs_per_frame(model, size=256):
+    """Forward multiply-accumulates of one heat-map network (backbone + head) per frame, from the modules' shapes."""
+    import torch.nn as nn
+    macs, hw = 0, {}
+
+    def walk(mod, h):
+        nonlocal macs
+        for m in mod.children():
+            if isinstance(m, nn.Conv2d):
+                h = (h + 2 * m.padding[0] - m.kernel_size[0]) // m.stride[0] + 1
+                macs += h * h * m.out_channels * m.in_channels * m.kernel_size[0] * m.kernel_size[1]
+            elif isinstance(m, nn.ConvTranspose2d):
+                h = h * 2
+                macs += h * h * m.out_channels * m.in_channels * 4          # 4x4 stride 2: four taps per output pixel
+        return h
+    r = model.preact
+    h = walk(nn.Sequential(r.conv1), size)
+    h = (h + 2 - 3) // 2 + 1                                               # max-pool 3x3 / 2
+    for li in (1, 2, 3, 4):
+        for blk in getattr(r, f"layer{li}"):
+            hin = h
+            h1 = walk(nn.Sequential(blk.conv1), hin)
+            h2 = walk(nn.Sequential(blk.conv2), h1)
+            h = walk(nn.Sequential(blk.conv3), h2)
+            if blk.downsample is not None:
+                walk(nn.Sequential(blk.downsample[0]), hin)
+    h = walk(model.deconv_layers, h)
+    walk(nn.Sequential(model.final_layer), h)
+    return macs
+
+
+def cycle_workload(pkg, a, rank, local, world):
+    """BASELINE configs[4]: one phase5 cycle step (train_5 copy.py:147-236) per `step`, 128 frames of 256 x 256 per GPU,
+    data parallel = one gradient all-reduce per model (dp.SyncedOptimizer).  Reference optimizers: Adam on all four models."""
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU path")
+    dev = pkg.dp.local_device(local)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)
+    m2, m3 = pkg.Model_2D().train(), pkg.Model_3D().train()
+    for m, seed in ((m2, 61), (m3, 62)):
+        m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), seed))
+        with torch.no_grad():
+            m.final_layer.weight.mul_(1e-3)
+    macs = conv_macs_per_frame(m2) + conv_macs_per_frame(m3)
+    m2, m3 = m2.to(dev), m3.to(dev)
+    lift = pkg.LinearModel(34, 51, linear_size=1024, p_dropout=0.5, compute_dtype="f16x3").to(dev).train()   # train_5 copy.py:94
+    proj = pkg.LinearModel(51, 34, linear_size=64, p_dropout=0.5, compute_dtype="f16x3").to(dev).train()     # :96
+    lift.manual_seed(1234 + rank); proj.manual_seed(4321 + rank)
+    lr = 1e-4
+    opts = [torch.optim.Adam(m2.parameters(), lr=lr), torch.optim.Adam(m3.parameters(), lr=lr),               # :105-109
+            pkg.FlatAdamW(lift, lr=lr, weight_decay=0.0), pkg.FlatAdamW(proj, lr=lr, weight_decay=0.0)]
+    if world > 1:
+        opts = [pkg.dp.SyncedOptimizer(o, m) for o, m in zip(opts, (m2, m3, lift, proj))]
+    B = a.batch
+    pool = [(pkg.synth.seeded_frames(B, 70 + 10 * rank + i).to(dev),) + pkg.synth.synthetic_batch(B, 80 + 10 * rank + i, dev)
+            for i in range(2)]
+    crit = pkg.TriangleLoss(Project=True, era="lifter")
+    torch.cuda.synchronize()
+
+    def run(n, first=0):
+        loss = None
+        for i in range(first, first + n):
+            fr, y1, y2 = pool[i % len(pool)]
+            loss = pkg.cycle_step(m2, m3, lift, opts, fr, y1, y2, crit, model_proj=proj, Flip=a.flip)[0]
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+    run(a.warmup)
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = run(a.steps, a.warmup)
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        passes = 2 if a.flip else 1
+        flop_frame = 2.0 * macs * 3 * passes                  # forward + data gradient + weight gradient (convolutions only)
+        value = B * world * a.steps / dt
+        tf = value * flop_frame / 1e12
+        out = {"metric": "frames/sec, phase5 cycle step (Model_2D + Model_3D on 256x256 frames, lifter x2, projector, TriangleLoss, Adam x4)",
+               "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f16x3 (two fp16 planes per fp32 operand, 3 fp16 MFMAs per product, fp32 accumulate)", "data": "synthetic",
+               "config": {"workload": "BASELINE configs[4]: phase5_loop train_5 copy.py:147-236 cycle step, Triangle + Project"
+                                      + (" + Flip" if a.flip else "") + (f", {dist.get_backend()} gradient all-reduce per model" if world > 1 else ""),
+                          "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                          "frame": "256x256x3 NHWC", "lifter": "LinearModel(34,51,1024)", "projector": "LinearModel(51,34,64)"},
+               "final_loss": float(loss),
+               "roofline": {"bound": "mfma", "achieved": round(tf / world, 2), "peak": PEAK_BF16_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(tf / world / PEAK_BF16_MATRIX_TFLOPS, 4), "traffic": None,
+                            "kernel": "whole step (about 2,200 launches; no single dominant kernel), convolution FLOPs only",
+                            "flop_per_frame": flop_frame, "mfma_issue_frac": round(3 * tf / world / PEAK_BF16_MATRIX_TFLOPS, 4)}}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cycle_cpu_baseline(pkg, a.flip)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cycle_cpu_baseline(pkg, flip, B=4, steps=2):
+    """The same step on stock torch.nn modules (oracle/cycle_twin.py) on the host cores, fp32: a bounded sample."""
+    import copy
+    import torch
+    from oracle import cycle_twin as twin
+    from oracle.torch_twin import TwinLifter
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    m2, m3 = pkg.Model_2D().train(), pkg.Model_3D().train()
+    for m, seed in ((m2, 61), (m3, 62)):
+        m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), seed))
+    lift, proj = TwinLifter(34, 51, linear_size=1024).train(), TwinLifter(51, 34, linear_size=64).train()
+    opts = [torch.optim.Adam(m.parameters(), lr=1e-4) for m in (m2, m3, lift, proj)]
+    fr = pkg.synth.seeded_frames(B, 5).permute(0, 3, 1, 2).contiguous()
+    y1, y2 = pkg.synth.synthetic_batch(B, 6)
+    ts = []
+    for i in range(1 + steps):
+        t0 = time.perf_counter()
+        twin.cycle_step(m2, m3, lift, proj, opts, fr, y1, y2, flip)
+        if i:
+            ts.append(time.perf_counter() - t0)
+    t = _median(ts)
+    return {"value": round(B / t, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"median of {steps} cycle steps of the stock-PyTorch eager twin at batch {B} (256x256 frames), fp32, "
+                      f"{cores} threads, after 1 warm-up step", "ms_per_step": round(1e3 * t, 1), "torch": torch.__version__}
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(a)                               # before anything in this process touches the GPU
     import torch
     import torch.distributed as dist
     pkg = importlib.import_module("3d_poseestimation_amd")
     rank, local, world = pkg.dp.init_from_env()
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.workload == "cycle":
+        return cycle_workload(pkg, a, rank, local, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the lifter has no CPU path")
     dev = pkg.dp.local_device(local)
@@ -425,7 +617,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: phase1_lifting "
                                    "LinearModel 34-1024-2x(1024-1024)-51, BN+ReLU+Dropout(0.5), one train_1.py "
                                    "step = zero_grad+forward+MSE+backward+AdamW"
-                                   + ("+RCCL grad all-reduce" if world > 1 else ""),
+                                   + (f"+{dist.get_backend()} grad all-reduce" if world > 1 else ""),
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}" + ("+syncbn" if a.sync_bn and world > 1 else ""),
                        "gemm_arith": {

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PL_VERSION 104 /* 0.1.4: + pl_planes_split_strided; 0.1.3: + pl_bn_join_bwd (0.1.2: operand-plane outputs of the BatchNorm / join kernels, pl_gemm_planes_raw) */
+#define PL_VERSION 105 /* 0.1.5: + pl_flip_pose_ex, pl_flip_w_nhwc (phase5 Flip branch); 0.1.4: + pl_planes_split_strided; 0.1.3: + pl_bn_join_bwd (0.1.2: operand-plane outputs of the BatchNorm / join kernels, pl_gemm_planes_raw) */
 
 typedef enum PLStatus {
   PL_OK = 0,
@@ -371,6 +371,17 @@ int pl_mpjpe_accum(const float* pred, const float* tgt, int64_t B, int64_t joint
  * out = horizontal flip of in, both [B][17][D], D = 2 (x -> 1-x) or 3 (x -> -x), left/right joints
  * [4,5,6,11,12,13] <-> [1,2,3,14,15,16] swapped.  Out of place. */
 int pl_flip_pose(const float* in, float* out, int64_t B, int64_t joints, int64_t D, void* stream);
+
+/* The training-mode Flip branch of the phase5 cycle step, phase5_loop/train_5 copy.py:174-199:
+ *   y = (flip_pose(a) + b) / 2      -> pl_flip_pose_ex(a, b, y, ..., x_offset = (D == 2 ? 1 : 0), scale = 0.5)
+ *   its backward da = flip'(g) / 2  -> pl_flip_pose_ex(g, NULL, da, ..., x_offset = 0, scale = 0.5)
+ * out[b][j][d] = ((d == 0 ? x_offset - in[b][src(j)][0] : in[b][src(j)][d]) + (addend ? addend[b][j][d] : 0)) * scale,
+ * src = the left/right joint swap of pl_flip_pose.  addend may be NULL.  Out of place. */
+int pl_flip_pose_ex(const float* in, const float* addend, float* out, int64_t B, int64_t joints, int64_t D,
+                    float x_offset, float scale, void* stream);
+
+/* torch.flip(frame, (3,)) of train_5 copy.py:176 (NCHW dim 3 = width) on NHWC frames: out[b][h][w][c] = in[b][h][W-1-w][c]. */
+int pl_flip_w_nhwc(const float* in, float* out, int64_t B, int64_t H, int64_t W, int64_t C, void* stream);
 
 /* Flip test-time augmentation, (flip_pose(model(flip_pose(x))) + model(x)) / 2 -- the intent of
  * train_1.py:128-134 and phase5_loop/train_5 copy.py:160-171 -- around ONE eval forward of 2B rows:

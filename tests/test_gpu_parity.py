@@ -385,8 +385,15 @@ def full(pkg):
     return m, x, y
 
 
-def test_full_size_train_then_eval_vs_oracle(pkg, full):
+@pytest.mark.parametrize("compute_dtype", ["fp32", "f16x3"])
+def test_full_size_train_then_eval_vs_oracle(pkg, full, compute_dtype):
+    """B = 4096, H = 1024 (BASELINE configs[1]) against the oracle, in the exact-fp32 arithmetic and in the arithmetic
+    bench.py's headline runs (f16x3: fp16 operand planes, three MFMAs per product)."""
     m, x, y = full
+    if compute_dtype != "fp32":
+        torch.manual_seed(0)
+        m = pkg.LinearModel(34, 51, linear_size=1024, num_stage=2, p_dropout=0.5, BN=True,
+                            compute_dtype=compute_dtype).to(DEV)
     st = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
     m.train().manual_seed(7, step=0)
     pred = m(x).reshape(-1, 17, 3)

@@ -1,8 +1,11 @@
 """GPU tests of the operand-planes GEMM path (csrc/gemm_planes.h, gemm_planes.hip): PL_F16X3 -- fp32-grade products
 from two fp16 planes per operand written by the producing kernels, three MFMAs per product term -- and the planes
-GEMM itself in all three layouts.  The golden-vector / oracle gates of this mode (g1 eval forward, g2 'full' train
-step, the 1024 x 1024 train step against the oracle) are parametrisations of the tests in test_gpu_parity.py; here:
-the GEMM against fp64, tensor scales, bitwise properties at BASELINE.json's full size, the fallbacks."""
+GEMM itself in all three layouts.  The golden-vector / oracle gates of this mode are parametrisations of the tests in
+test_gpu_parity.py: g1 eval forward, g2 'full' train step, the B = 1024 train step against the oracle, and (round 3)
+test_full_size_train_then_eval_vs_oracle[f16x3] -- B = 4096, H = 1024, the bench's shape and arithmetic.  Here: the GEMM
+against fp64, tensor scales, properties at BASELINE.json's full size (bitwise repeatability and a comparison with this
+library's own fp32 path -- a self-comparison, not an oracle gate), the fallbacks, and the freshness of the persistent
+weight planes."""
 import numpy as np
 import pytest
 import torch
@@ -267,3 +270,125 @@ def test_eval_mode_backward_vs_torch_twin(pkg, dtype, B, H):
         if "running" in k or "num_batches" in k:
             assert torch.equal(after[k].cpu(), v), k
     assert m._live_graphs == 0
+
+
+# ---------------------------------------------------------------------------- freshness of the persistent weight planes
+@pytest.mark.parametrize("dtype", ["f16x3", "bf16"])
+def test_weight_planes_follow_load_state_dict_and_torch_optimizers(pkg, dtype):
+    """The 1024-wide weights' operand planes persist across calls.  Parameters are attached to the arena with
+    `p.data = view`, so an in-place torch op (load_state_dict, nn.init, torch.optim.*.step) bumps only that Parameter's
+    version counter: the planes must be re-derived all the same (they were not)."""
+    H, B = 256, 256
+    tol = 1e-3 if dtype == "f16x3" else 30.0                  # bf16 storage: ~1 mm-class, only staleness matters
+    torch.manual_seed(1)
+    a = pkg.LinearModel(34, 51, linear_size=H, p_dropout=0.0, compute_dtype=dtype).to(DEV).eval()
+    torch.manual_seed(2)
+    b = pkg.LinearModel(34, 51, linear_size=H, p_dropout=0.0, compute_dtype=dtype).to(DEV).eval()
+    ref = pkg.LinearModel(34, 51, linear_size=H, p_dropout=0.0, compute_dtype="fp32").to(DEV).eval()
+    x, y = pkg.synth.synthetic_batch(B, 9, DEV)
+    with torch.no_grad():
+        ya = a(x)                                             # planes of a's weights are now valid
+        a.load_state_dict(b.state_dict())                     # ... and now stale
+        ref.load_state_dict(b.state_dict())
+        got, want, fresh = a(x), ref(x), b(x)
+    assert not torch.equal(ya, got)
+    assert torch.equal(got, fresh)                            # same weights, same kernels: bit-identical
+    assert orc.mpjpe_mm(got.cpu().numpy(), want.cpu().numpy()) < tol
+    # weight_init (nn.init on the Linear weights) after a forward
+    torch.manual_seed(3)
+    a.apply(pkg.weight_init)
+    ref.load_state_dict(a.state_dict())
+    with torch.no_grad():
+        assert orc.mpjpe_mm(a(x).cpu().numpy(), ref(x).cpu().numpy()) < tol
+    # a stock torch optimizer stepping the parameters (what cycle_step's Adam does, train_5 copy.py:105-109): after every
+    # step the model must compute with the NEW weights -- bit for bit what a fresh model loaded with them computes
+    # (two arithmetics' Adam trajectories diverge on their own: a same-arithmetic twin is the staleness check)
+    a.train()
+    oa = torch.optim.Adam(a.parameters(), lr=1e-2)
+    for _ in range(3):
+        oa.zero_grad()
+        pkg.mse_loss(a(x).reshape(B, 17, 3), y).backward()
+        oa.step()
+        fresh = pkg.LinearModel(34, 51, linear_size=H, p_dropout=0.0, compute_dtype=dtype).to(DEV).train()
+        fresh.load_state_dict(a.state_dict())
+        sd = {k: v.clone() for k, v in a.state_dict().items()}
+        assert torch.equal(a(x), fresh(x))                    # (training-mode forward: moves the running statistics)
+        a.load_state_dict(sd)
+    a.eval(); fresh.eval()
+    fresh.load_state_dict(a.state_dict())
+    with torch.no_grad():
+        assert torch.equal(a(x), fresh(x))
+
+
+def test_weight_planes_are_written_before_the_first_planes_call_whatever_came_first(pkg):
+    """A call off the planes path (ragged batch) leaves the planes untouched: the next whole-tile call must not find
+    them marked valid (fresh model: the buffer is uninitialised memory).  ADVICE r02."""
+    H = 256
+    torch.manual_seed(4)
+    m = pkg.LinearModel(34, 51, linear_size=H, p_dropout=0.0, compute_dtype="f16x3").to(DEV).eval()
+    m._wplanes.fill_(0xFF)                                    # poison: NaN planes if they were ever read as they are
+    ref = pkg.LinearModel(34, 51, linear_size=H, p_dropout=0.0, compute_dtype="bf16x6").to(DEV).eval()
+    ref.load_state_dict(m.state_dict())
+    x, _ = pkg.synth.synthetic_batch(128, 5, DEV)
+    with torch.no_grad():
+        y100 = m(x[:100])                                     # round-1 kernels
+        y128 = m(x)                                           # planes path
+        r100, r128 = ref(x[:100]), ref(x)
+    assert torch.isfinite(y128).all()
+    assert orc.mpjpe_mm(y100.cpu().numpy(), r100.cpu().numpy()) < 1e-3
+    assert orc.mpjpe_mm(y128.cpu().numpy(), r128.cpu().numpy()) < 1e-3
+    # flip TTA at B = 64 runs 2B = 128 rows (the ADVICE example)
+    m2 = pkg.LinearModel(34, 51, linear_size=H, p_dropout=0.0, compute_dtype="f16x3").to(DEV).eval()
+    m2._wplanes.fill_(0xFF)
+    m2.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        m2(x[:64])
+        t = pkg.train.predict_flip_tta(m2, x[:64])
+        tr = pkg.train.predict_flip_tta(ref, x[:64])
+    assert orc.mpjpe_mm(t.cpu().numpy().reshape(64, -1), tr.cpu().numpy().reshape(64, -1)) < 1e-3
+
+
+@pytest.mark.parametrize("H,B", [(512, 128 * 17), (256, 128 * 5)])
+def test_f16x3_shapes_whose_batch_does_not_split_into_whole_k_tiles_fall_back(pkg, H, B):
+    """H = 512 with B = 128 * 17: the weight-gradient GEMM would split K = B sixteen ways, not whole 32-k tiles -- such
+    a batch must run on the round-1 kernels (as fp32 / bf16x6 do), not fail with PL_ESHAPE.  ADVICE r02."""
+    torch.manual_seed(6)
+    m = pkg.LinearModel(34, 51, linear_size=H, p_dropout=0.0, compute_dtype="f16x3").to(DEV).train()
+    r = pkg.LinearModel(34, 51, linear_size=H, p_dropout=0.0, compute_dtype="bf16x6").to(DEV).train()
+    r.load_state_dict(m.state_dict())
+    x, y = pkg.synth.synthetic_batch(B, 8, DEV)
+    for mm in (m, r):
+        pkg.mse_loss(mm(x).reshape(B, 17, 3), y).backward()
+    assert torch.isfinite(m.flat_grads).all()
+    rel = float((m.flat_grads.double() - r.flat_grads.double()).norm() / r.flat_grads.double().norm())
+    assert rel < 2e-4, rel
+
+
+def test_graphed_train_step_follows_or_refuses_host_side_counter_changes(pkg):
+    """The graph owns the dropout-stream step and AdamW's t (capture-time base + a device counter).  An eager
+    train_step between replays moves the host counters: the next replay re-seeds the device counter and stays bitwise
+    the eager sequence; counters that drift apart, a new dropout seed or re-bound optimizer arenas are refused."""
+    def make():
+        torch.manual_seed(3)
+        m = pkg.LinearModel(34, 51, linear_size=256, p_dropout=0.5, compute_dtype="f16x3").to(DEV).train()
+        m.manual_seed(99, step=0)
+        return m, pkg.FlatAdamW(m, lr=1e-3)
+    batches = [pkg.synth.synthetic_batch(256, 60 + i, DEV) for i in range(4)]
+    me, oe = make()
+    eager = [pkg.train_step(me, oe, x, y)[0].clone() for x, y in batches]
+    mg, og = make()
+    step = pkg.GraphedTrainStep(mg, og, *batches[0])
+    l0 = step(*batches[0])[0].clone()
+    l1 = pkg.train_step(mg, og, *batches[1])[0].clone()       # an eager step in between
+    l2 = step(*batches[2])[0].clone()
+    l3 = step(*batches[3])[0].clone()
+    for got, want in zip((l0, l1, l2, l3), eager):
+        assert torch.equal(got, want)
+    assert torch.equal(mg.flat_params, me.flat_params)
+    og._advance_host(1)                                       # optimizer ahead of the model
+    with pytest.raises(pkg.PoseliftError, match="capture a new"):
+        step(*batches[0])
+    og._advance_host(-1)
+    mg.manual_seed(5, step=mg._step)
+    with pytest.raises(pkg.PoseliftError, match="capture a new"):
+        step(*batches[0])

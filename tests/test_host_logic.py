@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(pkg):
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in include/poselift.h but not exported"
     assert declared == set(pkg._lib.SIGNATURES), "ctypes signature table out of sync with the header"
-    assert pkg.lib().pl_version() == 104
+    assert pkg.lib().pl_version() == int(re.search(r"#define PL_VERSION (\d+)", header).group(1)) >= 105
     conv = importlib.import_module("3d_poseestimation_amd.conv")
     assert pkg.lib().pl_conv_act_plane_scale() == conv.ACT_PLANE_SCALE      # one constant on both sides of the C ABI
 
