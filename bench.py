@@ -129,7 +129,8 @@ def self_launch(a):
         line = out0.read()
     if failed or any(rcs):
         raise SystemExit(f"bench.py --gpus {a.gpus}: a rank failed (exit codes {rcs}); no result line")
-    sys.stdout.write(line)
+    # exactly the result line (the gloo rehearsal backend prints a connection banner on stdout)
+    sys.stdout.write("".join(ln + "\n" for ln in line.splitlines() if ln.startswith("{")))
     sys.stdout.flush()
 
 
