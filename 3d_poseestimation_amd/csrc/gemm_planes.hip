@@ -28,7 +28,7 @@ struct PlanesKern {
 // col0 .. col0+3 of rows lr, lr+4, ..., lr+60.  Same operation order per element as gemm_epilogue (bias, skip-gradient
 // addend, eval-BN fold, ReLU, residual, ReLU); statistics and the BatchNorm-backward sums per 64-row block in a fixed order.
 template <bool EDGE>
-__device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __restrict__ C, const float* __restrict__ ldsw,
+__device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __restrict__ C, float4 (&v)[16],
                                                 const int m0, const int n0, const int wm, const int wn, const int lane) {
   const GemmArgs& e = k.e;
   const int lr = lane >> 4, lc = (lane & 15) * 4;
@@ -43,9 +43,6 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
   // (Tried: requesting bnr_z's sixteen float4 here, ahead of the addend, so that both arrive in one round trip instead of two in
   //  a row.  Same-box A/B over five interleaved runs: dual launch 63.1 us against 62.4 us as it is -- the epilogue's burst is
   //  bandwidth, not latency; more of it in flight at once only lengthens the queue.  Not kept.)
-  float4 v[16];
-#pragma unroll
-  for (int it = 0; it < 16; ++it) v[it] = *reinterpret_cast<const float4*>(ldsw + (it * 4 + lr) * 68 + lc);
   if (!plain) {
     if (e.bias) {
       const float4 b = cok ? *reinterpret_cast<const float4*>(e.bias + col0) : zero4;
@@ -199,32 +196,54 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
 // 32x32x16 loop; its accumulator layout is gemm_epilogue's, so only the addend / BatchNorm-backward cases are staged.
 // EDGE (16x16x32 loop only): M / N need not be multiples of 128 -- the conv path's 64-wide layers and ragged pixel counts
 // CONV (16x16x32 loop only): 1 = A gathered as a convolution input (NT), 2 = B gathered for the weight gradient (TN)
-template <bool A_KS, bool B_KS, int MODE, bool S16, bool EDGE = false, int CONV = 0>
-__device__ __forceinline__ void planes_body(const PlanesKern& k, const int block_id, const int nwork, char* lds) {
+// PERSIST (16x16x32 loop only): the workgroup walks a run of work items, operands streaming across the item boundaries
+// (gemm_planes16.h); the epilogue then stages through LDS of its own behind the three-stage ring.
+template <int MODE> constexpr int ring_bytes() { return plp::PlanesCfg<32, plp::ModeCfg<MODE>::NPL, 3>::LDS; }
+constexpr int kHalfStage = 4 * 32 * 68 * 4;      // four waves x 32 rows x 68 floats: the staged epilogue works in two halves
+// LDS: three operand stages, and never less than the 4 x 17 KB the 32x32x16 loop's epilogue stages a whole block in
+template <int MODE, bool PERSIST = false>
+constexpr int lds_bytes() {
+  if (PERSIST) return ring_bytes<MODE>() + kHalfStage;
+  return ring_bytes<MODE>() > 4 * 64 * 68 * 4 ? ring_bytes<MODE>() : 4 * 64 * 68 * 4;
+}
+
+template <bool A_KS, bool B_KS, int MODE, bool S16, bool EDGE = false, int CONV = 0, bool PERSIST = false>
+__device__ __forceinline__ void planes_body(const PlanesKern& k, const int block_id, const int nblocks, const int nwork, char* lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave & 3) >> 1, wn = wave & 1;
   // main + low / 2048, then back from the operands' power-of-two scales (exact unless the result under/overflows)
   const float os = MODE == plp::kF16x3 ? (k.dyn_inv ? k.out_scale * k.dyn_inv[0] : k.out_scale) : 1.f;
-  float* ldsw = reinterpret_cast<float*>(lds) + (wave & 3) * 64 * 68;
-  int m0, n0, slice;
   if constexpr (S16) {
-    plp::f32x4v acc[plp::ModeCfg<MODE>::NACC][4][4];
-    if (!plp::planes_mainloop16<A_KS, B_KS, MODE, EDGE, CONV>(k.p, block_id, nwork, lds, acc, m0, n0, slice)) return;
-    __syncthreads();                                   // every computing wave is done reading operand tiles
-    const int q = lane >> 4, c = lane & 15;
+    // the wave's 64x64 block goes through 32 rows x 68 floats of LDS twice (rows 0-31, then 32-63): the lane that owned
+    // accumulator elements leaves with float4 rows (v[it] = row 4 it + (lane >> 4), columns 4 (lane & 15) ..)
+    float* ldsw = reinterpret_cast<float*>(lds + (PERSIST ? ring_bytes<MODE>() : 0)) + (wave & 3) * 32 * 68;
+    const int q = lane >> 4, c = lane & 15, lc = c * 4;
+    auto epi = [&](plp::f32x4v (&acc)[plp::ModeCfg<MODE>::NACC][4][4], const int m0, const int n0, const int slice) {
+      if (!PERSIST) __syncthreads();                     // every computing wave is done reading operand tiles (the staging
+                                                         // rows alias the ring); PERSIST: a region of its own, wave-private
+      float4 v[16];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+      for (int half = 0; half < 2; ++half) {
 #pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
+        for (int r2 = 0; r2 < 2; ++r2)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = acc[0][rt][ct][r];
-          if constexpr (MODE == plp::kF16x3) v = fmaf(acc[1][rt][ct][r], 1.0f / plp::kF16LoScale, v) * os;
-          ldsw[(rt * 16 + 4 * q + r) * 68 + ct * 16 + c] = v;
-        }
-    float* C = k.e.C ? k.e.C + (k.e.split_k > 1 ? (size_t)slice * k.e.M * k.e.ldc : 0) : nullptr;
-    staged_epilogue<EDGE>(k, C, ldsw, m0, n0, wm, wn, lane);
+          for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x = acc[0][2 * half + r2][ct][r];
+              if constexpr (MODE == plp::kF16x3) x = fmaf(acc[1][2 * half + r2][ct][r], 1.0f / plp::kF16LoScale, x) * os;
+              ldsw[(r2 * 16 + 4 * q + r) * 68 + ct * 16 + c] = x;
+            }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) v[8 * half + it] = *reinterpret_cast<const float4*>(ldsw + (it * 4 + q) * 68 + lc);
+      }
+      float* C = k.e.C ? k.e.C + (k.e.split_k > 1 ? (size_t)slice * k.e.M * k.e.ldc : 0) : nullptr;
+      staged_epilogue<EDGE>(k, C, v, m0, n0, wm, wn, lane);
+    };
+    plp::planes_run16<A_KS, B_KS, MODE, EDGE, CONV, PERSIST>(k.p, block_id, nblocks, nwork, lds, epi);
   } else {
+    float* ldsw = reinterpret_cast<float*>(lds) + (wave & 3) * 64 * 68;
+    int m0, n0, slice;
     f32x16 acc[plp::ModeCfg<MODE>::NACC][2][2];
     if (!plp::planes_mainloop<A_KS, B_KS, 32, MODE, 4, 0, 3>(k.p, block_id, nwork, lds, acc, m0, n0, slice)) return;
     const int i = lane & 31, h = lane >> 5;
@@ -251,24 +270,28 @@ __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             ldsw[(a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 68 + b * 32 + i] = acc[0][a][b][r];
-      staged_epilogue<false>(k, C, ldsw, m0, n0, wm, wn, lane);
+      float4 v[16];
+      const int lr = lane >> 4, lc = (lane & 15) * 4;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) v[it] = *reinterpret_cast<const float4*>(ldsw + (it * 4 + lr) * 68 + lc);
+      staged_epilogue<false>(k, C, v, m0, n0, wm, wn, lane);
       return;
     }
     gemm_epilogue<false, 2>(k.e, C, acc[0], m0, n0, wm, wn, i, h);
   }
 }
 
-// LDS: three operand stages, and never less than the 4 x 17 KB the addend epilogue stages the output block in
-template <int MODE>
-constexpr int lds_bytes() {
-  constexpr int stages = plp::PlanesCfg<32, plp::ModeCfg<MODE>::NPL, 3>::LDS;
-  return stages > 4 * 64 * 68 * 4 ? stages : 4 * 64 * 68 * 4;
-}
-
 template <bool A_KS, bool B_KS, int MODE, bool S16, bool EDGE = false, int CONV = 0>
 __global__ __launch_bounds__(512) void planes_gemm_kernel(PlanesKern k) {
   __shared__ __attribute__((aligned(16))) char lds[lds_bytes<MODE>()];
-  planes_body<A_KS, B_KS, MODE, S16, EDGE, CONV>(k, blockIdx.x, gridDim.x, lds);
+  planes_body<A_KS, B_KS, MODE, S16, EDGE, CONV>(k, blockIdx.x, gridDim.x, gridDim.x, lds);
+}
+
+// one workgroup per CU, each walking nwork / gridDim.x consecutive work items (NT, 16x16x32 loop)
+template <int MODE, bool EDGE, int CONV>
+__global__ __launch_bounds__(512) void planes_gemm_persistent_kernel(PlanesKern k, int nwork) {
+  __shared__ __attribute__((aligned(16))) char lds[lds_bytes<MODE, true>()];
+  planes_body<false, false, MODE, true, EDGE, CONV, true>(k, blockIdx.x, gridDim.x, nwork, lds);
 }
 
 // backward pair of one layer in one launch: workgroups [0, n0) run dX = dz W (NN), the rest dW = dz^T a (TN, split-K
@@ -276,13 +299,28 @@ __global__ __launch_bounds__(512) void planes_gemm_kernel(PlanesKern k) {
 // and the tail of the first problem, which the second one's workgroups fill.
 // (Tried: alternating the two problems in groups of 8 workgroups, so that half the CUs run dX's heavy epilogues beside the
 //  other half's main loops -- same-box A/B 0.688 vs 0.629 ms per step: two working sets per XCD L2 cost far more.)
+// (Tried in round 3, xsplit = 1 / POSELIFT_DUAL_XSPLIT=1: the two problems taking turns PER XCD -- XCDs 0-3 run their share
+//  of dX first and of dW second, XCDs 4-7 the other way round (blocks b and b + 8 share an XCD and are dispatched in order), so
+//  that each L2 still holds ONE problem's working set at a time while dX's 50 MB epilogue burst comes in two halves, each
+//  beside the other half's main loops.  Same-box A/B over three interleaved runs: 68.5 us per dual launch against 65.1 us,
+//  0.650 against 0.638 ms per step.  Not kept -- the burst is not what a half-chip of main loops can hide.)
 template <int MODE, bool S16>
-__global__ __launch_bounds__(512) void planes_gemm_dual_kernel(PlanesKern k0, PlanesKern k1, int n0) {
+__global__ __launch_bounds__(512) void planes_gemm_dual_kernel(PlanesKern k0, PlanesKern k1, int n0, int xsplit) {
   __shared__ __attribute__((aligned(16))) char lds[lds_bytes<MODE>()];
-  if ((int)blockIdx.x < n0)
-    planes_body<false, true, MODE, S16>(k0, blockIdx.x, n0, lds);
+  const int b = blockIdx.x;
+  if (xsplit) {                                   // (host: n0 == gridDim.x - n0, n0 % 8 == 0)
+    const bool second = b >= n0;
+    const int bb = second ? b - n0 : b;
+    if (((b & 7) < 4) != second)
+      planes_body<false, true, MODE, S16>(k0, bb, n0, n0, lds);
+    else
+      planes_body<true, true, MODE, S16>(k1, bb, n0, n0, lds);
+    return;
+  }
+  if (b < n0)
+    planes_body<false, true, MODE, S16>(k0, b, n0, n0, lds);
   else
-    planes_body<true, true, MODE, S16>(k1, blockIdx.x - n0, gridDim.x - n0, lds);
+    planes_body<true, true, MODE, S16>(k1, b - n0, gridDim.x - n0, gridDim.x - n0, lds);
 }
 
 bool mfma16_shape() {
@@ -310,6 +348,19 @@ PlanesKern kern_of(GemmLayout layout, const PlanesGemmArgs& a) {
   k.vec_addend = vec;
   (void)layout;
   return k;
+}
+
+// CUs of the current device (the persistent form launches one workgroup per CU)
+int cu_count() {
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  if (!cached[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev] = n;
+  }
+  return cached[dev];
 }
 
 int grid_of(const PlanesGemmArgs& a) {
@@ -389,7 +440,21 @@ int launch_gemm_planes(GemmLayout layout, const PlanesGemmArgs& a, hipStream_t s
     case kTN: hipLaunchKernelGGL((planes_gemm_kernel<true, true, MODE, S16>), grid, block, 0, s, k); break;      \
     default: PL_FAIL(PL_EINVAL, "gemm_planes: bad layout %d", (int)layout);                                     \
   }
-  if (a.e.conv_cin) {
+  // persistent form (round 3): NT problems with at least two work items per CU -- the conv path's 1x1 / 3x3 / transposed
+  // convolutions over 16K .. 1M pixels.  POSELIFT_PERSIST=0: one workgroup per item, as round 2 (same-box A/B).
+  static const int persist_env = [] { const char* e = getenv("POSELIFT_PERSIST"); return e ? atoi(e) : 1; }();
+  const int ncu = cu_count();
+  if (persist_env && mfma16_shape() && layout == kNT && (int)grid.x >= 2 * ncu && (a.e.conv_cin == 0 || layout == kNT)) {
+    const dim3 pg(ncu);
+    const int nwork = (int)grid.x;
+    const bool edge = is_edge(a) || a.e.conv_cin;
+#define PL_PERSIST(MODE)                                                                                               \
+    if (a.e.conv_cin) hipLaunchKernelGGL((planes_gemm_persistent_kernel<MODE, true, 1>), pg, block, 0, s, k, nwork);   \
+    else if (edge) hipLaunchKernelGGL((planes_gemm_persistent_kernel<MODE, true, 0>), pg, block, 0, s, k, nwork);      \
+    else hipLaunchKernelGGL((planes_gemm_persistent_kernel<MODE, false, 0>), pg, block, 0, s, k, nwork);
+    if (a.mode == plp::kF16x3) { PL_PERSIST(plp::kF16x3) } else { PL_PERSIST(plp::kBf16) }
+#undef PL_PERSIST
+  } else if (a.e.conv_cin) {
     if (layout == kNT) {
       if (a.mode == plp::kF16x3) hipLaunchKernelGGL((planes_gemm_kernel<false, false, plp::kF16x3, true, true, 1>), grid, block, 0, s, k);
       else hipLaunchKernelGGL((planes_gemm_kernel<false, false, plp::kBf16, true, true, 1>), grid, block, 0, s, k);
@@ -425,12 +490,14 @@ int launch_gemm_planes_pair(const PlanesGemmArgs& nn, const PlanesGemmArgs& tn, 
   const int g0 = grid_of(nn), g1 = grid_of(tn);
   void* prof = prof_begin_flops(2.0 * nn.e.M * nn.e.N * nn.e.K + 2.0 * tn.e.M * tn.e.N * tn.e.K, s);
   const dim3 grid(g0 + g1), block(512);
+  static const int xs_env = [] { const char* e = getenv("POSELIFT_DUAL_XSPLIT"); return e ? atoi(e) : 0; }();   // =1: same-box A/B (not kept)
+  const int xs = (xs_env && g0 == g1 && (g0 & 7) == 0) ? 1 : 0;
   if (mfma16_shape()) {
-    if (nn.mode == plp::kF16x3) hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kF16x3, true>), grid, block, 0, s, k0, k1, g0);
-    else hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kBf16, true>), grid, block, 0, s, k0, k1, g0);
+    if (nn.mode == plp::kF16x3) hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kF16x3, true>), grid, block, 0, s, k0, k1, g0, xs);
+    else hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kBf16, true>), grid, block, 0, s, k0, k1, g0, xs);
   } else {
-    if (nn.mode == plp::kF16x3) hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kF16x3, false>), grid, block, 0, s, k0, k1, g0);
-    else hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kBf16, false>), grid, block, 0, s, k0, k1, g0);
+    if (nn.mode == plp::kF16x3) hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kF16x3, false>), grid, block, 0, s, k0, k1, g0, xs);
+    else hipLaunchKernelGGL((planes_gemm_dual_kernel<plp::kBf16, false>), grid, block, 0, s, k0, k1, g0, xs);
   }
   prof_end(prof, s);
   PL_CHECK_LAUNCH("gemm_planes_dual");

@@ -90,17 +90,24 @@ __device__ __forceinline__ f32x4v mfma16x16(const s16x8 a, const s16x8 b, const 
 }
 
 // acc[c][rt][ct][reg]: row = m0 + wm*64 + rt*16 + 4*(lane>>4) + reg, col = n0 + wn*64 + ct*16 + (lane&15)
-// Whole tiles only (as planes_mainloop); 512 threads; returns false in the loader waves.
+// Whole tiles only (as planes_mainloop); 512 threads; the loader waves never call `epi`.
 // EDGE: M and N need not be multiples of 128 (M: any for a k-contiguous A, % 8 for a k-strided one; N % 8): see
 // glds_lane_off16.  K stays a whole number of 32-k tiles per slice.
 // CONV = 1 (with !A_KS, !B_KS): A gathered as an implicit-GEMM convolution input; CONV = 2 (A_KS, B_KS): B gathered as the
 // weight gradient's input (PlanesArgs::cv_*).  Only the loader waves change: per-lane source offsets from the pixel
 // decomposition, the tap's validity per lane, out-of-range (zero-filling) offsets for padding pixels.
+//
+// PERSIST (round 3): the workgroup walks a contiguous run of work items (output tile x K slice) instead of one, and the
+// operand stream does not stop at an item boundary: the loader waves issue the k-tiles of item i+1 into the three-stage
+// ring while the computing waves are still in item i's last steps and in its epilogue (which stages through LDS of its own,
+// outside the ring).  What a one-item workgroup pays in series -- first-tile latency from HBM, the MFMAs, the 64 KB store --
+// overlaps here; the short-K convolution layers (K = 64 .. 256 at 1M pixels: two to eight k-tiles per item) are the ones
+// that were spending most of their time in exactly those two ends.  One barrier per k-tile for every wave, as before;
+// `epi(acc, m0, n0, slice)` is called by the computing waves once per item.
 constexpr int kDmaOutOfRange = 0x7ffffff0;     // >= num_records of the gathered operand's descriptor
-template <bool A_KS, bool B_KS, int MODE, bool EDGE = false, int CONV = 0>
-__device__ __forceinline__ bool planes_mainloop16(const PlanesArgs& p, const int block_id, const int nwork,
-                                                  char* __restrict__ lds, f32x4v (&acc)[ModeCfg<MODE>::NACC][4][4],
-                                                  int& m0, int& n0, int& slice) {
+template <bool A_KS, bool B_KS, int MODE, bool EDGE, int CONV, bool PERSIST, class Epi>
+__device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int block_id, const int nblocks, const int nwork,
+                                             char* __restrict__ lds, Epi&& epi) {
   static_assert(MODE == kF16x3 || MODE == kBf16, "two fp16 planes or one bf16 plane");
   constexpr int NPL = ModeCfg<MODE>::NPL, NACC = ModeCfg<MODE>::NACC;
   using Cf = PlanesCfg<32, NPL, 3>;
@@ -114,39 +121,35 @@ __device__ __forceinline__ bool planes_mainloop16(const PlanesArgs& p, const int
   const int tiles_n = EDGE ? (p.N + 127) / 128 : p.N / 128;
   const int splits = p.split_k > 1 ? p.split_k : 1;
   const int ntiles = nwork / splits;
-  int w = block_id;
-  if ((nwork & 7) == 0) w = (w & 7) * (nwork >> 3) + (w >> 3);   // XCD-aware: blocks b and b+8 share an L2
-  slice = w / ntiles;
-  const int t = w - slice * ntiles;
-  m0 = (t / tiles_n) * 128;
-  n0 = (t % tiles_n) * 128;
-  int kbeg = 0, kend = p.K;
-  if (splits > 1) {
-    const int per = ((p.K / 32 + splits - 1) / splits) * 32;
-    kbeg = min(slice * per, p.K);
-    kend = min(kbeg + per, p.K);
+  // this workgroup's items: one (the block id, XCD-aware: blocks b and b+8 share an L2), or a contiguous run of them
+  // (consecutive items are the column tiles of one row block: its A rows are re-read from L2, not from HBM)
+  int item_lo, item_hi;
+  if (PERSIST) {
+    const int per = (nwork + nblocks - 1) / nblocks;
+    item_lo = min(block_id * per, nwork);
+    item_hi = min(item_lo + per, nwork);
+  } else {
+    item_lo = block_id;
+    if ((nwork & 7) == 0) item_lo = (block_id & 7) * (nwork >> 3) + (block_id >> 3);
+    item_hi = item_lo + 1;
   }
-  const int nk = (kend - kbeg) / 32;
+  if (item_lo >= item_hi) return;
+  const int per_slice = ((p.K / 32 + splits - 1) / splits) * 32;
+  // item -> (m0, n0, slice, first k, k-tiles)
+  auto decode = [&](const int w, int& m0, int& n0, int& slice, int& kbeg) {
+    slice = w / ntiles;
+    const int t = w - slice * ntiles;
+    m0 = (t / tiles_n) * 128;
+    n0 = (t % tiles_n) * 128;
+    kbeg = 0;
+    int kend = p.K;
+    if (splits > 1) {
+      kbeg = min(slice * per_slice, p.K);
+      kend = min(kbeg + per_slice, p.K);
+    }
+    return (kend - kbeg) / 32;
+  };
 
-#pragma unroll
-  for (int c = 0; c < NACC; ++c)
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[c][a][b][r] = 0.f;
-  if (nk <= 0) return !loader;
-
-  const __bf16* ta = A_KS ? p.A + (size_t)kbeg * p.lda + m0 : p.A + (size_t)m0 * p.lda + kbeg;
-  const __bf16* tb = B_KS ? p.B + (size_t)kbeg * p.ldb + n0 : p.B + (size_t)n0 * p.ldb + kbeg;
-  // one descriptor per plane (64-bit plane stride in the base: a plane of the conv head's 4.5 GB gradient is 2.3 GB away)
-  __amdgpu_buffer_rsrc_t ra[NPL], rb[NPL];
-#pragma unroll
-  for (int pl = 0; pl < NPL; ++pl) {
-    ra[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(ta + (size_t)pl * p.a_plane), 0, 0x7fffffff, 0x00020000);
-    rb[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(tb + (size_t)pl * p.b_plane), 0, 0x7fffffff, 0x00020000);
-  }
   const int ga_step = A_KS ? 32 * p.lda * 2 : 64;
   const int gb_step = B_KS ? 32 * p.ldb * 2 : 64;
   auto barrier = [&]() {
@@ -154,17 +157,20 @@ __device__ __forceinline__ bool planes_mainloop16(const PlanesArgs& p, const int
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  int st[3] = {0, Cf::STAGE, 2 * Cf::STAGE};      // st[q] = stage of tile kt + q
+  int st[3] = {0, Cf::STAGE, 2 * Cf::STAGE};      // st[q] = stage of k-tile g + q of the stream
   auto rotate = [&]() { const int o = st[0]; st[0] = st[1]; st[1] = st[2]; st[2] = o; };
 
   if (loader) {
     static_assert(CONV == 0 || (CONV == 1 && !A_KS && !B_KS) || (CONV == 2 && A_KS && B_KS), "conv gathers: NT forward, TN wgrad");
+    // total k-tiles of the stream (the computing waves run one barrier per k-tile of the same items)
+    int total = 0;
+    if (splits == 1) total = (item_hi - item_lo) * (p.K / 32);
+    else for (int w = item_lo; w < item_hi; ++w) { int a_, b_, c_, d_; total += max(decode(w, a_, b_, c_, d_), 0); }
+    // ---- state of the item whose k-tiles are being issued
+    int it = item_lo, kt = 0, nk = 0, m0 = 0, n0 = 0, slice = 0, kbeg = 0;
+    // one descriptor per plane (64-bit plane stride in the base: a plane of the conv head's 4.5 GB gradient is 2.3 GB away)
+    __amdgpu_buffer_rsrc_t ra[NPL], rb[NPL];
     int oa[2], ob[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      oa[j] = (int)glds_lane_off16<A_KS>(lw + 4 * j, lane, p.lda, EDGE ? p.M - m0 : 0x7fffffff);
-      ob[j] = (int)glds_lane_off16<B_KS>(lw + 4 * j, lane, p.ldb, EDGE ? p.N - n0 : 0x7fffffff);
-    }
     // ---- convolution gathers: descriptors on the whole tensor, offsets rebuilt per K tile by the (otherwise idle) loader VALU
     __amdgpu_buffer_rsrc_t rx[NPL];
 #pragma unroll
@@ -174,29 +180,44 @@ __device__ __forceinline__ bool planes_mainloop16(const PlanesArgs& p, const int
     int cih0[2] = {0, 0}, ciw0[2] = {0, 0}, cbase[2] = {0, 0};      // CONV 1: per DMA row of this lane
     int ctap = 0, cc0 = 0, ckh = 0, ckw = 0;                        // CONV 1: filter tap / channel offset of the next tile issued
     int wkh = 0, wkw = 0, wcol = 0;                                 // CONV 2: this lane's column chunk: tap and channel (fixed)
-    if (CONV == 1) {
+    auto setup = [&]() {
+      nk = decode(it, m0, n0, slice, kbeg);
+      const __bf16* ta = A_KS ? p.A + (size_t)kbeg * p.lda + m0 : p.A + (size_t)m0 * p.lda + kbeg;
+      const __bf16* tb = B_KS ? p.B + (size_t)kbeg * p.ldb + n0 : p.B + (size_t)n0 * p.ldb + kbeg;
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        ra[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(ta + (size_t)pl * p.a_plane), 0, 0x7fffffff, 0x00020000);
+        rb[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(tb + (size_t)pl * p.b_plane), 0, 0x7fffffff, 0x00020000);
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const int row = (lw + 4 * j) * 16 + (lane >> 2);
-        const int m = min(m0 + row, p.M - 1);
-        const int ow = m % p.cv_wo, t2 = m / p.cv_wo;
-        const int oh = t2 % p.cv_ho, b = t2 / p.cv_ho;
-        cih0[j] = oh * p.cv_stride - p.cv_pad_h;
-        ciw0[j] = ow * p.cv_stride - p.cv_pad_w;
-        cbase[j] = ((b * p.cv_h + cih0[j]) * p.cv_w + ciw0[j]) * p.cv_cin * 2 + (((lane & 3) ^ kc16_swz(row)) << 4);
+        oa[j] = (int)glds_lane_off16<A_KS>(lw + 4 * j, lane, p.lda, EDGE ? p.M - m0 : 0x7fffffff);
+        ob[j] = (int)glds_lane_off16<B_KS>(lw + 4 * j, lane, p.ldb, EDGE ? p.N - n0 : 0x7fffffff);
       }
-      ctap = kbeg / p.cv_cin; cc0 = kbeg - ctap * p.cv_cin;
-      ckh = ctap / p.cv_kw; ckw = ctap - ckh * p.cv_kw;
-    }
-    if (CONV == 2) {
-      // the lane's 16-byte chunk = 8 consecutive columns n = (tap, ci .. ci+7) of the [k][N] image (cv_cin % 8 == 0)
-      const int ch = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (lw & 3));
-      const int n = min(n0 + ch * 8, p.N - 8);
-      const int tap = n / p.cv_cin;
-      wcol = n - tap * p.cv_cin;
-      wkh = tap / p.cv_kw; wkw = tap - wkh * p.cv_kw;
-    }
-    auto issue = [&](const int kt, const int stage_off) {
+      if (CONV == 1) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int row = (lw + 4 * j) * 16 + (lane >> 2);
+          const int m = min(m0 + row, p.M - 1);
+          const int ow = m % p.cv_wo, t2 = m / p.cv_wo;
+          const int oh = t2 % p.cv_ho, b = t2 / p.cv_ho;
+          cih0[j] = oh * p.cv_stride - p.cv_pad_h;
+          ciw0[j] = ow * p.cv_stride - p.cv_pad_w;
+          cbase[j] = ((b * p.cv_h + cih0[j]) * p.cv_w + ciw0[j]) * p.cv_cin * 2 + (((lane & 3) ^ kc16_swz(row)) << 4);
+        }
+        ctap = kbeg / p.cv_cin; cc0 = kbeg - ctap * p.cv_cin;
+        ckh = ctap / p.cv_kw; ckw = ctap - ckh * p.cv_kw;
+      }
+      if (CONV == 2) {
+        // the lane's 16-byte chunk = 8 consecutive columns n = (tap, ci .. ci+7) of the [k][N] image (cv_cin % 8 == 0)
+        const int ch = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (lw & 3));
+        const int n = min(n0 + ch * 8, p.N - 8);
+        const int tap = n / p.cv_cin;
+        wcol = n - tap * p.cv_cin;
+        wkh = tap / p.cv_kw; wkw = tap - wkh * p.cv_kw;
+      }
+    };
+    auto issue = [&](const int stage_off) {
       const int sa = kt * ga_step, sb = kt * gb_step;
       char* d = lds + stage_off + lw * 1024;
       int va[2] = {oa[0], oa[1]}, vb[2] = {ob[0], ob[1]};
@@ -232,15 +253,30 @@ __device__ __forceinline__ bool planes_mainloop16(const PlanesArgs& p, const int
           else PLP_BLDS16(rb[pl], d + (NPL + pl) * Cf::OPP + j * 4096, vb[j], sb);
         }
     };
-    issue(0, st[0]);
-    if (nk > 1) { issue(1, st[1]); wait_vmcnt<Cf::NDMA>(); } else { wait_vmcnt<0>(); }
+    // the stream: items in order, each one's k-tiles in order; an item without k-tiles (a K slice past the end) is skipped,
+    // as the computing waves skip it
+    auto open_item = [&]() {
+      for (; it < item_hi; ++it) {
+        setup();
+        if (nk > 0) { kt = 0; return true; }
+      }
+      return false;
+    };
+    auto issue_next = [&](const int stage_off) {     // called exactly `total` times
+      if (kt >= nk) { ++it; if (!open_item()) return; }
+      issue(stage_off);
+      ++kt;
+    };
+    if (total <= 0 || !open_item()) return;
+    issue_next(st[0]);
+    if (total > 1) { issue_next(st[1]); wait_vmcnt<Cf::NDMA>(); } else { wait_vmcnt<0>(); }
     barrier();
-    for (int kt = 0; kt < nk; ++kt) {
-      if (kt + 2 < nk) { issue(kt + 2, st[2]); wait_vmcnt<Cf::NDMA>(); } else { wait_vmcnt<0>(); }
+    for (int g = 0; g < total; ++g) {
+      if (g + 2 < total) { issue_next(st[2]); wait_vmcnt<Cf::NDMA>(); } else { wait_vmcnt<0>(); }
       barrier();
       rotate();
     }
-    return false;
+    return;
   }
 
   FragAddr16<A_KS> fra;
@@ -249,6 +285,7 @@ __device__ __forceinline__ bool planes_mainloop16(const PlanesArgs& p, const int
   frb.init(wn, lane);
   s16x8 fa[4][NPL];          // A fragments of the tile in flight (row tiles 0..3)
   s16x8 fb[2][4][NPL];       // B fragments: set P of tile kt, set 1-P of tile kt+1
+  f32x4v acc[NACC][4][4];
 
 #define PLP16_READ_A(stage_off, t0, t1)                                                      \
   do {                                                                                       \
@@ -281,6 +318,7 @@ __device__ __forceinline__ bool planes_mainloop16(const PlanesArgs& p, const int
 
   constexpr int RA = NPL * (A_KS ? 2 : 1), RB = NPL * (B_KS ? 2 : 1);     // ds_reads per fragment tile
   constexpr int NMF = 8 * ModeCfg<MODE>::NPROD;                           // MFMAs per half step
+  int nk = 0;
   auto step = [&](const int kt, auto par, auto steady) {
     constexpr int P = decltype(par)::value;
     constexpr bool STEADY = decltype(steady)::value;
@@ -301,25 +339,40 @@ __device__ __forceinline__ bool planes_mainloop16(const PlanesArgs& p, const int
     rotate();
   };
 
-  barrier();
-  PLP16_READ_A(st[0], 0, 2);
-  PLP16_READ_B(0, st[0]);
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
-  int kt = 0;
-  for (; kt + 3 < nk; kt += 2) {
-    step(kt, P0{}, std::true_type{});
-    step(kt + 1, P1{}, std::true_type{});
-  }
-  for (; kt < nk; kt += 2) {
-    step(kt, P0{}, std::false_type{});
-    if (kt + 1 < nk) step(kt + 1, P1{}, std::false_type{});
+  bool first = true;
+  for (int w = item_lo; w < item_hi; ++w) {
+    int m0, n0, slice, kbeg;
+    nk = decode(w, m0, n0, slice, kbeg);
+#pragma unroll
+    for (int c = 0; c < NACC; ++c)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[c][a][b][r] = 0.f;
+    if (nk > 0) {
+      if (first) { barrier(); first = false; }   // the stream's first k-tile has landed (later ones: the previous step's barrier)
+      PLP16_READ_A(st[0], 0, 2);
+      PLP16_READ_B(0, st[0]);
+      int kt = 0;
+      for (; kt + 3 < nk; kt += 2) {
+        step(kt, P0{}, std::true_type{});
+        step(kt + 1, P1{}, std::true_type{});
+      }
+      for (; kt < nk; kt += 2) {
+        step(kt, P0{}, std::false_type{});
+        if (kt + 1 < nk) step(kt + 1, P1{}, std::false_type{});
+      }
+    }
+    epi(acc, m0, n0, slice);
   }
 #undef PLP16_READ_A
 #undef PLP16_READ_B
 #undef PLP16_MFS
 #undef PLP16_ROWS
-  return true;
 }
 
 }  // namespace plp
