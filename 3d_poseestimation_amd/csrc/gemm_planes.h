@@ -65,6 +65,7 @@ struct PlanesArgs {
   //   forward / data gradient (NT, gathered A): A = x, row m = output pixel (b, oh, ow), k = (kh*cv_kw + kw)*cv_cin + ci;
   //   weight gradient (TN, gathered B):          B = x, k = output pixel, column n = (kh*cv_kw + kw)*cv_cin + ci.
   int cv_cin, cv_h, cv_w, cv_ho, cv_wo, cv_kw, cv_stride, cv_pad_h, cv_pad_w;
+  int abl;           // timing-only ablations (POSELIFT_ABL, wrong results by construction): 2 = no operand DMA, 4 = no MFMAs
 };
 
 template <int BKX, int NPL, int NST = 3>

@@ -21,7 +21,24 @@ struct PlanesKern {
   float out_scale;
   const float* dyn_inv;
   int vec_addend;          // POSELIFT_ADDEND_SCALAR=1 (same-box A/B): the addend through gemm_epilogue's dword loads
+  int nt_store;            // C leaves with nontemporal stores (an output far larger than the caches, read next from HBM anyway)
 };
+
+// x_l + x_(l ^ 16) and x_l + x_(l ^ 32) in every lane, by ONE vector instruction each (gfx950: v_permlane16_swap /
+// v_permlane32_swap exchange 16- / 32-lane rows of two registers) instead of a ds_bpermute round trip through the LDS
+// crossbar.  IEEE addition commutes, so the sums are bit for bit those of `x += __shfl_xor(x, 16 | 32)`.
+__device__ __forceinline__ float xadd16(const float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xadd32(const float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float4 xadd_rows(float4 s) {       // the four lanes l, l^16, l^32, l^48: fixed order (16, then 32)
+  s.x = xadd32(xadd16(s.x)); s.y = xadd32(xadd16(s.y)); s.z = xadd32(xadd16(s.z)); s.w = xadd32(xadd16(s.w));
+  return s;
+}
 
 // ---- the epilogue on the wave's 64x64 block staged in its own 17 KB of LDS (row stride 68 floats: conflict-free both
 // ways), everything as 16-byte accesses on 256-byte row segments.  Lane (lr = lane >> 4, lc = 4 (lane & 15)) owns columns
@@ -99,12 +116,23 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
     }
     return;
   }
+  if (k.nt_store && C) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int it = 0; it < 16; ++it)
+      if (ok(it)) {
+        const f4v q = {v[it].x, v[it].y, v[it].z, v[it].w};
+        __builtin_nontemporal_store(q, reinterpret_cast<f4v*>(C + o0 + (size_t)it * 4 * e.ldc));
+        if (cpd.kind) store_planes4(cpd, o0 + (size_t)it * 4 * e.ldc, v[it]);
+      }
+  } else {
 #pragma unroll
   for (int it = 0; it < 16; ++it)
     if (ok(it)) {
       if (C) *reinterpret_cast<float4*>(C + o0 + (size_t)it * 4 * e.ldc) = v[it];
       if (cpd.kind) store_planes4(cpd, o0 + (size_t)it * 4 * e.ldc, v[it]);
     }
+  }
   if (plain) return;
   if (e.stat_sum) {
     // training-mode BatchNorm partial statistics of this 64-row block (sum and M2 about the block's own mean); lanes l,
@@ -117,10 +145,7 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int it = 0; it < 16; ++it) { s.x += v[it].x; s.y += v[it].y; s.z += v[it].z; s.w += v[it].w; }
-#pragma unroll
-    for (int o = 16; o <= 32; o <<= 1) {
-      s.x += __shfl_xor(s.x, o); s.y += __shfl_xor(s.y, o); s.z += __shfl_xor(s.z, o); s.w += __shfl_xor(s.w, o);
-    }
+    s = xadd_rows(s);
     const int cnt = EDGE ? max(0, min(64, nrows)) : 64;
     const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
     const float4 mean = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
@@ -131,10 +156,7 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
       const float dx = v[it].x - mean.x, dy = v[it].y - mean.y, dz = v[it].z - mean.z, dw = v[it].w - mean.w;
       m2.x = fmaf(dx, dx, m2.x); m2.y = fmaf(dy, dy, m2.y); m2.z = fmaf(dz, dz, m2.z); m2.w = fmaf(dw, dw, m2.w);
     }
-#pragma unroll
-    for (int o = 16; o <= 32; o <<= 1) {
-      m2.x += __shfl_xor(m2.x, o); m2.y += __shfl_xor(m2.y, o); m2.z += __shfl_xor(m2.z, o); m2.w += __shfl_xor(m2.w, o);
-    }
+    m2 = xadd_rows(m2);
     if (lr == 0 && cok) {
       const size_t o = (size_t)((m0 >> 6) + wm) * e.N + col0;
       *reinterpret_cast<float4*>(e.stat_sum + o) = s;
@@ -170,11 +192,8 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
       mxd = fmaxf(fmaxf(mxd, fmaxf(fabsf(d0), fabsf(d1))), fmaxf(fabsf(d2), fabsf(d3)));
       mxz = fmaxf(fmaxf(mxz, fmaxf(fabsf(z0), fabsf(z1))), fmaxf(fabsf(z2), fabsf(z3)));
     }
-#pragma unroll
-    for (int o = 16; o <= 32; o <<= 1) {
-      s1.x += __shfl_xor(s1.x, o); s1.y += __shfl_xor(s1.y, o); s1.z += __shfl_xor(s1.z, o); s1.w += __shfl_xor(s1.w, o);
-      s2.x += __shfl_xor(s2.x, o); s2.y += __shfl_xor(s2.y, o); s2.z += __shfl_xor(s2.z, o); s2.w += __shfl_xor(s2.w, o);
-    }
+    s1 = xadd_rows(s1);
+    s2 = xadd_rows(s2);
     const int rg = (m0 >> 6) + wm;                   // 64-row block of the whole matrix
     if (lr == 0) {
       *reinterpret_cast<float4*>(e.bnr_part_dy + (size_t)rg * N + col0) = s1;
@@ -198,14 +217,20 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
 // CONV (16x16x32 loop only): 1 = A gathered as a convolution input (NT), 2 = B gathered for the weight gradient (TN)
 // PERSIST (16x16x32 loop only): the workgroup walks a run of work items, operands streaming across the item boundaries
 // (gemm_planes16.h); the epilogue then stages through LDS of its own behind the three-stage ring.
-template <int MODE> constexpr int ring_bytes() { return plp::PlanesCfg<32, plp::ModeCfg<MODE>::NPL, 3>::LDS; }
-constexpr int kHalfStage = 4 * 32 * 68 * 4;      // four waves x 32 rows x 68 floats: the staged epilogue works in two halves
-// LDS: three operand stages, and never less than the 4 x 17 KB the 32x32x16 loop's epilogue stages a whole block in
+template <int MODE, int NST = 3> constexpr int ring_bytes() { return plp::PlanesCfg<32, plp::ModeCfg<MODE>::NPL, NST>::LDS; }
+// the staged epilogue takes the wave's 64x64 block through LDS in 64 / ER passes of ER rows x 68 floats per wave
+template <int ER> constexpr int stage_bytes() { return 4 * ER * 68 * 4; }
+// ring depth of the persistent form.  (Measured with 4 stages + 16-row staging passes for f16x3, 6 for bf16: the K = 64
+// layer 372 us against 379 us with 3 -- the ring is not what those launches wait for)
+template <int MODE> constexpr int persist_nst() { return 3; }
+constexpr int kPersistRows = 32;
+// LDS: the operand ring, and never less than the 4 x 17 KB the 32x32x16 loop's epilogue stages a whole block in
 template <int MODE, bool PERSIST = false>
 constexpr int lds_bytes() {
-  if (PERSIST) return ring_bytes<MODE>() + kHalfStage;
+  if (PERSIST) return ring_bytes<MODE, persist_nst<MODE>()>() + stage_bytes<kPersistRows>();
   return ring_bytes<MODE>() > 4 * 64 * 68 * 4 ? ring_bytes<MODE>() : 4 * 64 * 68 * 4;
 }
+static_assert(lds_bytes<plp::kF16x3, true>() <= 160 * 1024 && lds_bytes<plp::kBf16, true>() <= 160 * 1024, "LDS per CU");
 
 template <bool A_KS, bool B_KS, int MODE, bool S16, bool EDGE = false, int CONV = 0, bool PERSIST = false>
 __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block_id, const int nblocks, const int nwork, char* lds) {
@@ -214,33 +239,36 @@ __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block
   // main + low / 2048, then back from the operands' power-of-two scales (exact unless the result under/overflows)
   const float os = MODE == plp::kF16x3 ? (k.dyn_inv ? k.out_scale * k.dyn_inv[0] : k.out_scale) : 1.f;
   if constexpr (S16) {
-    // the wave's 64x64 block goes through 32 rows x 68 floats of LDS twice (rows 0-31, then 32-63): the lane that owned
-    // accumulator elements leaves with float4 rows (v[it] = row 4 it + (lane >> 4), columns 4 (lane & 15) ..)
-    float* ldsw = reinterpret_cast<float*>(lds + (PERSIST ? ring_bytes<MODE>() : 0)) + (wave & 3) * 32 * 68;
+    // the wave's 64x64 block goes through ER rows x 68 floats of LDS in 64 / ER passes: the lane that owned accumulator
+    // elements leaves with float4 rows (v[it] = row 4 it + (lane >> 4), columns 4 (lane & 15) ..)
+    constexpr int NST = PERSIST ? persist_nst<MODE>() : 3;
+    constexpr int ER = PERSIST ? kPersistRows : 32;
+    float* ldsw = reinterpret_cast<float*>(lds + (PERSIST ? ring_bytes<MODE, NST>() : 0)) + (wave & 3) * ER * 68;
     const int q = lane >> 4, c = lane & 15, lc = c * 4;
     auto epi = [&](plp::f32x4v (&acc)[plp::ModeCfg<MODE>::NACC][4][4], const int m0, const int n0, const int slice) {
       if (!PERSIST) __syncthreads();                     // every computing wave is done reading operand tiles (the staging
                                                          // rows alias the ring); PERSIST: a region of its own, wave-private
       float4 v[16];
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+      for (int pass = 0; pass < 64 / ER; ++pass) {
 #pragma unroll
-        for (int r2 = 0; r2 < 2; ++r2)
+        for (int r2 = 0; r2 < ER / 16; ++r2)
 #pragma unroll
           for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              float x = acc[0][2 * half + r2][ct][r];
-              if constexpr (MODE == plp::kF16x3) x = fmaf(acc[1][2 * half + r2][ct][r], 1.0f / plp::kF16LoScale, x) * os;
+              float x = acc[0][pass * (ER / 16) + r2][ct][r];
+              if constexpr (MODE == plp::kF16x3) x = fmaf(acc[1][pass * (ER / 16) + r2][ct][r], 1.0f / plp::kF16LoScale, x) * os;
               ldsw[(r2 * 16 + 4 * q + r) * 68 + ct * 16 + c] = x;
             }
 #pragma unroll
-        for (int it = 0; it < 8; ++it) v[8 * half + it] = *reinterpret_cast<const float4*>(ldsw + (it * 4 + q) * 68 + lc);
+        for (int it = 0; it < ER / 4; ++it)
+          v[pass * (ER / 4) + it] = *reinterpret_cast<const float4*>(ldsw + (it * 4 + q) * 68 + lc);
       }
       float* C = k.e.C ? k.e.C + (k.e.split_k > 1 ? (size_t)slice * k.e.M * k.e.ldc : 0) : nullptr;
       staged_epilogue<EDGE>(k, C, v, m0, n0, wm, wn, lane);
     };
-    plp::planes_run16<A_KS, B_KS, MODE, EDGE, CONV, PERSIST>(k.p, block_id, nblocks, nwork, lds, epi);
+    plp::planes_run16<A_KS, B_KS, MODE, EDGE, CONV, PERSIST, NST>(k.p, block_id, nblocks, nwork, lds, epi);
   } else {
     float* ldsw = reinterpret_cast<float*>(lds) + (wave & 3) * 64 * 68;
     int m0, n0, slice;
@@ -346,6 +374,12 @@ PlanesKern kern_of(GemmLayout layout, const PlanesGemmArgs& a) {
   k.dyn_inv = a.dyn_inv;
   static const int vec = [] { const char* e = getenv("POSELIFT_ADDEND_SCALAR"); return (e && e[0] == '1') ? 0 : 1; }();
   k.vec_addend = vec;
+  // POSELIFT_ABL (timing-only, wrong results): 1 = the epilogue stores nothing to C, 2 = no operand DMA, 4 = no MFMAs
+  static const int abl = [] { const char* e = getenv("POSELIFT_ABL"); return e ? atoi(e) : 0; }();
+  k.p.abl = abl;
+  static const int ntc = [] { const char* e = getenv("POSELIFT_NT_C"); return e ? atoi(e) : 1; }();   // =0: same-box A/B
+  k.nt_store = (ntc && (int64_t)a.e.M * a.e.N * 4 >= (64ll << 20)) ? 1 : 0;
+  if (abl & 1) { k.e.C = nullptr; k.p.C = nullptr; }
   (void)layout;
   return k;
 }

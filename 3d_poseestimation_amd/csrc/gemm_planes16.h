@@ -105,12 +105,15 @@ __device__ __forceinline__ f32x4v mfma16x16(const s16x8 a, const s16x8 b, const 
 // that were spending most of their time in exactly those two ends.  One barrier per k-tile for every wave, as before;
 // `epi(acc, m0, n0, slice)` is called by the computing waves once per item.
 constexpr int kDmaOutOfRange = 0x7ffffff0;     // >= num_records of the gathered operand's descriptor
-template <bool A_KS, bool B_KS, int MODE, bool EDGE, int CONV, bool PERSIST, class Epi>
+// NST: stages of the operand ring (3: a k-tile being read, one landed, one in flight; the persistent form of the short-K
+// layers runs deeper -- every barrier waits for the NEXT k-tile, so the ring depth is what HBM latency is hidden behind).
+template <bool A_KS, bool B_KS, int MODE, bool EDGE, int CONV, bool PERSIST, int NST, class Epi>
 __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int block_id, const int nblocks, const int nwork,
                                              char* __restrict__ lds, Epi&& epi) {
   static_assert(MODE == kF16x3 || MODE == kBf16, "two fp16 planes or one bf16 plane");
   constexpr int NPL = ModeCfg<MODE>::NPL, NACC = ModeCfg<MODE>::NACC;
-  using Cf = PlanesCfg<32, NPL, 3>;
+  using Cf = PlanesCfg<32, NPL, NST>;
+  static_assert(NST >= 3 && (NST - 2) * Cf::NDMA <= 63, "ring depth: vmcnt counts at most 63 requests");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -157,8 +160,10 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
   };
-  int st[3] = {0, Cf::STAGE, 2 * Cf::STAGE};      // st[q] = stage of k-tile g + q of the stream
-  auto rotate = [&]() { const int o = st[0]; st[0] = st[1]; st[1] = st[2]; st[2] = o; };
+  // stage of k-tile g of the stream: (g % NST) * STAGE, kept as running offsets
+  auto next_stage = [](const int o) { return o + Cf::STAGE == NST * Cf::STAGE ? 0 : o + Cf::STAGE; };
+  int st[2] = {0, Cf::STAGE};                       // computing waves: the k-tile being read, the next one
+  auto rotate = [&]() { st[0] = st[1]; st[1] = next_stage(st[1]); };
 
   if (loader) {
     static_assert(CONV == 0 || (CONV == 1 && !A_KS && !B_KS) || (CONV == 2 && A_KS && B_KS), "conv gathers: NT forward, TN wgrad");
@@ -218,6 +223,7 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
       }
     };
     auto issue = [&](const int stage_off) {
+      if (p.abl & 2) return;
       const int sa = kt * ga_step, sb = kt * gb_step;
       char* d = lds + stage_off + lw * 1024;
       int va[2] = {oa[0], oa[1]}, vb[2] = {ob[0], ob[1]};
@@ -262,19 +268,32 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
       }
       return false;
     };
-    auto issue_next = [&](const int stage_off) {     // called exactly `total` times
+    int sw = 0;                                       // stage the next k-tile is issued into
+    auto issue_next = [&]() {                         // called exactly `total` times
       if (kt >= nk) { ++it; if (!open_item()) return; }
-      issue(stage_off);
+      issue(sw);
+      sw = next_stage(sw);
       ++kt;
     };
+    // at most n k-tiles (the youngest) still in flight
+    auto wait_tiles = [&](const int n) {
+      if (NST >= 7 && n >= 5) wait_vmcnt<5 * Cf::NDMA>();
+      else if (NST >= 6 && n == 4) wait_vmcnt<4 * Cf::NDMA>();
+      else if (NST >= 5 && n == 3) wait_vmcnt<3 * Cf::NDMA>();
+      else if (NST >= 4 && n == 2) wait_vmcnt<2 * Cf::NDMA>();
+      else if (n == 1) wait_vmcnt<Cf::NDMA>();
+      else wait_vmcnt<0>();
+    };
+    static_assert(NST <= 7, "wait_tiles covers rings of up to seven stages");
     if (total <= 0 || !open_item()) return;
-    issue_next(st[0]);
-    if (total > 1) { issue_next(st[1]); wait_vmcnt<Cf::NDMA>(); } else { wait_vmcnt<0>(); }
+    const int pre = min(total, NST - 1);
+    for (int i = 0; i < pre; ++i) issue_next();
+    wait_tiles(pre - 1);                              // k-tile 0 has landed
     barrier();
     for (int g = 0; g < total; ++g) {
-      if (g + 2 < total) { issue_next(st[2]); wait_vmcnt<Cf::NDMA>(); } else { wait_vmcnt<0>(); }
+      if (g + NST - 1 < total) issue_next();          // into the stage k-tile g-1 left at the previous barrier
+      wait_tiles(max(min(g + NST - 1, total - 1) - (g + 1), 0));      // k-tile g+1 has landed
       barrier();
-      rotate();
     }
     return;
   }
@@ -312,6 +331,7 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
   } while (0)
 #define PLP16_ROWS(set, r0, r1)                                                              \
   do {                                                                                       \
+    if (p.abl & 4) break;                                                                    \
     _Pragma("unroll") for (int rt = (r0); rt < (r1); ++rt)                                   \
     _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) PLP16_MFS(set, rt, ct);                 \
   } while (0)
@@ -319,6 +339,9 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
   constexpr int RA = NPL * (A_KS ? 2 : 1), RB = NPL * (B_KS ? 2 : 1);     // ds_reads per fragment tile
   constexpr int NMF = 8 * ModeCfg<MODE>::NPROD;                           // MFMAs per half step
   int nk = 0;
+  const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+  // (Tried: the item's first k-tile as a step of its own whose MFMAs take a zero C operand, instead of 128 accumulator moves
+  //  per item -- a fifth instance of the step body: hipcc then spills 360-650 VGPRs in the persistent kernels.  Not kept.)
   auto step = [&](const int kt, auto par, auto steady) {
     constexpr int P = decltype(par)::value;
     constexpr bool STEADY = decltype(steady)::value;
@@ -341,30 +364,39 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
 
   using P0 = std::integral_constant<int, 0>;
   using P1 = std::integral_constant<int, 1>;
+  using T_ = std::true_type;
+  using F_ = std::false_type;
   bool first = true;
+  // (m0, n0, slice) of the run's items without a division per item: the column tile advances, then the row block
+  int m0, n0, slice, kbeg;
+  nk = decode(item_lo, m0, n0, slice, kbeg);
   for (int w = item_lo; w < item_hi; ++w) {
-    int m0, n0, slice, kbeg;
-    nk = decode(w, m0, n0, slice, kbeg);
+    if (w > item_lo) {
+      if (splits > 1) {
+        nk = decode(w, m0, n0, slice, kbeg);
+      } else {
+        n0 += 128;
+        if (n0 >= tiles_n * 128) { n0 = 0; m0 += 128; }
+      }
+    }
 #pragma unroll
     for (int c = 0; c < NACC; ++c)
 #pragma unroll
       for (int a = 0; a < 4; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[c][a][b][r] = 0.f;
+        for (int b = 0; b < 4; ++b) acc[c][a][b] = zero4;
     if (nk > 0) {
       if (first) { barrier(); first = false; }   // the stream's first k-tile has landed (later ones: the previous step's barrier)
       PLP16_READ_A(st[0], 0, 2);
       PLP16_READ_B(0, st[0]);
       int kt = 0;
       for (; kt + 3 < nk; kt += 2) {
-        step(kt, P0{}, std::true_type{});
-        step(kt + 1, P1{}, std::true_type{});
+        step(kt, P0{}, T_{});
+        step(kt + 1, P1{}, T_{});
       }
       for (; kt < nk; kt += 2) {
-        step(kt, P0{}, std::false_type{});
-        if (kt + 1 < nk) step(kt + 1, P1{}, std::false_type{});
+        step(kt, P0{}, F_{});
+        if (kt + 1 < nk) step(kt + 1, P1{}, F_{});
       }
     }
     epi(acc, m0, n0, slice);
