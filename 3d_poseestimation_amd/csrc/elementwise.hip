@@ -403,7 +403,7 @@ __device__ __forceinline__ void bn_apply_rows(
     if (active) {
       float4 out = make_float4(o[0], o[1], o[2], o[3]);
       if (RESID && !resid_first) { out.x += rv.x; out.y += rv.y; out.z += rv.z; out.w += rv.w; }
-      if (act) st4(act + off, out);
+      if (act) st4_nt(act + off, out, pd.nt);
       if (pd.kind) store_planes4(pd, off, out);
     }
   }
@@ -659,7 +659,7 @@ __device__ __forceinline__ void bn_bwd_dz_rows(
       d.z = c0.z * (d.z - c1.z - (zv.z - mu.z) * rs.z * c2.z);
       d.w = c0.w * (d.w - c1.w - (zv.w - mu.w) * rs.w * c2.w);
     }
-    if (dz) st4(dz + off, d);
+    if (dz) st4_nt(dz + off, d, pd.nt);
     if (pd.kind) store_planes4(pd, off, d);
     sdb.x += d.x; sdb.y += d.y; sdb.z += d.z; sdb.w += d.w;
   }
@@ -1234,7 +1234,8 @@ int launch_bn_apply(const float* z, const float* scale, const float* shift, cons
                     int layer, const uint64_t* inject_keep, hipStream_t s, const PlaneOut* planes,
                     const uint64_t* step_dev) {
   int mode = 0;
-  const PlaneOut po = planes ? *planes : PlaneOut{nullptr, nullptr, 1.f, nullptr, 0};
+  PlaneOut po = planes ? *planes : PlaneOut{nullptr, nullptr, 1.f, nullptr, 0};
+  po.nt = (nontemporal_on() && (int64_t)B * H * 4 >= kNontemporalBytes) ? 1 : 0;
   if (!act && !po.kind) PL_FAIL(PL_EINVAL, "bn_apply: nothing to write");
   float kscale = 1.f;
   if (p >= 1.f) mode = 3;
@@ -1292,12 +1293,18 @@ int launch_bn_bwd_dz(const float* g, const uint64_t* bits, const float* z, const
                      const float* rstd, const float* coef, float keep_scale, int bn, int B, int H,
                      float* dz, float* part_db, hipStream_t s, int Hc, const PlaneOut* planes, int rc) {
   dim3 grid((H + 255) / 256, rc > 0 ? rc : bwd_row_chunks(B, H));
-  const PlaneOut po = planes ? *planes : PlaneOut{nullptr, nullptr, 1.f, nullptr, 0};
+  PlaneOut po = planes ? *planes : PlaneOut{nullptr, nullptr, 1.f, nullptr, 0};
+  po.nt = (nontemporal_on() && (int64_t)B * H * 4 >= kNontemporalBytes) ? 1 : 0;
   if (!dz && !po.kind) PL_FAIL(PL_EINVAL, "bn_bwd_dz: nothing to write");
   hipLaunchKernelGGL(bn_bwd_dz_kernel, grid, dim3(NTHR), 0, s, g, bits, z, mean, rstd, coef, keep_scale,
                      bn, B, H, dz, part_db, Hc > 0 ? Hc : H, po);
   PL_CHECK_LAUNCH("bn_bwd_dz");
   return PL_OK;
+}
+
+bool nontemporal_on() {
+  static const bool on = [] { const char* e = getenv("POSELIFT_NT"); return !(e && e[0] == '0'); }();
+  return on;
 }
 
 int launch_split_planes(const float* x, int64_t n, const PlaneOut& out, hipStream_t s) {

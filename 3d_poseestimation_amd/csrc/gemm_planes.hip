@@ -102,7 +102,7 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
       }
     }
   }
-  const PlaneDst cpd = {e.cpl_h, e.cpl_l, e.cpl_scale, plain ? 0 : e.cpl_kind};      // the result as the next GEMM's operand planes
+  const PlaneDst cpd = {e.cpl_h, e.cpl_l, e.cpl_scale, plain ? 0 : e.cpl_kind, k.nt_store};      // the result as the next GEMM's operand planes
   if (EDGE && e.scat_on) {                       // one output parity of a transposed convolution (GemmArgs::scat_*)
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
@@ -378,7 +378,7 @@ PlanesKern kern_of(GemmLayout layout, const PlanesGemmArgs& a) {
   static const int abl = [] { const char* e = getenv("POSELIFT_ABL"); return e ? atoi(e) : 0; }();
   k.p.abl = abl;
   static const int ntc = [] { const char* e = getenv("POSELIFT_NT_C"); return e ? atoi(e) : 1; }();   // =0: same-box A/B
-  k.nt_store = (ntc && (int64_t)a.e.M * a.e.N * 4 >= (64ll << 20)) ? 1 : 0;
+  k.nt_store = (ntc && nontemporal_on() && (int64_t)a.e.M * a.e.N * 4 >= kNontemporalBytes) ? 1 : 0;
   if (abl & 1) { k.e.C = nullptr; k.p.C = nullptr; }
   (void)layout;
   return k;

@@ -105,7 +105,11 @@ struct PlaneOut {
   float scale;
   const float* dyn;
   int kind;
+  int nt;             // the tensor (planes and its fp32 twin) leaves with nontemporal stores: far larger than the caches
 };
+// outputs at least this large are streamed past the caches (their consumer reads them from HBM whatever the store policy)
+constexpr long long kNontemporalBytes = 64ll << 20;
+bool nontemporal_on();     // POSELIFT_NT=0: plain stores everywhere (same-box A/B)
 constexpr float kActPlaneScale = 1.0f;      // activations: fp16 covers 6e-5 .. 65504 in h, the remainder in l
 constexpr float kWeightPlaneScale = 16.0f;  // weights (|w| ~ 0.03 at init): 3.8e-6 .. 4094
 // conv path: eval-mode feature maps of an unnormalised network reach 1e5 (seeded test weights: 6.7e4 after the first

@@ -7,10 +7,10 @@ namespace pl {
 
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-struct PlaneDst { unsigned short* h; unsigned short* l; float scale; int kind; };
+struct PlaneDst { unsigned short* h; unsigned short* l; float scale; int kind; int nt; };
 
 __device__ __forceinline__ PlaneDst plane_dst(const PlaneOut& o) {
-  PlaneDst d = {o.h, o.l, o.scale, o.kind};
+  PlaneDst d = {o.h, o.l, o.scale, o.kind, o.nt};
   if (o.kind == 2 && o.dyn) d.scale = o.dyn[0];
   return d;
 }
@@ -24,12 +24,28 @@ __device__ __forceinline__ void store_planes4(const PlaneDst& d, size_t off, flo
       hh[j] = (_Float16)a[j];
       ll[j] = (_Float16)((a[j] - (float)hh[j]) * 2048.0f);
     }
-    *reinterpret_cast<f16x4*>(d.h + off) = hh;
-    *reinterpret_cast<f16x4*>(d.l + off) = ll;
+    if (d.nt) {
+      __builtin_nontemporal_store(hh, reinterpret_cast<f16x4*>(d.h + off));
+      __builtin_nontemporal_store(ll, reinterpret_cast<f16x4*>(d.l + off));
+    } else {
+      *reinterpret_cast<f16x4*>(d.h + off) = hh;
+      *reinterpret_cast<f16x4*>(d.l + off) = ll;
+    }
   } else if (d.kind == 1) {
     bf16x4 q;
     q[0] = (__bf16)v.x; q[1] = (__bf16)v.y; q[2] = (__bf16)v.z; q[3] = (__bf16)v.w;
-    *reinterpret_cast<bf16x4*>(d.h + off) = q;
+    if (d.nt) __builtin_nontemporal_store(q, reinterpret_cast<bf16x4*>(d.h + off));
+    else *reinterpret_cast<bf16x4*>(d.h + off) = q;
+  }
+}
+
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_nt(float* p, float4 v, int nt) {
+  if (nt) {
+    const f32x4s q = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(q, reinterpret_cast<f32x4s*>(p));
+  } else {
+    *reinterpret_cast<float4*>(p) = v;
   }
 }
 
