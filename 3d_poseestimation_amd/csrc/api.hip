@@ -64,9 +64,10 @@ int sync_gather(const PLDesc* d, float* base, int64_t floats_per_rank, hipStream
 }
 
 // PL_F16X3: the 1024-wide GEMMs run on fp16 operand planes written by the kernels that produce the tensors
-// (gemm_planes.hip).  That path wants whole 128x128 tiles, BatchNorm (its backward pass 1 supplies the range bound
-// of dz) and local statistics; anything else runs the same fp32-grade arithmetic class on the round-1 kernels
-// (PL_BF16X6: fp32 operands split inside the GEMM) -- never a lower precision, never the CPU.
+// (gemm_planes.hip).  That path wants whole 128x128 tiles and BatchNorm (its backward pass 1 supplies the range bound
+// of dz; under cross-rank statistics every rank's maxima travel in the gathered slab, round 3); anything else runs the
+// same fp32-grade arithmetic class on the round-1 kernels (PL_BF16X6: fp32 operands split inside the GEMM) -- never a
+// lower precision, never the CPU.
 // PL_BF16 takes the same path with ONE bf16 plane per tensor (kind 1): bf16 STORAGE of the GEMM operands
 // (activations, dz, weight shadow), no scales -- bf16 has fp32's exponent range.
 int tn_splits(int M, int N, int K) {
@@ -78,7 +79,7 @@ int tn_splits(int M, int N, int K) {
 }
 
 inline int planes_kind(const PLDesc* d, int64_t B) {       // PlaneOut::kind of the operand planes, 0 = not on that path
-  const bool ok = d->bn && sync_world(d) == 1 && d->hidden % 128 == 0 && B % 128 == 0 && d->num_stage >= 1 &&
+  const bool ok = d->bn && d->hidden % 128 == 0 && B % 128 == 0 && d->num_stage >= 1 &&
                   B * (int64_t)d->hidden * 4 < (1ll << 30);
   if (!ok) return 0;
   // the weight-gradient GEMM splits K = B into tn_splits slices of whole 32-k tiles (H = 512 with B = 128 * 17 would
@@ -184,7 +185,10 @@ Ws plan(const PLDesc* d, int64_t B) {
     w.dbpart.push_back(take((size_t)w.RC * H * 4));
   }
   const int Pmax = std::max(std::max(w.G, skinny_stat_groups((int)B)), w.RC);
-  w.stat = take((size_t)sync_world(d) * 2 * Pmax * H * 4);
+  // per rank: two sets of at most Pmax partial rows, and (planes path under SyncBN) the {max|dy|, max|zhat|} pairs of
+  // BatchNorm-backward pass 1 behind them
+  const size_t amax_pairs = std::max((size_t)((H + 255) / 256) * w.RC, (size_t)(B / 64 + 1) * (H / 32 + 1));
+  w.stat = take((size_t)sync_world(d) * ((size_t)2 * Pmax * H + 2 * amax_pairs) * 4);
   w.scale = take((size_t)w.L * H * 4);
   w.shift = take((size_t)w.L * H * 4);
   w.coef = take((size_t)3 * H * 4);
@@ -227,6 +231,32 @@ Ws plan(const PLDesc* d, int64_t B) {
   }
   w.total = o;
   return w;
+}
+
+// Where BatchNorm-backward pass 1 of one layer puts its output: this rank's slab of the gather buffer -- rc partial rows of
+// sum dy, rc of sum dy zhat and, behind them, n_amax {max|dy|, max|zhat|} pairs (PL_F16X3: the range bound of dz).  One
+// rank: the sums at the head of the buffer and the maxima in the workspace's own amax region, as before round 3.
+struct BnrSlab {
+  float *mine, *amax_mine, *amax0;     // this rank's partial sums / maxima; rank 0's maxima (what the finalize kernel walks)
+  int64_t floats_per_rank;
+  int world;
+};
+BnrSlab bnr_slab(const PLDesc* d, const Ws& w, void* ws, int rc, int n_amax, bool eval_bn) {
+  BnrSlab b;
+  float* stat = reinterpret_cast<float*>(static_cast<char*>(ws) + w.stat);
+  b.world = eval_bn ? 1 : sync_world(d);
+  const int64_t sums = (int64_t)2 * rc * d->hidden;
+  if (b.world == 1) {
+    b.mine = stat;
+    b.amax_mine = b.amax0 = w.amax ? reinterpret_cast<float*>(static_cast<char*>(ws) + w.amax) : nullptr;
+    b.floats_per_rank = sums;
+    return b;
+  }
+  b.floats_per_rank = sums + 2 * (int64_t)n_amax;
+  b.mine = stat + (size_t)sync_rank(d) * b.floats_per_rank;
+  b.amax_mine = b.mine + sums;
+  b.amax0 = stat + sums;
+  return b;
 }
 
 struct Layer {
@@ -606,10 +636,11 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
       GemmArgs be = {};
       const int lt = w.L - 1;
       if (fused_reduce(d, w.planes, lt, w.L, eval_bn)) {      // pass 1 of the top hidden layer, on the block just produced
+        const BnrSlab sl = bnr_slab(d, w, ws, Bi / 64, (w.pkind == 2 && lt > 0) ? (Bi / 64) * (H / 32) : 0, eval_bn);
         be.bnr_z = f32(ws, w.z[lt]); be.bnr_bits = u64(ws, w.bits[lt]);
         be.bnr_mean = f32(ws, w.mean[lt]); be.bnr_rstd = f32(ws, w.rstd[lt]); be.bnr_kscale = kscale;
-        be.bnr_part_dy = f32(ws, w.stat); be.bnr_part_dyz = f32(ws, w.stat) + (size_t)(Bi / 64) * H;
-        be.bnr_amax = (w.pkind == 2 && lt > 0) ? f32(ws, w.amax) : nullptr;
+        be.bnr_part_dy = sl.mine; be.bnr_part_dyz = sl.mine + (size_t)(Bi / 64) * H;
+        be.bnr_amax = (w.pkind == 2 && lt > 0) ? sl.amax_mine : nullptr;
       }
       PL_TRY(launch_skinny_wide_out(dy, W5, nullptr, GA, Bi, O, H, true, nullptr, nullptr, s, &be));
     } else {
@@ -635,16 +666,16 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
       const bool fr = fused_reduce(d, w.planes, l, w.L, eval_bn);
       const int rc_l = fr ? Bi / 64 : w.RC;
       const int n_amax_l = fr ? (Bi / 64) * (l == w.L - 1 ? H / 32 : H / 64) : n_amax;   // (top layer: skinny epilogue, 32-column strips)
+      const BnrSlab sl = bnr_slab(d, w, ws, rc_l, dzs ? n_amax_l : 0, eval_bn);
       float* stat = f32(ws, w.stat);
-      float* mine = stat + (size_t)((eval_bn || fr) ? 0 : sync_rank(d)) * 2 * rc_l * H;
-      if (!fr) {
+      if (!fr)
         PL_TRY(launch_bn_bwd_reduce(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), kscale, Bi, H,
-                                    mine, mine + (size_t)rc_l * H, s, 0, dzs ? f32(ws, w.amax) : nullptr, rc_l));
-        if (!eval_bn) PL_TRY(sync_gather(d, stat, (int64_t)2 * rc_l * H, s));
-      }
+                                    sl.mine, sl.mine + (size_t)rc_l * H, s, 0, dzs ? sl.amax_mine : nullptr, rc_l));
+      // (fused: the partials were written by the GEMM / skinny epilogue that produced `gin`, into this rank's slab)
+      if (!eval_bn) PL_TRY(sync_gather(d, stat, sl.floats_per_rank, s));
       PL_TRY(launch_bn_bwd_finalize(stat, rc_l, eval_bn ? 1 : sync_world(d), eval_bn ? 0 : sync_rank(d), Bi, H, ly.gamma,
                                     f32(ws, w.rstd[l]), f32(ws, w.coef), ly.ggamma, ly.gbeta, s,
-                                    dzs ? f32(ws, w.amax) : nullptr, n_amax_l, dzs, eval_bn ? 1 : 0));
+                                    dzs ? sl.amax0 : nullptr, n_amax_l, dzs, eval_bn ? 1 : 0, sl.floats_per_rank, sl.world));
     } else {
       PL_TRY(launch_fill(ly.ggamma, H, 0.f, s));
       PL_TRY(launch_fill(ly.gbeta, H, 0.f, s));
@@ -661,14 +692,15 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
       if (l % 2 == 1) nn.e.addend = GA;
       if (fused_reduce(d, w.planes, l - 1, w.L, eval_bn)) {      // pass 1 of the layer below, on the block just produced
         const bool lower_scaled = w.pkind == 2 && l - 1 > 0;       // its dz planes (fp16) want the range maxima too
+        const BnrSlab sl = bnr_slab(d, w, ws, Bi / 64, lower_scaled ? (Bi / 64) * (H / 64) : 0, eval_bn);
         nn.e.bnr_z = f32(ws, w.z[l - 1]);
         nn.e.bnr_bits = u64(ws, w.bits[l - 1]);
         nn.e.bnr_mean = f32(ws, w.mean[l - 1]);
         nn.e.bnr_rstd = f32(ws, w.rstd[l - 1]);
         nn.e.bnr_kscale = kscale;
-        nn.e.bnr_part_dy = f32(ws, w.stat);
-        nn.e.bnr_part_dyz = f32(ws, w.stat) + (size_t)(Bi / 64) * H;
-        nn.e.bnr_amax = lower_scaled ? f32(ws, w.amax) : nullptr;
+        nn.e.bnr_part_dy = sl.mine;
+        nn.e.bnr_part_dyz = sl.mine + (size_t)(Bi / 64) * H;
+        nn.e.bnr_amax = lower_scaled ? sl.amax_mine : nullptr;
       }
       float* wsl = f32(ws, w.wslab[l]);                // this layer's own slabs: combined by the range's one reduce launch
       PlanesGemmArgs tn = planes_args(w.pkind, u16(ws, w.dzp), BH, H, u16(ws, w.actp[l - 1]), BH, H,

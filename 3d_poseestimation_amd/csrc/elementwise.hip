@@ -509,7 +509,10 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_finalize_kernel(
     const float* __restrict__ part_all, int RC, int world, int rank, int Br, int H,
     const float* __restrict__ gamma, const float* __restrict__ rstd, float* __restrict__ coef,
     float* __restrict__ dgamma, float* __restrict__ dbeta, const float* __restrict__ part_amax, int n_amax,
-    float* __restrict__ dz_scale, int eval_mode) {
+    float* __restrict__ dz_scale, int eval_mode, long long rstride, int amax_world) {
+  // rstride: floats between two ranks' slabs (0: the dense 2 RC H); amax_world > 1: every rank's slab carries its n_amax
+  // {max|dy|, max|zhat|} pairs behind its partial sums (part_amax points at rank 0's) -- under SyncBN the batch means in dz
+  // are global, so the range bound of dz needs the GLOBAL maxima
   __shared__ float red[RPARTS][RCOLS];
   if (dz_scale && blockIdx.x == gridDim.x - 1) {
     // the extra workgroup: range bound of dz = c0 (dy - c1 - zhat c2), |c1| <= max|dy|, |c2| <= max|dy| (mean |zhat| <= 1):
@@ -517,13 +520,16 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_finalize_kernel(
     float a = 0.f, b = 0.f, c0 = 0.f;
     // (this one workgroup is the kernel's critical path: its loads go out eight at a time, at clamped indices -- a maximum does
     //  not care about repeats -- instead of one dependent round trip per trip)
-    for (int k0 = threadIdx.x; k0 < n_amax; k0 += 8 * NTHR) {
-      float2 t[8];
+    for (int r = 0; r < max(amax_world, 1); ++r) {
+      const float2* pa = reinterpret_cast<const float2*>(part_amax + (size_t)r * rstride);
+      for (int k0 = threadIdx.x; k0 < n_amax; k0 += 8 * NTHR) {
+        float2 t[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = reinterpret_cast<const float2*>(part_amax)[min(k0 + u * NTHR, n_amax - 1)];
-      __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < 8; ++u) t[u] = pa[min(k0 + u * NTHR, n_amax - 1)];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) { a = fmaxf(a, t[u].x); b = fmaxf(b, t[u].y); }
+        for (int u = 0; u < 8; ++u) { a = fmaxf(a, t[u].x); b = fmaxf(b, t[u].y); }
+      }
     }
     for (int k0 = threadIdx.x; k0 < H; k0 += 4 * NTHR) {
       float gv[4], rv[4];
@@ -559,8 +565,9 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_finalize_kernel(
   const int c = blockIdx.x * RCOLS + cl;
   const bool ok = c < H;
   const size_t RH = (size_t)RC * H;
+  const size_t RS = rstride > 0 ? (size_t)rstride : 2 * RH;
   // rank < 0: the "ranks" are replicas of a narrow map (bn_colstats_kernel): every partial is this process's own
-  const float* mine = part_all + (size_t)max(rank, 0) * 2 * RH;
+  const float* mine = part_all + (size_t)max(rank, 0) * RS;
   float gac = 0.f, rsc = 0.f;               // requested with the partials: one memory round trip, not two
   if (part == 0 && ok) { gac = gamma[c]; rsc = rstd[c]; }
   float a = 0.f, b = 0.f;
@@ -589,7 +596,7 @@ __global__ __launch_bounds__(NTHR) void bn_bwd_finalize_kernel(
         for (int u = 0; u < 8; ++u) {
           const int k = k0 + u * RPARTS, kk = min(k, RC * world - 1);
           const int r = kk / RC, kl = kk - r * RC;
-          const float x = part_all[(size_t)r * 2 * RH + (size_t)kl * H + c], y = part_all[(size_t)r * 2 * RH + RH + (size_t)kl * H + c];
+          const float x = part_all[(size_t)r * RS + (size_t)kl * H + c], y = part_all[(size_t)r * RS + RH + (size_t)kl * H + c];
           av[u] = k < RC * world ? x : 0.f; bv[u] = k < RC * world ? y : 0.f;
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1282,9 +1289,10 @@ int launch_bn_bwd_reduce(const float* g, const uint64_t* bits, const float* z, c
 int launch_bn_bwd_finalize(const float* part, int RC, int world, int rank, int B, int H,
                            const float* gamma, const float* rstd, float* coef, float* dgamma,
                            float* dbeta, hipStream_t s, const float* part_amax, int n_amax, float* dz_scale,
-                           int eval_mode) {
+                           int eval_mode, int64_t rstride, int amax_world) {
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((H + RCOLS - 1) / RCOLS + (dz_scale ? 1 : 0)), dim3(NTHR), 0, s, part,
-                     RC, world, rank, B, H, gamma, rstd, coef, dgamma, dbeta, part_amax, n_amax, dz_scale, eval_mode);
+                     RC, world, rank, B, H, gamma, rstd, coef, dgamma, dbeta, part_amax, n_amax, dz_scale, eval_mode,
+                     (long long)rstride, amax_world);
   PL_CHECK_LAUNCH("bn_bwd_finalize");
   return PL_OK;
 }

@@ -185,7 +185,7 @@ int launch_bn_bwd_reduce(const float* g, const uint64_t* bits, const float* z, c
 int launch_bn_bwd_finalize(const float* part, int RC, int world, int rank, int B, int H,
                            const float* gamma, const float* rstd, float* coef, float* dgamma,
                            float* dbeta, hipStream_t s, const float* part_amax = nullptr, int n_amax = 0,
-                           float* dz_scale = nullptr, int eval_mode = 0);
+                           float* dz_scale = nullptr, int eval_mode = 0, int64_t rstride = 0, int amax_world = 1);
 // eval-mode BatchNorm for the saved-state forward: mean := running mean, rstd := rsqrt(running var + eps), scale, shift
 int launch_bn_eval_stats(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int H,
                          float* mean, float* rstd, float* scale, float* shift, hipStream_t s);

@@ -70,12 +70,14 @@ def test_cut_backward_is_bitwise_the_one_call_backward(cuts):
 
 
 @pytest.mark.parametrize("rank", [0, 1])
-@pytest.mark.parametrize("dtype", ["fp32", "bf16x6"])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x6", "f16x3", "bf16"])
 def test_sync_bn_with_a_mirror_rank_is_the_doubled_batch(rank, dtype):
     """PLSync in one process: a fake 2-rank world whose other rank holds the same rows (the gather
     copies this rank's slab into the other).  Global-batch statistics of [x; x] -- the forward
     must be bitwise what one process computes on the concatenated batch (B % 128 == 0), running
-    statistics included; gradients agree to round-off once the mirror's share is added."""
+    statistics included; gradients agree to round-off once the mirror's share is added.
+    f16x3 / bf16 (round 3): the operand-planes kernels under SyncBN -- every rank's {max|dy|, max|zhat|} travel in the
+    gathered slab, so the range scale of the fp16 dz planes is the one the doubled batch computes."""
     import __graft_entry__ as ge
     pkg = ge.build()
     B = 256
