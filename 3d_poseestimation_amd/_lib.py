@@ -103,6 +103,7 @@ SIGNATURES = {
     "pl_weight_plane_scale": (_c.c_float, []),
     "pl_wplanes_refresh": (_c.c_int, [_D, _P]),
     "pl_flip_pose": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P]),
+    "pl_counter_add": (_c.c_int, [_P, _c.c_int64, _P]),
     "pl_flip_pose_ex": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_float, _c.c_float, _P]),
     "pl_flip_w_nhwc": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P]),
     "pl_softargmax3d_nhwc_fwd": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P, _P, _P]),
@@ -148,6 +149,7 @@ SIGNATURES = {
     "pl_gather_rows2": (_c.c_int, [_P, _c.c_int64, _P, _c.c_int64, _P, _c.c_int64, _c.c_int64, _P, _P, _P]),
     "pl_flip_tta_pack": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P]),
     "pl_flip_tta_merge": (_c.c_int, [_P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _P]),
+    "pl_softargmax_dl_scale": (_c.c_int, [_P, _c.c_int64, _c.c_int, _P, _P]),
     "pl_softargmax_fwd": (_c.c_int, [_P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _P, _P, _P]),
     "pl_softargmax_bwd": (_c.c_int, [_P, _P, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int, _c.c_int,
                                      _P, _P]),

@@ -43,6 +43,55 @@ def fold_bn(bn):
     return scale.contiguous(), (bn.bias - bn.running_mean * scale).contiguous()
 
 
+def _pgrad(param, make):
+    """The gradient of `param` from an autograd node's backward.  make(out) computes it: into `out` (a contiguous tensor of
+    the parameter's shape) when given, else into a fresh tensor it returns.
+    A parameter managed by arena.ModuleArena (`_pl_grad`: its view of the flat gradient arena) gets its gradient written
+    straight into the arena -- the first backward of a step overwrites and attaches the view as .grad, a later one in the
+    same step (a second forward pass: the phase5 Flip branch) accumulates -- and autograd is handed None; any other
+    parameter's gradient goes to autograd as usual."""
+    view = getattr(param, "_pl_grad", None)
+    if view is None:
+        return make(None)
+    if param.grad is None:
+        make(view)
+        param.grad = view
+    else:
+        param.grad.add_(make(None).reshape(param.shape))
+    return None
+
+
+def _pgrad2(pa, pb, C, dev, run):
+    """_pgrad for two parameters whose gradients ONE kernel writes (BatchNorm's dgamma, dbeta): run(out_a, out_b)."""
+    va, vb = getattr(pa, "_pl_grad", None), getattr(pb, "_pl_grad", None)
+    if va is not None and vb is not None and pa.grad is None and pb.grad is None:
+        run(va, vb)
+        pa.grad, pb.grad = va, vb
+        return None, None
+    a, b = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    run(a, b)
+    if va is None or vb is None:
+        return a, b
+    for p, v, t in ((pa, va, a), (pb, vb, b)):
+        if p.grad is None:
+            v.copy_(t)
+            p.grad = v
+        else:
+            p.grad.add_(t)
+    return None, None
+
+
+def _oihw_from_ohwi(dw_ohwi, out):
+    """[O][KH][KW][I] -> the parameter's [O][I][KH][KW] layout (pl_nhwc_to_nchw: rows O, pixels KH*KW, channels I)."""
+    O, KH, KW, I = dw_ohwi.shape
+    if out is None:
+        out = torch.empty(O, I, KH, KW, device=dw_ohwi.device)
+    with _lib.on_device(dw_ohwi.device):
+        rc = _lib.lib().pl_nhwc_to_nchw(dw_ohwi.data_ptr(), O, KH * KW, I, out.data_ptr(), _lib.current_stream_ptr())
+    _lib.check(rc, "pl_nhwc_to_nchw")
+    return out
+
+
 def _opt(t, name, n):
     if t is None:
         return None
@@ -238,7 +287,7 @@ class _BNReLUFn(torch.autograd.Function):
                                    _lib.current_stream_ptr())
         _lib.check(rc, "pl_bn_train_fwd")
         ctx.save_for_backward(z2, bits, mean, rstd, gamma)
-        ctx.shape = shape
+        ctx.shape, ctx.gparam, ctx.bparam = shape, gamma, beta
         return y.reshape(shape)
 
     @staticmethod
@@ -247,13 +296,16 @@ class _BNReLUFn(torch.autograd.Function):
         rows, C = z2.shape
         dy2 = dy.contiguous().reshape(rows, C)
         dev, L = z2.device, _lib.lib()
-        dz, dgamma, dbeta = torch.empty_like(z2), torch.empty(C, device=dev), torch.empty(C, device=dev)
+        dz = torch.empty_like(z2)
         scratch = torch.empty(L.pl_bn_train_scratch_bytes(rows, C), dtype=torch.uint8, device=dev)
-        with _lib.on_device(dev):
-            rc = L.pl_bn_train_bwd(dy2.data_ptr(), bits.data_ptr(), z2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                   gamma.data_ptr(), rows, C, dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                   scratch.data_ptr(), _lib.current_stream_ptr())
-        _lib.check(rc, "pl_bn_train_bwd")
+
+        def run(dgamma, dbeta):
+            with _lib.on_device(dev):
+                rc = L.pl_bn_train_bwd(dy2.data_ptr(), bits.data_ptr(), z2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                       gamma.data_ptr(), rows, C, dz.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                                       scratch.data_ptr(), _lib.current_stream_ptr())
+            _lib.check(rc, "pl_bn_train_bwd")
+        dgamma, dbeta = _pgrad2(ctx.gparam, ctx.bparam, C, dev, run)
         return dz.reshape(ctx.shape), dgamma, dbeta, None, None, None, None, None, None
 
 
@@ -490,11 +542,12 @@ def _stat_buffer(rows, cols, dev):
     return torch.empty(2, _lib.lib().pl_gemm_stat_groups(rows), cols, device=dev)
 
 
-def _gemm_planes_raw(layout, a, a_rows_cols, b, b_rows_cols, M, N, K, out_scale, dyn_inv=None, mode=_lib.PL_F16X3, stat=None):
-    """C [M][N] fp32 from two carriers (planes of row-major matrices a_rows_cols / b_rows_cols)."""
+def _gemm_planes_raw(layout, a, a_rows_cols, b, b_rows_cols, M, N, K, out_scale, dyn_inv=None, mode=_lib.PL_F16X3, stat=None,
+                     out=None):
+    """C [M][N] fp32 from two carriers (planes of row-major matrices a_rows_cols / b_rows_cols); out: where to put it."""
     L = _lib.lib()
     dev = a.device
-    C = torch.empty(M, N, device=dev)
+    C = torch.empty(M, N, device=dev) if out is None else out
     splits = L.pl_gemm_planes_splits(M, N, K)
     slabs = torch.empty(splits * M * N, device=dev) if splits > 1 else None
     with _lib.on_device(dev):
@@ -518,17 +571,18 @@ class _Conv1x1PlanesFn(torch.autograd.Function):
     backward takes dz as a carrier (written by the BatchNorm behind this convolution, see PlaneLink)."""
 
     @staticmethod
-    def forward(ctx, xp, w, link):
+    def forward(ctx, xp, wparam, link):
         rows, cin = xp.shape
-        cout = w.shape[0]
+        cout = wparam.shape[0]
+        w = wparam.float().reshape(cout, cin)
         wp = _planes_of(w, WEIGHT_PLANE_SCALE, link.mode)
         # the BatchNorm behind this convolution reads the epilogue's statistics (no pass over z) -- unless the GEMM is split over K
         stat = (_stat_buffer(rows, cout, xp.device) if _lib.lib().pl_gemm_planes_splits(rows, cout, cin) == 1
                 else torch.empty(0, device=xp.device))
         z = _gemm_planes_raw(0, xp, (rows, cin), wp, (cout, cin), rows, cout, cin,
                              1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), None, link.mode, stat if stat.numel() else None)
-        ctx.save_for_backward(xp, w)
-        ctx.link = link
+        ctx.save_for_backward(xp)
+        ctx.link, ctx.wparam = link, wparam
         ctx.mark_non_differentiable(stat)
         ctx.set_materialize_grads(False)       # (no zero tensor the size of `stat` per backward)
         return z, stat
@@ -537,9 +591,11 @@ class _Conv1x1PlanesFn(torch.autograd.Function):
     def backward(ctx, dzp, _gstat):
         if dzp is None:
             return None, None, None
-        xp, w = ctx.saved_tensors
+        (xp,) = ctx.saved_tensors
+        wparam = ctx.wparam
         rows, cin = xp.shape
-        cout = w.shape[0]
+        cout = wparam.shape[0]
+        w = wparam.detach().float().reshape(cout, cin)
         dzp = dzp.contiguous()
         inv, mode = ctx.link.dz_scale[1:], ctx.link.mode   # 1 / S of the dz planes (device scalar; fp16 planes only)
         dx = dw = None
@@ -547,7 +603,11 @@ class _Conv1x1PlanesFn(torch.autograd.Function):
             wtp = _planes_of(w.t(), WEIGHT_PLANE_SCALE, mode)  # [Cin][Cout]: the data gradient is NT on W^T
             dx = _gemm_planes_raw(0, dzp, (rows, cout), wtp, (cin, cout), rows, cin, cout, 1.0 / WEIGHT_PLANE_SCALE, inv, mode)
         if ctx.needs_input_grad[1]:
-            dw = _gemm_planes_raw(2, dzp, (rows, cout), xp, (rows, cin), cout, cin, rows, 1.0 / ACT_PLANE_SCALE, inv, mode)
+            def make(out):
+                o2 = out.reshape(cout, cin) if out is not None else None
+                r = _gemm_planes_raw(2, dzp, (rows, cout), xp, (rows, cin), cout, cin, rows, 1.0 / ACT_PLANE_SCALE, inv, mode, out=o2)
+                return r.reshape(wparam.shape)
+            dw = _pgrad(wparam, make)
         return dx, dw, None
 
 
@@ -555,7 +615,7 @@ def conv1x1_planes(xp, weight_oihw, link):
     """xp: carrier [B, H, W, Cin] of the input's planes; weight: the nn.Conv2d parameter [Cout][Cin][1][1]."""
     shape = xp.shape
     cout, cin = weight_oihw.shape[0], weight_oihw.shape[1]
-    z, stat = _Conv1x1PlanesFn.apply(xp.reshape(-1, cin), weight_oihw.float().reshape(cout, cin), link)
+    z, stat = _Conv1x1PlanesFn.apply(xp.reshape(-1, cin), weight_oihw, link)
     link.stat = stat if stat.numel() else None
     return z.reshape(*shape[:-1], cout)
 
@@ -591,7 +651,7 @@ class _BNPlanesFn(torch.autograd.Function):
                                       mode, gstat.data_ptr() if gstat is not None else None, None, _lib.current_stream_ptr())
         _lib.check(rc, "pl_bn_train_fwd_ex")
         ctx.save_for_backward(z2, bits, mean, rstd, gamma)
-        ctx.shape, ctx.link = shape, link
+        ctx.shape, ctx.link, ctx.gparam, ctx.bparam = shape, link, gamma, beta
         return y.reshape(shape)
 
     @staticmethod
@@ -600,19 +660,22 @@ class _BNPlanesFn(torch.autograd.Function):
         rows, C = z2.shape
         dy2 = dy.contiguous().reshape(rows, C)
         dev, L = z2.device, _lib.lib()
-        dz, dgamma, dbeta = torch.empty_like(z2), torch.empty(C, device=dev), torch.empty(C, device=dev)
+        dz = torch.empty_like(z2)
         scratch = torch.empty(L.pl_bn_train_scratch_bytes(rows, C), dtype=torch.uint8, device=dev)
         link = ctx.link
         if link is not None:
             link.dz_scale = torch.empty(2, device=dev)
-        with _lib.on_device(dev):
-            rc = L.pl_bn_train_bwd_ex(dy2.data_ptr(), bits.data_ptr(), z2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                      gamma.data_ptr(), rows, C, None if link is not None else dz.data_ptr(),
-                                      dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(),
-                                      dz.data_ptr() if link is not None else None,
-                                      link.mode if link is not None else _lib.PL_F16X3,
-                                      link.dz_scale.data_ptr() if link is not None else None, _lib.current_stream_ptr())
-        _lib.check(rc, "pl_bn_train_bwd_ex")
+
+        def run(dgamma, dbeta):
+            with _lib.on_device(dev):
+                rc = L.pl_bn_train_bwd_ex(dy2.data_ptr(), bits.data_ptr(), z2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                          gamma.data_ptr(), rows, C, None if link is not None else dz.data_ptr(),
+                                          dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(),
+                                          dz.data_ptr() if link is not None else None,
+                                          link.mode if link is not None else _lib.PL_F16X3,
+                                          link.dz_scale.data_ptr() if link is not None else None, _lib.current_stream_ptr())
+            _lib.check(rc, "pl_bn_train_bwd_ex")
+        dgamma, dbeta = _pgrad2(ctx.gparam, ctx.bparam, C, dev, run)
         return dz.reshape(ctx.shape), dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
@@ -730,7 +793,8 @@ class _ConvKxKPlanesFn(torch.autograd.Function):
     pixels with the gathered x."""
 
     @staticmethod
-    def forward(ctx, xp, w, stride, pad, link):
+    def forward(ctx, xp, wparam, stride, pad, link):
+        w = wparam.float().permute(0, 2, 3, 1)         # the OHWI kernel as a VIEW of the [Cout][Cin][KH][KW] parameter
         wp = _planes_of(w, WEIGHT_PLANE_SCALE, link.mode)
         B, H, W, _ = xp.shape
         cout, kh, kw, _ = w.shape
@@ -738,8 +802,8 @@ class _ConvKxKPlanesFn(torch.autograd.Function):
         stat = _stat_buffer(rows, cout, xp.device)
         z = _conv_planes_fwd(xp, xp.shape, wp, w.shape, stride, pad, 1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), None, link.mode,
                              stat)
-        ctx.save_for_backward(xp, w)
-        ctx.geom, ctx.link = (stride, pad), link
+        ctx.save_for_backward(xp)
+        ctx.geom, ctx.link, ctx.wparam = (stride, pad), link, wparam
         ctx.mark_non_differentiable(stat)
         ctx.set_materialize_grads(False)
         return z, stat
@@ -748,7 +812,9 @@ class _ConvKxKPlanesFn(torch.autograd.Function):
     def backward(ctx, dzp, _gstat):
         if dzp is None:
             return None, None, None, None, None
-        xp, w = ctx.saved_tensors
+        (xp,) = ctx.saved_tensors
+        wparam = ctx.wparam
+        w = wparam.detach().float().permute(0, 2, 3, 1)
         stride, pad = ctx.geom
         B, H, W, cin = xp.shape
         cout, kh, kw, _ = w.shape
@@ -805,6 +871,8 @@ class _ConvKxKPlanesFn(torch.autograd.Function):
                                               inv.data_ptr(), slabs.data_ptr() if slabs is not None else None,
                                               _lib.current_stream_ptr())
             _lib.check(rc, "pl_conv2d_planes_wgrad")
+            dw_ohwi = dw
+            dw = _pgrad(wparam, lambda out: _oihw_from_ohwi(dw_ohwi, out))
         return dx, dw, None, None, None
 
 
@@ -812,7 +880,7 @@ def conv_planes(xp, weight_oihw, stride, pad, link):
     """xp: carrier [B, H, W, Cin]; weight: the nn.Conv2d parameter [Cout][Cin][KH][KW]."""
     # (the OHWI kernel as a VIEW of the parameter: its planes -- and the flipped / transposed ones of the backward -- are
     #  gathered by pl_planes_split_strided, no layout copy)
-    z, stat = _ConvKxKPlanesFn.apply(xp, weight_oihw.float().permute(0, 2, 3, 1), stride, pad, link)
+    z, stat = _ConvKxKPlanesFn.apply(xp, weight_oihw, stride, pad, link)
     link.stat = stat
     return z
 
@@ -845,13 +913,14 @@ class _DeconvPlanesFn(torch.autograd.Function):
                                                       1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), None,
                                                       _lib.current_stream_ptr())
         _lib.check(rc, "pl_deconv4x4s2_planes_fwd")
-        ctx.save_for_backward(xp, weight)
-        ctx.link = link
+        ctx.save_for_backward(xp)
+        ctx.link, ctx.wparam = link, weight
         return y
 
     @staticmethod
     def backward(ctx, dyp):
-        xp, weight = ctx.saved_tensors
+        (xp,) = ctx.saved_tensors
+        weight = ctx.wparam
         B, H, W, cin = xp.shape
         cout = weight.shape[1]
         dyp = dyp.contiguous()
@@ -871,7 +940,7 @@ class _DeconvPlanesFn(torch.autograd.Function):
                                               cout, cin, 4, 4, 2, 1, dwc.data_ptr(), 1.0 / ACT_PLANE_SCALE, inv.data_ptr(),
                                               slabs.data_ptr() if slabs is not None else None, _lib.current_stream_ptr())
             _lib.check(rc, "pl_conv2d_planes_wgrad")
-            dw = dwc.permute(0, 3, 1, 2).contiguous()
+            dw = _pgrad(weight, lambda out: _oihw_from_ohwi(dwc, out))      # [Cin][4][4][Cout] -> [Cin][Cout][4][4]
         return dx, dw, None
 
 
@@ -891,9 +960,10 @@ class _ConvBiasPlanesFn(torch.autograd.Function):
     planes."""
 
     @staticmethod
-    def forward(ctx, xp, w, bias, link):
+    def forward(ctx, xp, wparam, bias, link):
         rows, cin = xp.shape
-        cout = w.shape[0]
+        cout = wparam.shape[0]
+        w = wparam.float().reshape(cout, cin)
         mode = link.mode
         wp = _planes_of(w, WEIGHT_PLANE_SCALE, mode)
         L = _lib.lib()
@@ -903,15 +973,17 @@ class _ConvBiasPlanesFn(torch.autograd.Function):
                                       cout, cin, bias.data_ptr(), 1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), None, None, None,
                                       _lib.current_stream_ptr())
         _lib.check(rc, "pl_gemm_planes_raw")
-        ctx.save_for_backward(xp, w)
-        ctx.link = link
+        ctx.save_for_backward(xp)
+        ctx.link, ctx.wparam, ctx.bparam = link, wparam, bias
         return y
 
     @staticmethod
     def backward(ctx, dyp):
-        xp, w = ctx.saved_tensors
+        (xp,) = ctx.saved_tensors
+        wparam, bparam = ctx.wparam, ctx.bparam
         rows, cin = xp.shape
-        cout = w.shape[0]
+        cout = wparam.shape[0]
+        w = wparam.detach().float().reshape(cout, cin)
         dyp = dyp.contiguous()
         inv, mode = ctx.link.dz_scale[1:], ctx.link.mode
         dx = dw = db = None
@@ -919,22 +991,30 @@ class _ConvBiasPlanesFn(torch.autograd.Function):
             wtp = _planes_of(w.t(), WEIGHT_PLANE_SCALE, mode)
             dx = _gemm_planes_raw(0, dyp, (rows, cout), wtp, (cin, cout), rows, cin, cout, 1.0 / WEIGHT_PLANE_SCALE, inv, mode)
         if ctx.needs_input_grad[1]:
-            dw = _gemm_planes_raw(2, dyp, (rows, cout), xp, (rows, cin), cout, cin, rows, 1.0 / ACT_PLANE_SCALE, inv, mode)
+            def make_w(out):
+                o2 = out.reshape(cout, cin) if out is not None else None
+                r = _gemm_planes_raw(2, dyp, (rows, cout), xp, (rows, cin), cout, cin, rows, 1.0 / ACT_PLANE_SCALE, inv, mode, out=o2)
+                return r.reshape(wparam.shape)
+            dw = _pgrad(wparam, make_w)
         if ctx.needs_input_grad[2]:
             L = _lib.lib()
-            db = torch.empty(cout, device=dyp.device)
-            scratch = torch.empty(L.pl_colsum_scratch_bytes(rows, cout), dtype=torch.uint8, device=dyp.device)
-            with _lib.on_device(dyp.device):
-                rc = L.pl_colsum_planes(dyp.data_ptr(), mode, rows, cout, inv.data_ptr(), db.data_ptr(), scratch.data_ptr(),
-                                        _lib.current_stream_ptr())
-            _lib.check(rc, "pl_colsum_planes")
+
+            def make_b(out):
+                b = torch.empty(cout, device=dyp.device) if out is None else out
+                scratch = torch.empty(L.pl_colsum_scratch_bytes(rows, cout), dtype=torch.uint8, device=dyp.device)
+                with _lib.on_device(dyp.device):
+                    rc = L.pl_colsum_planes(dyp.data_ptr(), mode, rows, cout, inv.data_ptr(), b.data_ptr(), scratch.data_ptr(),
+                                            _lib.current_stream_ptr())
+                _lib.check(rc, "pl_colsum_planes")
+                return b
+            db = _pgrad(bparam, make_b)
         return dx, dw, db, None
 
 
 def conv1x1_bias_planes(xp, weight_oihw, bias, link):
     shape = xp.shape
     cout, cin = weight_oihw.shape[0], weight_oihw.shape[1]
-    y = _ConvBiasPlanesFn.apply(xp.reshape(-1, cin), weight_oihw.float().reshape(cout, cin), bias.float(), link)
+    y = _ConvBiasPlanesFn.apply(xp.reshape(-1, cin), weight_oihw, bias, link)
     return y.reshape(*shape[:-1], cout)
 
 
@@ -1018,7 +1098,7 @@ class _BNJoinPlanesFn(torch.autograd.Function):
                                       _lib.current_stream_ptr())
         _lib.check(rc, "pl_bn_train_fwd_ex")
         ctx.save_for_backward(z2, bits, mean, rstd, gamma)
-        ctx.shape, ctx.link = shape, link
+        ctx.shape, ctx.link, ctx.gparam, ctx.bparam = shape, link, gamma, beta
         ctx.set_materialize_grads(False)
         return x.reshape(shape), xp.reshape(shape)
 
@@ -1034,26 +1114,29 @@ class _BNJoinPlanesFn(torch.autograd.Function):
         g2 = g.contiguous().reshape(rows, C)
         gp2 = gp.contiguous().reshape(rows, C) if gp is not None else None
         dx = torch.empty_like(g2)                    # masked sum: the identity's gradient and bn3's dy
-        dz, dgamma, dbeta = torch.empty_like(z2), torch.empty(C, device=dev), torch.empty(C, device=dev)
+        dz = torch.empty_like(z2)
         scratch = torch.empty(L.pl_bn_train_scratch_bytes(rows, C), dtype=torch.uint8, device=dev)
         link.dz_scale = torch.empty(2, device=dev)
-        with _lib.on_device(dev):
-            if C >= 256:
-                # one pass writes the masked sum and takes BatchNorm-backward's column sums of it (pl_bn_join_bwd)
-                rc = L.pl_bn_join_bwd(g2.data_ptr(), gp2.data_ptr() if gp2 is not None else None, bits.data_ptr(), z2.data_ptr(),
-                                      mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), rows, C, dx.data_ptr(), None,
-                                      dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(), dz.data_ptr(), link.mode,
-                                      link.dz_scale.data_ptr(), _lib.current_stream_ptr())
-                _lib.check(rc, "pl_bn_join_bwd")
-            else:
-                rc = L.pl_mask_add_by_bits(g2.data_ptr(), gp2.data_ptr() if gp2 is not None else None, bits.data_ptr(), rows, C,
-                                           dx.data_ptr(), _lib.current_stream_ptr())
-                _lib.check(rc, "pl_mask_add_by_bits")
-                # (dy = dx where the join's bitmap is set: masking the masked sum again changes nothing)
-                rc = L.pl_bn_train_bwd_ex(dx.data_ptr(), bits.data_ptr(), z2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                          gamma.data_ptr(), rows, C, None, dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(),
-                                          dz.data_ptr(), link.mode, link.dz_scale.data_ptr(), _lib.current_stream_ptr())
-                _lib.check(rc, "pl_bn_train_bwd_ex")
+
+        def run(dgamma, dbeta):
+            with _lib.on_device(dev):
+                if C >= 256:
+                    # one pass writes the masked sum and takes BatchNorm-backward's column sums of it (pl_bn_join_bwd)
+                    rc = L.pl_bn_join_bwd(g2.data_ptr(), gp2.data_ptr() if gp2 is not None else None, bits.data_ptr(), z2.data_ptr(),
+                                          mean.data_ptr(), rstd.data_ptr(), gamma.data_ptr(), rows, C, dx.data_ptr(), None,
+                                          dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(), dz.data_ptr(), link.mode,
+                                          link.dz_scale.data_ptr(), _lib.current_stream_ptr())
+                    _lib.check(rc, "pl_bn_join_bwd")
+                else:
+                    rc = L.pl_mask_add_by_bits(g2.data_ptr(), gp2.data_ptr() if gp2 is not None else None, bits.data_ptr(), rows, C,
+                                               dx.data_ptr(), _lib.current_stream_ptr())
+                    _lib.check(rc, "pl_mask_add_by_bits")
+                    # (dy = dx where the join's bitmap is set: masking the masked sum again changes nothing)
+                    rc = L.pl_bn_train_bwd_ex(dx.data_ptr(), bits.data_ptr(), z2.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                              gamma.data_ptr(), rows, C, None, dgamma.data_ptr(), dbeta.data_ptr(), scratch.data_ptr(),
+                                              dz.data_ptr(), link.mode, link.dz_scale.data_ptr(), _lib.current_stream_ptr())
+                    _lib.check(rc, "pl_bn_train_bwd_ex")
+        dgamma, dbeta = _pgrad2(ctx.gparam, ctx.bparam, C, dev, run)
         return dz.reshape(ctx.shape), dx.reshape(ctx.shape), dgamma, dbeta, None, None, None, None, None, None
 
 

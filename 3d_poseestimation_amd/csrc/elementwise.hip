@@ -1575,6 +1575,16 @@ extern "C" int pl_adamw_flat_planes(float* p, const float* g, float* m, float* v
   return adamw_launch(p, g, m, v, n, in, stream);
 }
 
+// *counter += delta, one thread: the step counter of an optimizer whose step is replayed from a hipGraph (pl_adamw_flat_dev
+// reads t = t_base + *t_dev; this ticks it behind the update)
+__global__ void counter_add_kernel(uint64_t* counter, int64_t delta) { counter[0] = (uint64_t)((int64_t)counter[0] + delta); }
+extern "C" int pl_counter_add(uint64_t* counter, int64_t delta, void* stream) {
+  if (!counter) PL_FAIL(PL_EINVAL, "pl_counter_add: null counter");
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, delta);
+  PL_CHECK_LAUNCH("counter_add");
+  return PL_OK;
+}
+
 extern "C" int pl_flip_pose(const float* in, float* out, int64_t B, int64_t joints, int64_t D, void* stream) {
   if (!in || !out || in == out) PL_FAIL(PL_EINVAL, "pl_flip_pose: null or aliased pointers");
   if (B <= 0 || joints != 17 || (D != 2 && D != 3)) PL_FAIL(PL_ESHAPE, "pl_flip_pose: expects (B, 17, 2|3)");

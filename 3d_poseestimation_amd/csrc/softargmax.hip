@@ -264,6 +264,45 @@ extern "C" int pl_softargmax3d_nhwc_fwd(const float* logits, int64_t B, int64_t 
   return PL_OK;
 }
 
+// {S, 1/S} for the fp16 planes of dlogits: S the power of two that maps the bound 2 max_(b,j) sum_c |g_c| >= max |dlogit|
+// into (2^13, 2^14] (softmax weights <= 1, index offsets < the map size); bound 0 / inf / nan -> 1.  One workgroup.
+__global__ __launch_bounds__(NTHR) void softargmax_dl_scale_kernel(const float* __restrict__ g, int64_t rows, int ncoord,
+                                                                   float* __restrict__ out) {
+  __shared__ float sm[2 * (NTHR / 64)];
+  float m = 0.f, bad = 0.f;                           // bad: a row sum that is inf / nan (fmaxf would drop a nan)
+  for (int64_t r = threadIdx.x; r < rows; r += NTHR) {
+    float a = 0.f;
+    for (int c = 0; c < ncoord; ++c) a += fabsf(g[r * ncoord + c]);
+    if (!(a < 3.0e38f)) bad = 1.f;
+    m = fmaxf(m, a);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); bad = fmaxf(bad, __shfl_xor(bad, o)); }
+  if ((threadIdx.x & 63) == 0) { sm[2 * (threadIdx.x >> 6)] = m; sm[2 * (threadIdx.x >> 6) + 1] = bad; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < NTHR / 64; ++w) { m = fmaxf(m, sm[2 * w]); bad = fmaxf(bad, sm[2 * w + 1]); }
+    if (bad > 0.f) m = 0.f;
+    const float bound = 2.0f * m;
+    float S = 1.0f, Si = 1.0f;
+    if (bound > 0.f && bound < 3.0e38f) {
+      int e = 0;
+      (void)frexpf(bound, &e);
+      e = min(max(14 - e, -100), 100);
+      S = ldexpf(1.0f, e); Si = ldexpf(1.0f, -e);
+    }
+    out[0] = S; out[1] = Si;
+  }
+}
+
+extern "C" int pl_softargmax_dl_scale(const float* gcoords, int64_t rows, int ncoord, float* scale2, void* stream) {
+  if (!gcoords || !scale2) PL_FAIL(PL_EINVAL, "pl_softargmax_dl_scale: null pointer");
+  if (rows <= 0 || ncoord <= 0 || ncoord > 3) PL_FAIL(PL_ESHAPE, "pl_softargmax_dl_scale: bad dims");
+  hipLaunchKernelGGL(softargmax_dl_scale_kernel, dim3(1), dim3(NTHR), 0, (hipStream_t)stream, gcoords, rows, ncoord, scale2);
+  PL_CHECK_LAUNCH("softargmax_dl_scale");
+  return PL_OK;
+}
+
 extern "C" int pl_softargmax3d_nhwc_bwd(const float* logits, const float* stats, const float* gcoords, int64_t B,
                                         int64_t J, int64_t H, int64_t W, float* dlogits, void* stream) {
   if (!dlogits) PL_FAIL(PL_EINVAL, "pl_softargmax3d_nhwc_bwd: null pointer");

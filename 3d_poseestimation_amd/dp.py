@@ -209,20 +209,23 @@ class SyncedOptimizer:
 
       * a FlatAdamW (lifter / projector): ONE sum all-reduce of the model's flat gradient arena, the 1/world average
         folded into the AdamW launch (grad_scale) -- GradSync, no overlap (two lifter calls per graph contribute first);
-      * any torch optimizer over a module with ordinary parameters (the conv models): the module's gradients live in
-        one FlatGrads buffer, zero_grad() zeroes it in place, step() all-reduces it once and steps.
+      * an arena.FlatAdam (the conv models): the same on the module's flat gradient arena;
+      * any torch optimizer over a module with ordinary parameters: the module's gradients live in one FlatGrads
+        buffer, zero_grad() zeroes it in place, step() all-reduces it once and steps.
     Without an initialised process group (or world 1) it is the optimizer itself."""
 
     def __init__(self, optimizer, module, group=None, bucket_bytes=None):
+        from .arena import FlatAdam
         from .optim import FlatAdamW
         self.optimizer, self.module, self.group = optimizer, module, group
         self.param_groups = optimizer.param_groups
         self._flat_adamw = isinstance(optimizer, FlatAdamW)
-        self._sync = GradSync(group, bucket_bytes, overlap=False) if self._flat_adamw else None
-        self._flat = None if self._flat_adamw else FlatGrads(module, group, bucket_bytes)
+        self._flat_adam = isinstance(optimizer, FlatAdam)
+        self._sync = GradSync(group, bucket_bytes, overlap=False) if (self._flat_adamw or self._flat_adam) else None
+        self._flat = None if (self._flat_adamw or self._flat_adam) else FlatGrads(module, group, bucket_bytes)
 
     def zero_grad(self, set_to_none=False):
-        if self._flat_adamw:
+        if self._flat_adamw or self._flat_adam:
             self.optimizer.zero_grad()
         else:
             if not self._flat.attached():                 # (someone set the grads to None: re-attach the views)
@@ -232,6 +235,10 @@ class SyncedOptimizer:
     def step(self):
         if self._flat_adamw:
             return self.optimizer.step(grad_scale=self._sync(self.module))
+        if self._flat_adam:
+            arena = self.optimizer.arena
+            arena.gather_grads()                          # (a gradient an op outside conv.py handed to autograd)
+            return self.optimizer.step(grad_scale=self._sync.reduce_flat(arena.grad))
         self._flat.all_reduce_mean()
         return self.optimizer.step()
 

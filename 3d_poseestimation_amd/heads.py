@@ -90,8 +90,10 @@ class _SoftArgmax3dNHWCFn(torch.autograd.Function):
         if link is not None:
             # the final convolution runs on the planes GEMM (conv.py): dlogits leave as a carrier of their planes, fp16 ones
             # scaled by a power of two from the bound |dlogit| <= 2 max_(b,j) sum_c |g_c| (softmax weights <= 1)
-            link.dz_scale = _pow2_scale_for_bound(2.0 * g.reshape(-1, 3).abs().sum(1).max())
+            link.dz_scale = torch.empty(2, dtype=torch.float32, device=x.device)
             with _lib.on_device(x.device):
+                _lib.check(_lib.lib().pl_softargmax_dl_scale(g.data_ptr(), g.numel() // 3, 3, link.dz_scale.data_ptr(),
+                                                             _lib.current_stream_ptr()), "pl_softargmax_dl_scale")
                 rc = _lib.lib().pl_softargmax3d_nhwc_bwd_ex(x.data_ptr(), stats.data_ptr(), g.data_ptr(), B, ctx.num_joints, H, W,
                                                             None, dl.data_ptr(), link.mode, link.dz_scale.data_ptr(),
                                                             _lib.current_stream_ptr())

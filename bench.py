@@ -403,7 +403,7 @@ def cycle_workload(pkg, a, rank, local, world):
     proj = pkg.LinearModel(51, 34, linear_size=64, p_dropout=0.5, compute_dtype="f16x3").to(dev).train()     # :96
     lift.manual_seed(1234 + rank); proj.manual_seed(4321 + rank)
     lr = 1e-4
-    opts = [torch.optim.Adam(m2.parameters(), lr=lr), torch.optim.Adam(m3.parameters(), lr=lr),               # :105-109
+    opts = [pkg.FlatAdam(m2, lr=lr), pkg.FlatAdam(m3, lr=lr),                                                 # :105-109: Adam x4
             pkg.FlatAdamW(lift, lr=lr, weight_decay=0.0), pkg.FlatAdamW(proj, lr=lr, weight_decay=0.0)]
     if world > 1:
         opts = [pkg.dp.SyncedOptimizer(o, m) for o, m in zip(opts, (m2, m3, lift, proj))]

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PL_VERSION 105 /* 0.1.5: + pl_flip_pose_ex, pl_flip_w_nhwc (phase5 Flip branch); 0.1.4: + pl_planes_split_strided; 0.1.3: + pl_bn_join_bwd (0.1.2: operand-plane outputs of the BatchNorm / join kernels, pl_gemm_planes_raw) */
+#define PL_VERSION 106 /* 0.1.6: + pl_counter_add; 0.1.5: + pl_flip_pose_ex, pl_flip_w_nhwc (phase5 Flip branch); 0.1.4: + pl_planes_split_strided; 0.1.3: + pl_bn_join_bwd (0.1.2: operand-plane outputs of the BatchNorm / join kernels, pl_gemm_planes_raw) */
 
 typedef enum PLStatus {
   PL_OK = 0,
@@ -367,6 +367,11 @@ size_t pl_mpjpe_scratch_bytes(int64_t B, int64_t joints);
 int pl_mpjpe_accum(const float* pred, const float* tgt, int64_t B, int64_t joints,
                    float* metric, void* scratch, void* stream);
 
+/* *counter += delta on the stream (one thread).  The optimizer of a step replayed from a hipGraph keeps its step count on
+ * the device: pl_adamw_flat_dev reads t = t_base + *t_dev, this call ticks it behind the update (arena.FlatAdam for the
+ * conv models: torch.optim.Adam(model.parameters(), lr) of phase4_joined/train.py:39, train_5 copy.py:105-109). */
+int pl_counter_add(uint64_t* counter, int64_t delta, void* stream);
+
 /* flip_pose  phase3_direct/my_HybrIK/utils.py:372-396 (used by train_1.py:89-92,128-134 when Flip):
  * out = horizontal flip of in, both [B][17][D], D = 2 (x -> 1-x) or 3 (x -> -x), left/right joints
  * [4,5,6,11,12,13] <-> [1,2,3,14,15,16] swapped.  Out of place. */
@@ -525,6 +530,9 @@ int pl_gemm_planes_raw(int layout, int mode, const void* A, int64_t a_plane, int
  * (batch, joint), then the expectation of the w / h / d index.  coords [BJ][ncoord] in (x, y, z)
  * order; stats [BJ][5] = {max, sum exp, Ex, Ey, Ez} is what the backward needs.
  * Backward: dlogits [BJ][D][H][W] from gcoords [BJ][ncoord]; re-reads logits, materialises nothing. */
+/* {S, 1/S} (device, two floats) for pl_softargmax3d_nhwc_bwd_ex's fp16 planes of dlogits: S = the power of two that maps
+ * the bound 2 max_rows sum_c |gcoords[row][c]| >= max |dlogit| into (2^13, 2^14]; a zero / non-finite bound gives 1. */
+int pl_softargmax_dl_scale(const float* gcoords, int64_t rows, int ncoord, float* scale2, void* stream);
 int pl_softargmax_fwd(const float* logits, int64_t BJ, int64_t D, int64_t H, int64_t W, int ncoord,
                       int centred, float* coords, float* stats, void* stream);
 int pl_softargmax_bwd(const float* logits, const float* stats, const float* gcoords, int64_t BJ,

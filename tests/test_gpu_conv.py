@@ -929,3 +929,99 @@ def test_softargmax_bwd_planes_and_colsum_planes_match_the_fp32_forms(pkg):
     assert rc == 0, L.pl_last_error()
     want = dl.reshape(rows, cols).double().sum(0)
     assert float((db.double() - want).abs().max()) <= 1e-5 * float(want.abs().max()) + bound * rows * 2.0 ** -21
+
+
+# ---------------------------------------------------------------------------- flat arenas + one-launch Adam for the conv models
+def _gpu_kernel_names(fn):
+    """Names of the GPU kernels one call of fn() launches (torch.profiler)."""
+    from torch.profiler import profile, ProfilerActivity
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        fn()
+        torch.cuda.synchronize()
+    return [e.name for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+
+
+def test_flat_adam_three_steps_of_model3d_vs_torch_adam(pkg):
+    """arena.FlatAdam (one pl_adamw_flat launch over the module's flat arenas; parameter gradients written by the library
+    straight into the gradient arena) against torch.optim.Adam(model.parameters(), lr) -- phase4_joined/train.py:39,87 -- on
+    the same model, same kernels for forward and backward: three steps, parameters within Adam's fp32 round-off (a
+    noise-level gradient element may land on the other side of zero: +-lr on that element, as with the lifter's AdamW)."""
+    import copy
+    torch.manual_seed(5)
+    m = pkg.Model_3D()
+    m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 81))
+    with torch.no_grad():
+        m.final_layer.weight.mul_(1e-2)
+    a, b = copy.deepcopy(m).to(DEV).train(), copy.deepcopy(m).to(DEV).train()
+    lr = 1e-3
+    oa, ob = torch.optim.Adam(a.parameters(), lr=lr), pkg.FlatAdam(b, lr=lr)
+    sd_keys = list(b.state_dict().keys())
+    assert sd_keys == list(a.state_dict().keys())               # the arena changes no key and no shape
+    frames = [pkg.synth.structured_frames(4, 82 + i, size=128).to(DEV) for i in range(3)]
+    target = torch.randn(4, 51, device=DEV) * 0.3
+    # An untrained network one Adam step (every weight moves by +-lr) away from its seed is chaotic: parameters 1e-7 apart
+    # give gradients 10 % apart on the next batch (measured).  So: the first step on each model's OWN backward (identical
+    # kernels, hence identical gradients -- this checks the direct-to-arena gradient writes), the next two on the SAME
+    # gradients for both optimizers (a's, copied into b's arena) -- this checks three steps of the update arithmetic.
+    for i in range(3):
+        la = lb = None
+        oa.zero_grad()
+        la = pkg.mse_loss(a(frames[i]), target)
+        la.backward()
+        ob.zero_grad()
+        if i == 0:
+            lb = pkg.mse_loss(b(frames[i]), target)
+            lb.backward()
+            assert float(la) == float(lb)
+            for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+                assert torch.equal(p.grad, q.grad), k
+        else:
+            for p, q in zip(a.parameters(), b.parameters()):
+                q._pl_grad.copy_(p.grad)
+                q.grad = q._pl_grad
+        oa.step()
+        ob.step()
+        for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+            d = float((p.detach() - q.detach()).abs().max())
+            assert d <= 1e-3 * lr, (i, k, d)                   # measured: 1.2e-4 lr after the first step
+    # every gradient sits in the arena (no copy at step time), the optimizer state has the stock Adam layout
+    arena = b._pl_arena
+    ob.zero_grad()
+    pkg.mse_loss(b(frames[0]), target).backward()
+    assert all(p.grad is not None and p.grad.data_ptr() == p._pl_grad.data_ptr() for p in arena.params
+               if p is not b.preact.conv1.weight)
+    st = ob.state_dict()["state"]
+    assert set(st[0]) == {"step", "exp_avg", "exp_avg_sq"} and float(st[0]["step"]) == 3.0
+    ref = torch.optim.Adam(b.parameters(), lr=lr)
+    ref.load_state_dict(ob.state_dict())                        # the stock optimizer can resume from it
+    # one training step launches no ATen optimizer / gradient-accumulation kernels any more
+    def step():
+        ob.zero_grad()
+        pkg.mse_loss(b(frames[0]), target).backward()
+        ob.step()
+    names = _gpu_kernel_names(step)
+    aten = [n for n in names if "at::native" in n or "multi_tensor" in n]
+    assert not any("multi_tensor" in n for n in aten), aten[:5]
+    assert len(aten) <= 30, (len(aten), sorted(set(aten))[:10])      # what is left: a few weight re-layouts (stem, transposed convs)
+    assert len(names) > 500
+
+
+def test_flat_adam_accumulates_a_second_backward_of_the_same_step(pkg):
+    """Two forward passes before one optimizer step (the phase5 Flip branch runs every network twice): the first backward of
+    a step overwrites the gradient arena, the second accumulates -- equal to autograd's own accumulation."""
+    import copy
+    torch.manual_seed(6)
+    m = pkg.ResNet("resnet50")
+    m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 91))
+    a, b = copy.deepcopy(m).to(DEV).train(), copy.deepcopy(m).to(DEV).train()
+    pkg.ModuleArena(b)
+    x1, x2 = (pkg.synth.structured_frames(4, 92 + i, size=128).to(DEV) for i in range(2))
+    for mod in (a, b):
+        for p in mod.parameters():
+            p.grad = None
+        (mod(x1).square().mean() + 0.5 * mod(x2).square().mean()).backward()
+    for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert p.grad is not None and q.grad is not None, k
+        den = float(p.grad.abs().max()) + 1e-30
+        assert float((p.grad - q.grad).abs().max()) <= 1e-5 * den, (k, float((p.grad - q.grad).abs().max()), den)

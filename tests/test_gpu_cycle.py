@@ -151,7 +151,9 @@ def test_cycle_step_at_config4_per_gpu_batch_properties(pkg, Flip):
     sd0 = [{k: v.clone() for k, v in m.state_dict().items()} for m in models]
 
     def fresh_opts():
-        return [torch.optim.Adam(m2.parameters(), lr=1e-4), torch.optim.Adam(m3.parameters(), lr=1e-4),
+        # (arena.FlatAdam: the conv models' gradients go straight into flat arenas, one Adam launch each; under Flip the
+        #  second backward of a step accumulates into them)
+        return [pkg.FlatAdam(m2, lr=1e-4), pkg.FlatAdam(m3, lr=1e-4),
                 pkg.FlatAdamW(lift, lr=1e-3, weight_decay=0.0), pkg.FlatAdamW(proj, lr=1e-3, weight_decay=0.0)]
 
     runs = []

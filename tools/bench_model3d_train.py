@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--B", type=int, default=32); ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--skip-eager", action="store_true")
     ap.add_argument("--graph", action="store_true", help="also time train.GraphedModuleStep (the step as one hipGraph)")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam for this library's model (round 2) instead of "
+                                                              "arena.FlatAdam (one launch over the flat arenas; same-box A/B)")
     a = ap.parse_args()
     m = pkg.Model_3D().train()
     m.load_state_dict(pkg.synth.seeded_state(m.state_dict(), 31))
@@ -34,12 +36,13 @@ def main():
     eager = copy.deepcopy(m).to("cuda")
     frames = pkg.synth.seeded_frames(a.B, 5).to("cuda")
     target = torch.randn(a.B, 51, device="cuda")
-    opt_o = torch.optim.Adam(ours.parameters(), lr=1e-3)
+    opt_o = torch.optim.Adam(ours.parameters(), lr=1e-3) if a.torch_adam else pkg.FlatAdam(ours, lr=1e-3)
+    print("optimizer of this library's model:", type(opt_o).__name__)
     opt_e = torch.optim.Adam(eager.parameters(), lr=1e-3)
 
     def step_ours():
         opt_o.zero_grad()
-        F.mse_loss(ours(frames), target).backward()
+        (F.mse_loss if a.torch_adam else pkg.mse_loss)(ours(frames), target).backward()
         opt_o.step()
 
     xn = frames.permute(0, 3, 1, 2).contiguous()
@@ -69,8 +72,9 @@ def main():
         for dt, label in (("f16x3", "fp32-grade, planes, hipGraph replay "), ("bf16p", "bf16 storage, planes, hipGraph replay")):
             gm = copy.deepcopy(m).to("cuda")
             gm.compute_dtype = gm.preact.compute_dtype = dt
-            gstep = pkg.GraphedModuleStep(gm, torch.optim.Adam(gm.parameters(), lr=1e-3, capturable=True), F.mse_loss,
-                                          frames, target)
+            gopt = (torch.optim.Adam(gm.parameters(), lr=1e-3, capturable=True) if a.torch_adam
+                    else pkg.FlatAdam(gm, lr=1e-3, capturable=True))
+            gstep = pkg.GraphedModuleStep(gm, gopt, F.mse_loss if a.torch_adam else pkg.mse_loss, frames, target)
             t = timed(lambda: gstep(frames, target), a.iters)
             print(f"B={a.B} this library ({label}): {t * 1e3:8.1f} ms/step = {a.B / t:7.1f} frames/s")
             del gstep, gm
