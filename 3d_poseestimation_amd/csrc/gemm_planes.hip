@@ -225,14 +225,19 @@ template <int ER> constexpr int stage_bytes() { return 4 * ER * 68 * 4; }
 template <int MODE> constexpr int persist_nst() { return 3; }
 constexpr int kPersistRows = 32;
 // LDS: the operand ring, and never less than the 4 x 17 KB the 32x32x16 loop's epilogue stages a whole block in
-template <int MODE, bool PERSIST = false>
+template <int MODE> constexpr int wide_ring_bytes() { return plp::WideCfg<plp::ModeCfg<MODE>::NPL>::LDS; }
+constexpr int kWidePersistRows = 16;              // 2 x 64 KB of pair-stages leave 32 KB: the staged epilogue in 16-row passes
+template <int MODE, bool PERSIST = false, bool WIDE = false>
 constexpr int lds_bytes() {
+  if (WIDE) return PERSIST ? wide_ring_bytes<MODE>() + stage_bytes<kWidePersistRows>()
+                           : (wide_ring_bytes<MODE>() > stage_bytes<32>() ? wide_ring_bytes<MODE>() : stage_bytes<32>());
   if (PERSIST) return ring_bytes<MODE, persist_nst<MODE>()>() + stage_bytes<kPersistRows>();
   return ring_bytes<MODE>() > 4 * 64 * 68 * 4 ? ring_bytes<MODE>() : 4 * 64 * 68 * 4;
 }
 static_assert(lds_bytes<plp::kF16x3, true>() <= 160 * 1024 && lds_bytes<plp::kBf16, true>() <= 160 * 1024, "LDS per CU");
+static_assert(lds_bytes<plp::kF16x3, true, true>() <= 160 * 1024 && lds_bytes<plp::kF16x3, false, true>() <= 160 * 1024, "LDS per CU");
 
-template <bool A_KS, bool B_KS, int MODE, bool S16, bool EDGE = false, int CONV = 0, bool PERSIST = false>
+template <bool A_KS, bool B_KS, int MODE, bool S16, bool EDGE = false, int CONV = 0, bool PERSIST = false, bool WIDE = false>
 __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block_id, const int nblocks, const int nwork, char* lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave & 3) >> 1, wn = wave & 1;
@@ -242,8 +247,9 @@ __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block
     // the wave's 64x64 block goes through ER rows x 68 floats of LDS in 64 / ER passes: the lane that owned accumulator
     // elements leaves with float4 rows (v[it] = row 4 it + (lane >> 4), columns 4 (lane & 15) ..)
     constexpr int NST = PERSIST ? persist_nst<MODE>() : 3;
-    constexpr int ER = PERSIST ? kPersistRows : 32;
-    float* ldsw = reinterpret_cast<float*>(lds + (PERSIST ? ring_bytes<MODE, NST>() : 0)) + (wave & 3) * ER * 68;
+    constexpr int ER = PERSIST ? (WIDE ? kWidePersistRows : kPersistRows) : 32;
+    constexpr int RING = WIDE ? wide_ring_bytes<MODE>() : ring_bytes<MODE, NST>();
+    float* ldsw = reinterpret_cast<float*>(lds + (PERSIST ? RING : 0)) + (wave & 3) * ER * 68;
     const int q = lane >> 4, c = lane & 15, lc = c * 4;
     auto epi = [&](plp::f32x4v (&acc)[plp::ModeCfg<MODE>::NACC][4][4], const int m0, const int n0, const int slice) {
       if (!PERSIST) __syncthreads();                     // every computing wave is done reading operand tiles (the staging
@@ -268,7 +274,8 @@ __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block
       float* C = k.e.C ? k.e.C + (k.e.split_k > 1 ? (size_t)slice * k.e.M * k.e.ldc : 0) : nullptr;
       staged_epilogue<EDGE>(k, C, v, m0, n0, wm, wn, lane);
     };
-    plp::planes_run16<A_KS, B_KS, MODE, EDGE, CONV, PERSIST, NST>(k.p, block_id, nblocks, nwork, lds, epi);
+    if constexpr (WIDE) plp::planes_run16w<A_KS, B_KS, MODE, EDGE, CONV, PERSIST>(k.p, block_id, nblocks, nwork, lds, epi);
+    else plp::planes_run16<A_KS, B_KS, MODE, EDGE, CONV, PERSIST, NST>(k.p, block_id, nblocks, nwork, lds, epi);
   } else {
     float* ldsw = reinterpret_cast<float*>(lds) + (wave & 3) * 64 * 68;
     int m0, n0, slice;
@@ -320,6 +327,14 @@ template <int MODE, bool EDGE, int CONV>
 __global__ __launch_bounds__(512) void planes_gemm_persistent_kernel(PlanesKern k, int nwork) {
   __shared__ __attribute__((aligned(16))) char lds[lds_bytes<MODE, true>()];
   planes_body<false, false, MODE, true, EDGE, CONV, true>(k, blockIdx.x, gridDim.x, nwork, lds);
+}
+
+// NT with the k-tiles staged in pairs (whole 128-byte lines of both k-contiguous operands: gemm_planes16.h, WIDE);
+// PERSIST: nwork items over gridDim.x workgroups, else one item per workgroup (nwork == gridDim.x)
+template <int MODE, bool EDGE, int CONV, bool PERSIST>
+__global__ __launch_bounds__(512) void planes_gemm_wide_kernel(PlanesKern k, int nwork) {
+  __shared__ __attribute__((aligned(16))) char lds[lds_bytes<MODE, PERSIST, true>()];
+  planes_body<false, false, MODE, true, EDGE, CONV, PERSIST, true>(k, blockIdx.x, gridDim.x, nwork, lds);
 }
 
 // backward pair of one layer in one launch: workgroups [0, n0) run dX = dz W (NN), the rest dW = dz^T a (TN, split-K
@@ -477,8 +492,26 @@ int launch_gemm_planes(GemmLayout layout, const PlanesGemmArgs& a, hipStream_t s
   // persistent form (round 3): NT problems with at least two work items per CU -- the conv path's 1x1 / 3x3 / transposed
   // convolutions over 16K .. 1M pixels.  POSELIFT_PERSIST=0: one workgroup per item, as round 2 (same-box A/B).
   static const int persist_env = [] { const char* e = getenv("POSELIFT_PERSIST"); return e ? atoi(e) : 1; }();
+  static const int wide_env = [] { const char* e = getenv("POSELIFT_WIDE"); return e ? atoi(e) : 1; }();   // =0: same-box A/B
   const int ncu = cu_count();
-  if (persist_env && mfma16_shape() && layout == kNT && (int)grid.x >= 2 * ncu && (a.e.conv_cin == 0 || layout == kNT)) {
+  const bool persist = persist_env && mfma16_shape() && layout == kNT && (int)grid.x >= 2 * ncu;
+  // pair-staged k-tiles: NT, every K slice a whole number of 64-k pairs, a gathered pair inside one filter tap -- and a long
+  // contraction: measured same-box (tools/bench_conv_gemm.py, bench.py) K = 1024 / 2048 take 4-6 % less time (the lifter's
+  // forward GEMM 33.2 -> 32.7 us in the step), K <= 512 0-3 % MORE (a pair is a coarser unit at an item boundary)
+  const bool wide = wide_env && mfma16_shape() && layout == kNT && splits_of(a.e) == 1 && a.e.K % 64 == 0 && a.e.K >= 1024 &&
+                    (a.e.conv_cin == 0 || a.e.conv_cin % 64 == 0);
+  if (wide) {
+    const int nwork = (int)grid.x;
+    const dim3 wg(persist ? ncu : nwork);
+    const bool edge = is_edge(a) || a.e.conv_cin;
+#define PL_WIDE(MODE, P)                                                                                                  \
+    if (a.e.conv_cin) hipLaunchKernelGGL((planes_gemm_wide_kernel<MODE, true, 1, P>), wg, block, 0, s, k, nwork);          \
+    else if (edge) hipLaunchKernelGGL((planes_gemm_wide_kernel<MODE, true, 0, P>), wg, block, 0, s, k, nwork);             \
+    else hipLaunchKernelGGL((planes_gemm_wide_kernel<MODE, false, 0, P>), wg, block, 0, s, k, nwork);
+    if (persist) { if (a.mode == plp::kF16x3) { PL_WIDE(plp::kF16x3, true) } else { PL_WIDE(plp::kBf16, true) } }
+    else { if (a.mode == plp::kF16x3) { PL_WIDE(plp::kF16x3, false) } else { PL_WIDE(plp::kBf16, false) } }
+#undef PL_WIDE
+  } else if (persist) {
     const dim3 pg(ncu);
     const int nwork = (int)grid.x;
     const bool edge = is_edge(a) || a.e.conv_cin;

@@ -407,4 +407,328 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
 #undef PLP16_ROWS
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// WIDE (round 3): the same loop with k-tiles staged in PAIRS, so that a k-contiguous operand is fetched in whole 128-byte
+// lines.  With one 32-k tile per stage a k-contiguous row contributes 64 bytes per tile: a DMA instruction covers 16 rows x
+// 64 B, i.e. 16 half lines, and every line crosses the L1 / texture-address path twice (once per tile).  The k-strided
+// operands never had that problem (256-byte rows) -- and they were the faster loops: DMA alone 16 us for the TN problem of
+// the lifter against 23.6 us for NT.  Here a stage holds TWO k-tiles:
+//   k-contiguous image [128 rows][128 B] per plane (16 KB): one DMA instruction = 8 rows x 128 B; the 16-byte chunk a lane
+//     FETCHES is XORed with (row >> 1) & 7, so that the 16 rows x 1 chunk column of a ds_read_b128 lane group fall on the 16
+//     slots of the 256-byte bank row; k-tile h of the pair = chunks 4h .. 4h+3;
+//   k-strided image: the pair's two [32 k][256 B] images back to back (unchanged).
+// Two pair-stages (2 x 64 KB for two fp16 planes).  The pair p+2 is issued right after the mid-step barrier of the odd
+// step 2p+1 (when the last fragment of pair p has left LDS) and has landed by the barrier of step 2p+3: two steps in
+// flight, as the three-stage ring gives a single tile.  Every K slice must be a whole number of PAIRS (K % 64 == 0 per
+// slice); CONV = 1 then needs Cin % 64 == 0 (a pair inside one filter tap).
+__device__ __forceinline__ int kc16w_swz(int row) { return (row >> 1) & 7; }
+
+template <bool KS>
+__device__ __forceinline__ uint32_t glds_lane_off16w(int rb, int lane, int ld, int left = 0x7fffffff) {
+  if (!KS) {   // 8 rows x 128 B per instruction
+    const int row = rb * 8 + (lane >> 3);
+    const int ch = (lane & 7) ^ kc16w_swz(row);
+    return (uint32_t)(min(row, left - 1) * ld * 2 + ch * 16);
+  }
+  const int krow = rb * 4 + (lane >> 4);               // 0 .. 63: both tiles of the pair
+  const int ch = (lane & 15) ^ ((((lane >> 4) & 3) << 2) | (rb & 3));
+  return (uint32_t)(krow * ld * 2 + min(ch, (left >> 3) - 1) * 16);
+}
+
+template <bool KS>
+struct FragAddr16W {
+  uint32_t b[KS ? 8 : 2];
+  __device__ __forceinline__ void init(int wq, int lane) {
+    const int r = lane & 15, q = lane >> 4;
+    if (!KS) {
+      const int row = wq * 64 + r;                       // (+ 16 t rows: (row >> 1) & 7 does not depend on t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) b[h] = (uint32_t)(row * 128 + (((q + 4 * h) ^ kc16w_swz(row)) << 4));
+    } else {
+      const int qq = r >> 2, pp = r & 3;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int row = 8 * q + 4 * u + qq;
+          const int ch = wq * 8 + t * 2 + (pp >> 1);
+          const int x = ((row & 3) << 2) | ((row >> 2) & 3);
+          b[t * 2 + u] = (uint32_t)(256 * row + 16 * (ch ^ x) + 8 * (pp & 1));
+        }
+    }
+  }
+};
+
+// fragment of 16-row tile t of the wave's block, k-tile h of the pair, from one plane's pair image `op`
+template <bool KS, int H>
+__device__ __forceinline__ s16x8 read_frag16w(const char* op, const FragAddr16W<KS>& fa, int t) {
+  if (!KS) return *reinterpret_cast<const s16x8*>(op + fa.b[H] + t * 2048);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(op + H * 8192 + fa.b[t * 2 + 0]));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(op + H * 8192 + fa.b[t * 2 + 1]));
+  return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+template <int NPL>
+struct WideCfg {
+  static constexpr int OPP = 128 * 64 * 2;      // one plane of one operand, a PAIR of k-tiles: 16 KB
+  static constexpr int STAGE = 2 * NPL * OPP;   // A planes then B planes
+  static constexpr int LDS = 2 * STAGE;
+  static constexpr int NDMA = 2 * NPL * 4;      // per loader wave and pair
+};
+
+template <bool A_KS, bool B_KS, int MODE, bool EDGE, int CONV, bool PERSIST, class Epi>
+__device__ __forceinline__ void planes_run16w(const PlanesArgs& p, const int block_id, const int nblocks, const int nwork,
+                                              char* __restrict__ lds, Epi&& epi) {
+  static_assert(MODE == kF16x3 || MODE == kBf16, "two fp16 planes or one bf16 plane");
+  static_assert(CONV == 0 || (CONV == 1 && !A_KS && !B_KS), "the gathered weight gradient keeps the one-tile stages");
+  constexpr int NPL = ModeCfg<MODE>::NPL, NACC = ModeCfg<MODE>::NACC;
+  using Cf = WideCfg<NPL>;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= 4;
+  const int lw = wave & 3;
+  const int wm = (wave & 3) >> 1, wn = wave & 1;
+
+  const int tiles_n = EDGE ? (p.N + 127) / 128 : p.N / 128;
+  const int splits = p.split_k > 1 ? p.split_k : 1;
+  const int ntiles = nwork / splits;
+  int item_lo, item_hi;
+  if (PERSIST) {
+    const int per = (nwork + nblocks - 1) / nblocks;
+    item_lo = min(block_id * per, nwork);
+    item_hi = min(item_lo + per, nwork);
+  } else {
+    item_lo = block_id;
+    if ((nwork & 7) == 0) item_lo = (block_id & 7) * (nwork >> 3) + (block_id >> 3);
+    item_hi = item_lo + 1;
+  }
+  if (item_lo >= item_hi) return;
+  const int per_slice = ((p.K / 64 + splits - 1) / splits) * 64;      // (host: every slice a whole number of pairs)
+  auto decode = [&](const int w, int& m0, int& n0, int& slice, int& kbeg) {
+    slice = w / ntiles;
+    const int t = w - slice * ntiles;
+    m0 = (t / tiles_n) * 128;
+    n0 = (t % tiles_n) * 128;
+    kbeg = 0;
+    int kend = p.K;
+    if (splits > 1) {
+      kbeg = min(slice * per_slice, p.K);
+      kend = min(kbeg + per_slice, p.K);
+    }
+    return (kend - kbeg) / 64;                         // PAIRS of k-tiles
+  };
+  auto barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if (loader) {
+    int npairs = 0;
+    if (splits == 1) npairs = (item_hi - item_lo) * (p.K / 64);
+    else for (int w = item_lo; w < item_hi; ++w) { int a_, b_, c_, d_; npairs += max(decode(w, a_, b_, c_, d_), 0); }
+    int it = item_lo, pp = 0, np = 0, m0 = 0, n0 = 0, slice = 0, kbeg = 0;
+    __amdgpu_buffer_rsrc_t ra[NPL], rb[NPL], rx[NPL];
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl)
+      rx[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(p.A + (size_t)pl * p.a_plane), 0, 0x7fffffe0, 0x00020000);
+    int oa[4], ob[4];
+    int cih0[4] = {0, 0, 0, 0}, ciw0[4] = {0, 0, 0, 0}, cbase[4] = {0, 0, 0, 0};
+    int cc0 = 0, ckh = 0, ckw = 0;
+    const int ga_step = A_KS ? 64 * p.lda * 2 : 128;
+    const int gb_step = B_KS ? 64 * p.ldb * 2 : 128;
+    auto setup = [&]() {
+      np = decode(it, m0, n0, slice, kbeg);
+      const __bf16* ta = A_KS ? p.A + (size_t)kbeg * p.lda + m0 : p.A + (size_t)m0 * p.lda + kbeg;
+      const __bf16* tb = B_KS ? p.B + (size_t)kbeg * p.ldb + n0 : p.B + (size_t)n0 * p.ldb + kbeg;
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl) {
+        ra[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(ta + (size_t)pl * p.a_plane), 0, 0x7fffffff, 0x00020000);
+        rb[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(tb + (size_t)pl * p.b_plane), 0, 0x7fffffff, 0x00020000);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        oa[j] = (int)glds_lane_off16w<A_KS>(lw + 4 * j, lane, p.lda, EDGE ? p.M - m0 : 0x7fffffff);
+        ob[j] = (int)glds_lane_off16w<B_KS>(lw + 4 * j, lane, p.ldb, EDGE ? p.N - n0 : 0x7fffffff);
+      }
+      if (CONV == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int row = (lw + 4 * j) * 8 + (lane >> 3);
+          const int m = min(m0 + row, p.M - 1);
+          const int ow = m % p.cv_wo, t2 = m / p.cv_wo;
+          const int oh = t2 % p.cv_ho, b = t2 / p.cv_ho;
+          cih0[j] = oh * p.cv_stride - p.cv_pad_h;
+          ciw0[j] = ow * p.cv_stride - p.cv_pad_w;
+          cbase[j] = ((b * p.cv_h + cih0[j]) * p.cv_w + ciw0[j]) * p.cv_cin * 2 + (((lane & 7) ^ kc16w_swz(row)) << 4);
+        }
+        const int ctap = kbeg / p.cv_cin;
+        cc0 = kbeg - ctap * p.cv_cin;
+        ckh = ctap / p.cv_kw; ckw = ctap - ckh * p.cv_kw;
+      }
+    };
+    auto issue = [&](const int stage_off) {
+      if (p.abl & 2) return;
+      const int sa = pp * ga_step, sb = pp * gb_step;
+      char* d = lds + stage_off + lw * 1024;
+      int va[4] = {oa[0], oa[1], oa[2], oa[3]};
+      if (CONV == 1) {                                   // pairs are issued in K order: the tap advances incrementally
+        const int toff = ((ckh * p.cv_w + ckw) * p.cv_cin + cc0) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = (unsigned)(cih0[j] + ckh) < (unsigned)p.cv_h && (unsigned)(ciw0[j] + ckw) < (unsigned)p.cv_w;
+          va[j] = ok ? cbase[j] + toff : kDmaOutOfRange;
+        }
+        cc0 += 64;
+        if (cc0 >= p.cv_cin) { cc0 = 0; if (++ckw == p.cv_kw) { ckw = 0; ++ckh; } }
+      }
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (CONV == 1) PLP_BLDS16(rx[pl], d + pl * Cf::OPP + j * 4096, va[j], 0);
+          else PLP_BLDS16(ra[pl], d + pl * Cf::OPP + j * 4096, va[j], sa);
+          PLP_BLDS16(rb[pl], d + (NPL + pl) * Cf::OPP + j * 4096, ob[j], sb);
+        }
+    };
+    auto open_item = [&]() {
+      for (; it < item_hi; ++it) {
+        setup();
+        if (np > 0) { pp = 0; return true; }
+      }
+      return false;
+    };
+    int sw = 0;
+    auto issue_next = [&]() {                         // called exactly `npairs` times
+      if (pp >= np) { ++it; if (!open_item()) return; }
+      issue(sw);
+      sw = Cf::STAGE - sw;
+      ++pp;
+    };
+    if (npairs <= 0 || !open_item()) return;
+    issue_next();
+    if (npairs > 1) { issue_next(); wait_vmcnt<Cf::NDMA>(); } else { wait_vmcnt<0>(); }
+    barrier();                                        // pair 0 has landed
+    int issued = npairs > 1 ? 2 : 1;
+    for (int g = 0; g < 2 * npairs; ++g) {
+      if (g & 1) {
+        wait_vmcnt<0>();                              // pair (g + 1) / 2 -- the only one in flight -- has landed
+        barrier();                                    // ... and the last fragment of pair (g - 1) / 2 has left LDS:
+        if (issued < npairs) { issue_next(); ++issued; }      // its stage takes pair (g + 3) / 2
+      } else {
+        barrier();
+      }
+    }
+    return;
+  }
+
+  FragAddr16W<A_KS> fra;
+  FragAddr16W<B_KS> frb;
+  fra.init(wm, lane);
+  frb.init(wn, lane);
+  s16x8 fa[4][NPL];
+  s16x8 fb[2][4][NPL];
+  f32x4v acc[NACC][4][4];
+
+#define PLW_READ_A(stage_off, H, t0, t1)                                                     \
+  do {                                                                                       \
+    const char* q_ = lds + (stage_off);                                                      \
+    _Pragma("unroll") for (int t2 = (t0); t2 < (t1); ++t2)                                   \
+    _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                       \
+      fa[t2][pl] = read_frag16w<A_KS, H>(q_ + pl * Cf::OPP, fra, t2);                        \
+  } while (0)
+#define PLW_READ_B(set, stage_off, H)                                                        \
+  do {                                                                                       \
+    const char* q_ = lds + (stage_off) + NPL * Cf::OPP;                                      \
+    _Pragma("unroll") for (int t2 = 0; t2 < 4; ++t2)                                         \
+    _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                       \
+      fb[set][t2][pl] = read_frag16w<B_KS, H>(q_ + pl * Cf::OPP, frb, t2);                   \
+  } while (0)
+#define PLW_MFS(set, rt, ct)                                                                           \
+  do {                                                                                                 \
+    if constexpr (MODE == kF16x3) {                                                                    \
+      acc[1][rt][ct] = mfma16x16<MODE>(fa[rt][0], fb[set][ct][1], acc[1][rt][ct]);                      \
+      acc[1][rt][ct] = mfma16x16<MODE>(fa[rt][1], fb[set][ct][0], acc[1][rt][ct]);                      \
+    }                                                                                                  \
+    acc[0][rt][ct] = mfma16x16<MODE>(fa[rt][0], fb[set][ct][0], acc[0][rt][ct]);                        \
+  } while (0)
+#define PLW_ROWS(set, r0, r1)                                                                \
+  do {                                                                                       \
+    if (p.abl & 4) break;                                                                    \
+    _Pragma("unroll") for (int rt = (r0); rt < (r1); ++rt)                                   \
+    _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) PLW_MFS(set, rt, ct);                   \
+  } while (0)
+
+  constexpr int RA = NPL * (A_KS ? 2 : 1), RB = NPL * (B_KS ? 2 : 1);
+  constexpr int NMF = 8 * ModeCfg<MODE>::NPROD;
+  int sc = 0, sn = Cf::STAGE;        // pair-stage of the k-tile being read, the other one
+  int nk = 0;
+  const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+  // step kt of parity P = kt & 1 = its half of the pair: the NEXT k-tile is half 1 of the same pair-stage (P = 0) or half 0 of
+  // the other one (P = 1)
+  auto step = [&](const int kt, auto par, auto steady) {
+    constexpr int P = decltype(par)::value;
+    constexpr bool STEADY = decltype(steady)::value;
+    const bool has_next = STEADY || kt + 1 < nk;
+    PLW_READ_A(sc, P, 2, 4);
+    PLW_ROWS(P, 0, 2);
+    if (STEADY) sched_half<2 * RA, 0, NMF>();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    barrier();
+    if (has_next) {
+      if constexpr (P == 0) { PLW_READ_A(sc, 1, 0, 2); PLW_READ_B(1, sc, 1); }
+      else { PLW_READ_A(sn, 0, 0, 2); PLW_READ_B(0, sn, 0); }
+    }
+    PLW_ROWS(P, 2, 4);
+    if (STEADY) sched_half<2 * RA + 4 * RB, 0, NMF>();
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (P == 1) { const int o = sc; sc = sn; sn = o; }
+  };
+
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  bool first = true;
+  int m0, n0, slice, kbeg;
+  nk = 2 * decode(item_lo, m0, n0, slice, kbeg);
+  for (int w = item_lo; w < item_hi; ++w) {
+    if (w > item_lo) {
+      if (splits > 1) {
+        nk = 2 * decode(w, m0, n0, slice, kbeg);
+      } else {
+        n0 += 128;
+        if (n0 >= tiles_n * 128) { n0 = 0; m0 += 128; }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NACC; ++c)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[c][a][b] = zero4;
+    if (nk > 0) {
+      if (first) { barrier(); first = false; }
+      PLW_READ_A(sc, 0, 0, 2);                 // (an item is a whole number of pairs: it starts on half 0)
+      PLW_READ_B(0, sc, 0);
+      int kt = 0;
+      for (; kt + 3 < nk; kt += 2) {
+        step(kt, P0{}, T_{});
+        step(kt + 1, P1{}, T_{});
+      }
+      for (; kt < nk; kt += 2) {
+        step(kt, P0{}, F_{});
+        if (kt + 1 < nk) step(kt + 1, P1{}, F_{});
+      }
+    }
+    epi(acc, m0, n0, slice);
+  }
+#undef PLW_READ_A
+#undef PLW_READ_B
+#undef PLW_MFS
+#undef PLW_ROWS
+}
+
 }  // namespace plp
