@@ -98,6 +98,11 @@ inline bool fused_reduce(const PLDesc* d, bool planes, int l, int L, bool eval_b
   if (!planes || !d->bn || eval_bn || off) return false;
   return l < L - 1 || (!top_off && skinny_supported(d->out_dim, d->hidden));
 }
+// hidden layers of a small local batch off the planes path: one fused launch per BatchNorm direction (elementwise.hip)
+inline bool bn_small_ok(const PLDesc* d, bool planes, int64_t B) {
+  static const bool off = [] { const char* e = getenv("POSELIFT_BN_SMALL"); return e && e[0] == '0'; }();   // =0: same-box A/B
+  return !off && d->bn && !planes && sync_world(d) == 1 && B >= 2 && B <= kBnSmallRows;
+}
 inline int arith_of(const PLDesc* d) { return d->dtype == PL_F16X3 ? (int)PL_BF16X6 : d->dtype; }
 
 struct ParamLayout {
@@ -258,6 +263,8 @@ BnrSlab bnr_slab(const PLDesc* d, const Ws& w, void* ws, int rc, int n_amax, boo
   b.amax0 = stat + sums;
   return b;
 }
+
+inline bool bn_small(const PLDesc* d, const Ws& w, int64_t B) { return bn_small_ok(d, w.planes, B); }
 
 struct Layer {
   const float *W, *b, *gamma, *beta;
@@ -534,7 +541,9 @@ static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, 
     const bool skinny = l == 0 && skinny_supported(ly.K, H);
     const int groups = skinny ? skinny_stat_groups((int)B) : w.G;
     float* stat = f32(ws, w.stat);
-    if (d->bn && !eval_bn) {
+    // small batches: statistics, finalize and apply in ONE launch straight from z (bn_small_fwd_kernel) -- no partials
+    const bool small = bn_small(d, w, B) && !eval_bn;
+    if (d->bn && !eval_bn && !small) {
       g.stat_sum = stat + (size_t)sync_rank(d) * 2 * groups * H;
       g.stat_m2 = g.stat_sum + (size_t)groups * H;
     }
@@ -555,7 +564,7 @@ static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, 
       PL_TRY(launch_bn_eval_stats(ly.gamma, ly.beta, ly.rm, ly.rv, d->bn_eps, H, f32(ws, w.mean[l]), f32(ws, w.rstd[l]),
                                   sc, sh, s));
       scale = sc; shift = sh;
-    } else if (d->bn) {
+    } else if (d->bn && !small) {
       float* sc = f32(ws, w.scale) + (size_t)l * H;
       float* sh = f32(ws, w.shift) + (size_t)l * H;
       PL_TRY(sync_gather(d, stat, (int64_t)2 * groups * H, s));
@@ -565,6 +574,13 @@ static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, 
       scale = sc; shift = sh;
     }
     const float* resid = (l >= 2 && (l % 2) == 0) ? f32(ws, w.act[l - 2]) : nullptr;
+    if (small) {
+      PL_TRY(launch_bn_small_fwd(g.C, ly.gamma, ly.beta, d->bn_eps, d->bn_momentum, ly.rm, ly.rv, ly.nbt, f32(ws, w.mean[l]),
+                                 f32(ws, w.rstd[l]), resid, f32(ws, w.act[l]), u64(ws, w.bits[l]), (int)B, H, d->p_dropout, seed,
+                                 step, l, inject_keep ? inject_keep + (size_t)l * inj_stride : nullptr, s, d->step_dev));
+      a_in = f32(ws, w.act[l]);
+      continue;
+    }
     PlaneOut po = {nullptr, nullptr, kActPlaneScale, nullptr, 0};
     if (w.planes && l + 1 < w.L) { po.h = u16(ws, w.actp[l]); po.l = po.h + BH; po.kind = w.pkind; }
     float* act = w.act_f32[l] ? f32(ws, w.act[l]) : nullptr;
@@ -659,7 +675,12 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
     float* dzs = (pl_layer && w.pkind == 2) ? f32(ws, w.dzscale) + 2 * l : nullptr;   // fp16 planes of dz are range-scaled
     PlaneOut dzo = {nullptr, nullptr, 1.0f, dzs, 0};
     if (pl_layer) { dzo.h = u16(ws, w.dzp); dzo.l = dzo.h + BH; dzo.kind = w.pkind; }
-    if (d->bn) {
+    const bool small = bn_small(d, w, B) && !eval_bn;
+    if (small) {
+      // pass 1, the coefficients, dz, the bias gradient and dgamma / dbeta of this layer in one launch (small batches)
+      PL_TRY(launch_bn_small_bwd(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), ly.gamma, kscale, Bi, H, DZ, ly.ggamma,
+                                 ly.gbeta, ly.gb, s));
+    } else if (d->bn) {
       // pass 1 (column sums of dy and dy*zhat): a streaming kernel of its own, or -- round 2 -- already done by the
       // LDS-staged epilogue of the planes GEMM that produced `gin` (round 1 tried it in the dword-per-lane epilogue of
       // the fp32-operand GEMM: +17 us per GEMM for the 7.5 us kernel it removed)
@@ -680,9 +701,11 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
       PL_TRY(launch_fill(ly.ggamma, H, 0.f, s));
       PL_TRY(launch_fill(ly.gbeta, H, 0.f, s));
     }
-    PL_TRY(launch_bn_bwd_dz(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), f32(ws, w.coef), kscale,
-                            d->bn, Bi, H, pl_layer ? nullptr : DZ, f32(ws, w.dbpart[l]), s, 0, &dzo, w.RC));
-    job(f32(ws, w.dbpart[l]), ly.gb, w.RC, H, 0, 0);
+    if (!small) {
+      PL_TRY(launch_bn_bwd_dz(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), f32(ws, w.coef), kscale,
+                              d->bn, Bi, H, pl_layer ? nullptr : DZ, f32(ws, w.dbpart[l]), s, 0, &dzo, w.RC));
+      job(f32(ws, w.dbpart[l]), ly.gb, w.RC, H, 0, 0);
+    }
     const float* a_in = l == 0 ? x : (w.planes ? nullptr : f32(ws, w.act[l - 1]));
     if (pl_layer) {
       // dX = dz W (NN) and dW = dz^T a (TN, split-K slabs) on the planes: one launch

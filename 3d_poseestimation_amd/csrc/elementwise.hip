@@ -349,6 +349,57 @@ __global__ __launch_bounds__(NTHR) void mask_by_bits_kernel(const float* __restr
 //  trip, interleaved on one box -- these passes are not short of requests in flight.)
 // RESID (is there a residual / join operand) is a template parameter for the same reason as bn_bwd_dz_rows' BN: its load leaves
 // with z's instead of after the wait for it.
+// one row of bn_apply: the lane's four columns c .. c+3 of row r (v = z, rv = the residual / join operand)
+template <bool RESID>
+__device__ __forceinline__ void bn_apply_row(
+    const int r, const int c, const bool active, const float4 v, const float4 rv, const float4 sc, const float4 sh, float* act,
+    uint64_t* __restrict__ bits, int H, int mode, bool norelu, uint32_t thr, float kscale, uint32_t k0,
+    uint32_t k1, uint32_t c3, uint32_t layer, const uint64_t* __restrict__ inject, const PlaneDst& pd, bool resid_first) {
+  const int lane = threadIdx.x & 63;
+  const int strip = c >> 8;
+  const int wpr = ((H + 255) >> 8) * 4;
+  const size_t off = (size_t)r * H + c;
+  float y[4] = {0.f, 0.f, 0.f, 0.f};
+  bool keep[4] = {true, true, true, true};
+  if (active) {
+    y[0] = fmaf(v.x, sc.x, sh.x); y[1] = fmaf(v.y, sc.y, sh.y);
+    y[2] = fmaf(v.z, sc.z, sh.z); y[3] = fmaf(v.w, sc.w, sh.w);
+    if (RESID && resid_first) { y[0] += rv.x; y[1] += rv.y; y[2] += rv.z; y[3] += rv.w; }
+    if (mode == 1) {
+      const uint64_t g = ((uint64_t)r * (uint64_t)H + (uint64_t)c) >> 2;
+      const Philox4 u = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), layer, c3, k0, k1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) keep[j] = u.v[j] >= thr;
+    } else if (mode == 2) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) keep[j] = (inject[(size_t)r * wpr + strip * 4 + j] >> lane) & 1ull;
+    } else if (mode == 3) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) keep[j] = false;
+    }
+  }
+  bool on[4];
+  float o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    on[j] = active && keep[j] && (norelu || y[j] > 0.f);
+    o[j] = on[j] ? y[j] * kscale : 0.f;
+  }
+  uint64_t word = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t b = __ballot(on[j]);
+    if (lane == j) word = b;
+  }
+  if (lane < 4) bits[(size_t)r * wpr + strip * 4 + lane] = word;
+  if (active) {
+    float4 out = make_float4(o[0], o[1], o[2], o[3]);
+    if (RESID && !resid_first) { out.x += rv.x; out.y += rv.y; out.z += rv.z; out.w += rv.w; }
+    if (act) st4_nt(act + off, out, pd.nt);
+    if (pd.kind) store_planes4(pd, off, out);
+  }
+}
+
 template <bool RESID>
 __device__ __forceinline__ void bn_apply_rows(
     const float* __restrict__ z, const float4 sc, const float4 sh, const float* resid, float* act,
@@ -358,54 +409,17 @@ __device__ __forceinline__ void bn_apply_rows(
   // resid_first: resid joins BEFORE the ReLU -- relu(bn(z) + resid), the Bottleneck's join (Resnet.py:90-91) -- instead of
   // after it (the lifter's block: x + relu(bn(z)))
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int strip = blockIdx.x;
-  const int c = strip * 256 + lane * 4;
+  const int c = blockIdx.x * 256 + lane * 4;
   const bool active = c < H;
-  const int wpr = ((H + 255) >> 8) * 4;
   for (int r = blockIdx.y * 4 + wave; r < B; r += gridDim.y * 4) {
     const size_t off = (size_t)r * H + c;
-    float y[4] = {0.f, 0.f, 0.f, 0.f};
-    bool keep[4] = {true, true, true, true};
-    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), rv = v;
     if (active) {
-      const float4 v = ld4(z + off);
+      v = ld4(z + off);
       if constexpr (RESID) rv = ld4(resid + off);
-      y[0] = fmaf(v.x, sc.x, sh.x); y[1] = fmaf(v.y, sc.y, sh.y);
-      y[2] = fmaf(v.z, sc.z, sh.z); y[3] = fmaf(v.w, sc.w, sh.w);
-      if (RESID && resid_first) { y[0] += rv.x; y[1] += rv.y; y[2] += rv.z; y[3] += rv.w; }
-      if (mode == 1) {
-        const uint64_t g = ((uint64_t)r * (uint64_t)H + (uint64_t)c) >> 2;
-        const Philox4 u = philox4x32_10((uint32_t)g, (uint32_t)(g >> 32), layer, c3, k0, k1);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) keep[j] = u.v[j] >= thr;
-      } else if (mode == 2) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) keep[j] = (inject[(size_t)r * wpr + strip * 4 + j] >> lane) & 1ull;
-      } else if (mode == 3) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) keep[j] = false;
-      }
     }
-    bool on[4];
-    float o[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      on[j] = active && keep[j] && (norelu || y[j] > 0.f);
-      o[j] = on[j] ? y[j] * kscale : 0.f;
-    }
-    uint64_t word = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint64_t b = __ballot(on[j]);
-      if (lane == j) word = b;
-    }
-    if (lane < 4) bits[(size_t)r * wpr + strip * 4 + lane] = word;
-    if (active) {
-      float4 out = make_float4(o[0], o[1], o[2], o[3]);
-      if (RESID && !resid_first) { out.x += rv.x; out.y += rv.y; out.z += rv.z; out.w += rv.w; }
-      if (act) st4_nt(act + off, out, pd.nt);
-      if (pd.kind) store_planes4(pd, off, out);
-    }
+    bn_apply_row<RESID>(r, c, active, v, rv, sc, sh, act, bits, H, mode, norelu, thr, kscale, k0, k1, c3, layer, inject, pd,
+                        resid_first);
   }
 }
 
@@ -431,6 +445,191 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(
   if (c < H && scale) { sc = ld4(scale + c % Hc); sh = ld4(shift + c % Hc); }
   if (resid) bn_apply_rows<true>(z, sc, sh, resid, act, bits, B, H, mode, norelu, thr, kscale, k0, k1, c3, layer, inject, pd, resid_first);
   else bn_apply_rows<false>(z, sc, sh, resid, act, bits, B, H, mode, norelu, thr, kscale, k0, k1, c3, layer, inject, pd, resid_first);
+}
+
+// -------------------------------------------------------------------------------------
+// Small batches (B <= kBnSmallRows: the reference's own batch of 64, train_1.py:194): the three launches of a hidden layer's
+// forward tail -- statistics finalize, apply -- and of its backward head -- pass 1, finalize, dz -- are launch latency and
+// nothing else at this size (5 us each for 256 KB of data).  Here ONE workgroup owns a 256-column strip for ALL rows:
+// statistics straight from z (no partials, no Chan merge: two passes over rows that sit in L2), then the apply loop itself.
+// -------------------------------------------------------------------------------------
+// every wave gets the strip total of a per-wave float4 partial (fixed order); NW waves
+template <int NW>
+__device__ __forceinline__ float4 allwaves4(float4 v, float4 (*sm)[64], int wave, int lane) {
+  sm[wave][lane] = v;
+  __syncthreads();
+  float4 t = sm[0][lane];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) {
+    const float4 u = sm[w][lane];
+    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+  }
+  __syncthreads();
+  return t;
+}
+
+// 512 threads: wave w holds rows w, w + 8, ... (RU of them: 8 for B <= 64, 16 for B <= 128) of the strip IN REGISTERS -- one
+// memory round trip for the whole kernel: statistics, the apply and the bitmap all work on the registers.
+// (First version: 256 threads streaming the rows twice for the statistics and a third time for the apply, four rows in
+//  flight: 0.313 ms per step at B = 64 against 0.304 for the three separate launches -- a dozen dependent round trips in
+//  four workgroups cost more than two launch boundaries.)
+constexpr int kSmallThreads = 512;
+template <int RU, bool RESID>
+__global__ __launch_bounds__(kSmallThreads) void bn_small_fwd_kernel(
+    const float* __restrict__ z, const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    float* running_mean, float* running_var, int64_t* batches, float* __restrict__ mean_out, float* __restrict__ rstd_out,
+    const float* resid, float* act, uint64_t* __restrict__ bits, int B, int H, int mode, uint32_t thr, float kscale,
+    uint32_t k0, uint32_t k1, uint32_t c3, uint32_t layer, const uint64_t* __restrict__ inject,
+    const uint64_t* __restrict__ step_dev, uint32_t seed_hi) {
+  __shared__ float4 sm[8][64];
+  if (step_dev) {
+    const uint64_t step = (((uint64_t)k1 << 32) | c3) + step_dev[0];
+    c3 = (uint32_t)step;
+    k1 = seed_hi ^ (uint32_t)(step >> 32);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const bool active = c < H;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 zv[RU], rv[RESID ? RU : 1];
+  float4 ga = zero, be = zero, rm = zero, rvar = zero;
+#pragma unroll
+  for (int u = 0; u < RU; ++u) {
+    const int r = wave + 8 * u;
+    const bool ok = active && r < B;
+    zv[u] = ok ? ld4(z + (size_t)r * H + c) : zero;
+    if constexpr (RESID) rv[u] = ok ? ld4(resid + (size_t)r * H + c) : zero;
+  }
+  if (active) {
+    ga = ld4(gamma + c); be = ld4(beta + c);
+    if (running_mean && wave == 0) { rm = ld4(running_mean + c); rvar = ld4(running_var + c); }
+  }
+  float4 s = zero;
+#pragma unroll
+  for (int u = 0; u < RU; ++u) { s.x += zv[u].x; s.y += zv[u].y; s.z += zv[u].z; s.w += zv[u].w; }
+  s = allwaves4<8>(s, sm, wave, lane);
+  const float Bt = (float)B;
+  const float4 mean = make_float4(s.x / Bt, s.y / Bt, s.z / Bt, s.w / Bt);
+  float4 q = zero;
+#pragma unroll
+  for (int u = 0; u < RU; ++u) {
+    if (wave + 8 * u >= B) continue;
+    const float dx = zv[u].x - mean.x, dy = zv[u].y - mean.y, dz = zv[u].z - mean.z, dw = zv[u].w - mean.w;
+    q.x = fmaf(dx, dx, q.x); q.y = fmaf(dy, dy, q.y); q.z = fmaf(dz, dz, q.z); q.w = fmaf(dw, dw, q.w);
+  }
+  q = allwaves4<8>(q, sm, wave, lane);
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = zero;
+  if (active) {
+    const float var[4] = {q.x / Bt, q.y / Bt, q.z / Bt, q.w / Bt};
+    const float mu[4] = {mean.x, mean.y, mean.z, mean.w};
+    const float g4[4] = {ga.x, ga.y, ga.z, ga.w}, b4[4] = {be.x, be.y, be.z, be.w};
+    float rs[4], scv[4], shv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      rs[j] = 1.0f / sqrtf(var[j] + eps);
+      scv[j] = g4[j] * rs[j];
+      shv[j] = bn_shift_of(b4[j], mu[j], scv[j]);
+    }
+    sc = make_float4(scv[0], scv[1], scv[2], scv[3]);
+    sh = make_float4(shv[0], shv[1], shv[2], shv[3]);
+    if (wave == 0) {
+      st4(mean_out + c, mean);
+      st4(rstd_out + c, make_float4(rs[0], rs[1], rs[2], rs[3]));
+      if (running_mean) {
+        bn_running_update(rm.x, rvar.x, mu[0], var[0], Bt, momentum);
+        bn_running_update(rm.y, rvar.y, mu[1], var[1], Bt, momentum);
+        bn_running_update(rm.z, rvar.z, mu[2], var[2], Bt, momentum);
+        bn_running_update(rm.w, rvar.w, mu[3], var[3], Bt, momentum);
+        st4(running_mean + c, rm); st4(running_var + c, rvar);
+      }
+    }
+  }
+  if (batches && blockIdx.x == 0 && threadIdx.x == 0) batches[0] += 1;
+  const bool norelu = (mode & 8) != 0;
+  const PlaneDst pd = {nullptr, nullptr, 1.f, 0, 0};
+#pragma unroll
+  for (int u = 0; u < RU; ++u) {
+    const int r = wave + 8 * u;
+    if (r >= B) break;                                 // (wave-uniform)
+    bn_apply_row<RESID>(r, c, active, zv[u], RESID ? rv[u] : zero, sc, sh, act, bits, H, mode & 7, norelu, thr, kscale, k0, k1,
+                        c3, layer, inject, pd, false);
+  }
+}
+
+// backward head of one hidden layer for a small batch: pass 1 (sum dy, sum dy zhat), the coefficients, dz = c0 (dy - c1 -
+// zhat c2), the bias gradient and dgamma / dbeta -- one workgroup per strip, the rows (masked dy and zhat) in registers
+template <int RU>
+__global__ __launch_bounds__(kSmallThreads) void bn_small_bwd_kernel(
+    const float* __restrict__ g, const uint64_t* __restrict__ bits, const float* __restrict__ z,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma, float kscale, int B, int H,
+    float* __restrict__ dz, float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dbias) {
+  __shared__ float4 sm[8][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int strip = blockIdx.x;
+  const int c = strip * 256 + lane * 4;
+  const bool active = c < H;
+  const int wpr = ((H + 255) >> 8) * 4;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 mu = zero, rs = zero, ga = zero;
+  float4 dv[RU], zh[RU];                                // masked, scaled dy and zhat of the wave's rows
+  {
+    float4 gv[RU], zv[RU];
+    ulonglong2 b01[RU], b23[RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const int r = min(wave + 8 * u, B - 1);
+      gv[u] = active ? ld4(g + (size_t)r * H + c) : zero;
+      zv[u] = active ? ld4(z + (size_t)r * H + c) : zero;
+      const uint64_t* bw = bits + (size_t)r * wpr + strip * 4;
+      b01[u] = *reinterpret_cast<const ulonglong2*>(bw);
+      b23[u] = *reinterpret_cast<const ulonglong2*>(bw + 2);
+    }
+    if (active) { mu = ld4(mean + c); rs = ld4(rstd + c); ga = ld4(gamma + c); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+      const bool ok = wave + 8 * u < B;
+      dv[u].x = (ok && ((b01[u].x >> lane) & 1ull)) ? gv[u].x * kscale : 0.f;
+      dv[u].y = (ok && ((b01[u].y >> lane) & 1ull)) ? gv[u].y * kscale : 0.f;
+      dv[u].z = (ok && ((b23[u].x >> lane) & 1ull)) ? gv[u].z * kscale : 0.f;
+      dv[u].w = (ok && ((b23[u].y >> lane) & 1ull)) ? gv[u].w * kscale : 0.f;
+      zh[u] = ok ? make_float4((zv[u].x - mu.x) * rs.x, (zv[u].y - mu.y) * rs.y, (zv[u].z - mu.z) * rs.z, (zv[u].w - mu.w) * rs.w) : zero;
+    }
+  }
+  float4 s1 = zero, s2 = zero, sz = zero;
+#pragma unroll
+  for (int u = 0; u < RU; ++u) {
+    s1.x += dv[u].x; s1.y += dv[u].y; s1.z += dv[u].z; s1.w += dv[u].w;
+    s2.x = fmaf(dv[u].x, zh[u].x, s2.x); s2.y = fmaf(dv[u].y, zh[u].y, s2.y);
+    s2.z = fmaf(dv[u].z, zh[u].z, s2.z); s2.w = fmaf(dv[u].w, zh[u].w, s2.w);
+    sz.x += zh[u].x; sz.y += zh[u].y; sz.z += zh[u].z; sz.w += zh[u].w;
+  }
+  s1 = allwaves4<8>(s1, sm, wave, lane);
+  s2 = allwaves4<8>(s2, sm, wave, lane);
+  sz = allwaves4<8>(sz, sm, wave, lane);
+  const float Bt = (float)B;
+  const float4 c0 = make_float4(ga.x * rs.x, ga.y * rs.y, ga.z * rs.z, ga.w * rs.w);
+  const float4 c1 = make_float4(s1.x / Bt, s1.y / Bt, s1.z / Bt, s1.w / Bt);
+  const float4 c2 = make_float4(s2.x / Bt, s2.y / Bt, s2.z / Bt, s2.w / Bt);
+  if (wave == 0 && active) {
+    st4(dgamma + c, s2); st4(dbeta + c, s1);
+    // bias gradient = sum_r dz_r = c0 (sum d - B c1 - c2 sum zhat): its true value is 0 (a bias in front of BatchNorm); formed
+    // from the three sums it carries a few ulps of them, where the sum of B rounded dz values carries sqrt(B) ulps of |dz|
+    float4 db;
+    db.x = c0.x * ((s1.x - Bt * c1.x) - c2.x * sz.x); db.y = c0.y * ((s1.y - Bt * c1.y) - c2.y * sz.y);
+    db.z = c0.z * ((s1.z - Bt * c1.z) - c2.z * sz.z); db.w = c0.w * ((s1.w - Bt * c1.w) - c2.w * sz.w);
+    st4(dbias + c, db);
+  }
+  if (!active) return;
+#pragma unroll
+  for (int u = 0; u < RU; ++u) {
+    const int r = wave + 8 * u;
+    if (r >= B) break;
+    float4 d;
+    d.x = c0.x * (dv[u].x - c1.x - zh[u].x * c2.x); d.y = c0.y * (dv[u].y - c1.y - zh[u].y * c2.y);
+    d.z = c0.z * (dv[u].z - c1.z - zh[u].z * c2.z); d.w = c0.w * (dv[u].w - c1.w - zh[u].w * c2.w);
+    st4(dz + (size_t)r * H + c, d);
+  }
 }
 
 // -------------------------------------------------------------------------------------
@@ -1259,6 +1458,42 @@ int launch_bn_apply(const float* z, const float* scale, const float* shift, cons
   hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NTHR), 0, s, z, scale, shift, resid, act, bits, B, H,
                      mode, thr, kscale, k0, k1, (uint32_t)step, (uint32_t)layer, inject_keep, H, po, step_dev, seed_hi);
   PL_CHECK_LAUNCH("bn_apply");
+  return PL_OK;
+}
+
+int launch_bn_small_fwd(const float* z, const float* gamma, const float* beta, float eps, float momentum, float* rm, float* rv,
+                        int64_t* nbt, float* mean, float* rstd, const float* resid, float* act, uint64_t* bits, int B, int H,
+                        float p, uint64_t seed, uint64_t step, int layer, const uint64_t* inject_keep, hipStream_t s,
+                        const uint64_t* step_dev) {
+  if (!z || !act || !bits || !mean || !rstd || B < 2 || (H & 3)) PL_FAIL(PL_EINVAL, "bn_small_fwd: bad arguments");
+  int mode = 0;
+  float kscale = 1.f;
+  if (p >= 1.f) mode = 3;
+  else if (p > 0.f) { mode = inject_keep ? 2 : 1; kscale = 1.0f / (1.0f - p); }
+  const uint32_t thr = dropout_threshold(p);
+  const uint32_t k0 = (uint32_t)seed, seed_hi = (uint32_t)(seed >> 32);
+  const uint32_t k1 = step_dev ? (uint32_t)(step >> 32) : seed_hi ^ (uint32_t)(step >> 32);
+  if (B > kBnSmallRows) PL_FAIL(PL_ESHAPE, "bn_small_fwd: B=%d", B);
+  const dim3 grid((H + 255) / 256), block(kSmallThreads);
+#define PL_SMALL_FWD(RU, RES)                                                                                               \
+  hipLaunchKernelGGL((bn_small_fwd_kernel<RU, RES>), grid, block, 0, s, z, gamma, beta, eps, momentum, rm, rv, nbt, mean, rstd,   \
+                     resid, act, bits, B, H, mode, thr, kscale, k0, k1, (uint32_t)step, (uint32_t)layer, inject_keep, step_dev, \
+                     seed_hi)
+  if (resid) PL_SMALL_FWD(8, true); else PL_SMALL_FWD(8, false);
+#undef PL_SMALL_FWD
+  PL_CHECK_LAUNCH("bn_small_fwd");
+  return PL_OK;
+}
+
+int launch_bn_small_bwd(const float* g, const uint64_t* bits, const float* z, const float* mean, const float* rstd,
+                        const float* gamma, float keep_scale, int B, int H, float* dz, float* dgamma, float* dbeta, float* dbias,
+                        hipStream_t s) {
+  if (!g || !bits || !z || !dz || !dgamma || !dbeta || !dbias || B < 1 || (H & 3)) PL_FAIL(PL_EINVAL, "bn_small_bwd: bad arguments");
+  if (B > kBnSmallRows) PL_FAIL(PL_ESHAPE, "bn_small_bwd: B=%d", B);
+  const dim3 grid((H + 255) / 256), block(kSmallThreads);
+  hipLaunchKernelGGL((bn_small_bwd_kernel<8>), grid, block, 0, s, g, bits, z, mean, rstd, gamma, keep_scale, B, H, dz, dgamma,
+                     dbeta, dbias);
+  PL_CHECK_LAUNCH("bn_small_bwd");
   return PL_OK;
 }
 

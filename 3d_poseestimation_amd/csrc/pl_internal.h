@@ -186,6 +186,18 @@ int launch_bn_bwd_finalize(const float* part, int RC, int world, int rank, int B
                            const float* gamma, const float* rstd, float* coef, float* dgamma,
                            float* dbeta, hipStream_t s, const float* part_amax = nullptr, int n_amax = 0,
                            float* dz_scale = nullptr, int eval_mode = 0, int64_t rstride = 0, int amax_world = 1);
+// Small batches (B <= kBnSmallRows, local statistics, fp32 outputs): statistics + finalize + apply of a hidden layer in ONE
+// launch (a workgroup owns a 256-column strip for all rows, held in registers), and pass 1 + finalize + dz + bias gradient
+// of its backward.  Measured same-box (bench.py --batch B): B = 64 0.305 -> 0.280 ms per step; B = 100 / 127 with sixteen
+// rows per wave 0.42 / 0.45 -> 0.47 / 0.52 ms (slower: kept to 64 rows).
+constexpr int kBnSmallRows = 64;
+int launch_bn_small_fwd(const float* z, const float* gamma, const float* beta, float eps, float momentum, float* rm, float* rv,
+                        int64_t* nbt, float* mean, float* rstd, const float* resid, float* act, uint64_t* bits, int B, int H,
+                        float p, uint64_t seed, uint64_t step, int layer, const uint64_t* inject_keep, hipStream_t s,
+                        const uint64_t* step_dev);
+int launch_bn_small_bwd(const float* g, const uint64_t* bits, const float* z, const float* mean, const float* rstd,
+                        const float* gamma, float keep_scale, int B, int H, float* dz, float* dgamma, float* dbeta, float* dbias,
+                        hipStream_t s);
 // eval-mode BatchNorm for the saved-state forward: mean := running mean, rstd := rsqrt(running var + eps), scale, shift
 int launch_bn_eval_stats(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int H,
                          float* mean, float* rstd, float* scale, float* shift, hipStream_t s);

