@@ -38,7 +38,10 @@ def main():
                                                             "profiles", "traffic.json")
     f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
     if dtype in ("f16x3", "bf16"):
-        names = {"dual": ("planes_gemm_dual_kernel",), "forward": ("planes_gemm_kernel", "Lb0ELb0E")}
+        # (round 3: the forward GEMM is the pair-staged NT kernel; round 2's name as the fallback)
+        names = {"dual": ("planes_gemm_dual_kernel",), "forward": ("planes_gemm_wide_kernel",)}
+        if pick(f, "planes_gemm_wide_kernel") is None:
+            names["forward"] = ("planes_gemm_kernel", "Lb0ELb0E")
     else:
         names = {"dual": ("dual_kernel",), "forward": ("gemm_x6_planes_kernel",) if dtype == "bf16x6" else ("gemm_f32_kernel",)}
     rec = {}
@@ -53,7 +56,7 @@ def main():
     data = json.load(open(out)) if os.path.exists(out) else {}
     data.setdefault("per_dtype", {})[dtype] = rec
     data["_comment_per_dtype"] = ("per_dtype[dtype][dual|forward].hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KB from "
-                                  "separate rocprofv3 --pmc passes of `bench.py --steps 20 --no-extras` (tools/final_profiles_r02.sh)")
+                                  "separate rocprofv3 --pmc passes of `bench.py --steps 20 --no-extras` (tools/final_profiles_r03.sh)")
     json.dump(data, open(out, "w"), indent=1)
     print(json.dumps(rec, indent=1))
 
