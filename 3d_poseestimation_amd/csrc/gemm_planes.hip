@@ -337,6 +337,49 @@ __global__ __launch_bounds__(512) void planes_gemm_wide_kernel(PlanesKern k, int
   planes_body<false, false, MODE, true, EDGE, CONV, PERSIST, true>(k, blockIdx.x, gridDim.x, nwork, lds);
 }
 
+// the wave's 64x64 accumulator block -> float4 rows through ER rows x 68 floats of LDS (64 / ER passes), then the staged epilogue
+template <int MODE, int ER, bool EDGE>
+__device__ __forceinline__ void acc_epilogue(const PlanesKern& k, plp::f32x4v (&acc)[plp::ModeCfg<MODE>::NACC][4][4], float* ldsw,
+                                             const int m0, const int n0, const int slice, const int wm, const int wn, const int lane) {
+  const float os = MODE == plp::kF16x3 ? (k.dyn_inv ? k.out_scale * k.dyn_inv[0] : k.out_scale) : 1.f;
+  const int q = lane >> 4, c = lane & 15, lc = c * 4;
+  float4 v[16];
+#pragma unroll
+  for (int pass = 0; pass < 64 / ER; ++pass) {
+#pragma unroll
+    for (int r2 = 0; r2 < ER / 16; ++r2)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = acc[0][pass * (ER / 16) + r2][ct][r];
+          if constexpr (MODE == plp::kF16x3) x = fmaf(acc[1][pass * (ER / 16) + r2][ct][r], 1.0f / plp::kF16LoScale, x) * os;
+          ldsw[(r2 * 16 + 4 * q + r) * 68 + ct * 16 + c] = x;
+        }
+#pragma unroll
+    for (int it = 0; it < ER / 4; ++it)
+      v[pass * (ER / 4) + it] = *reinterpret_cast<const float4*>(ldsw + (it * 4 + q) * 68 + lc);
+  }
+  float* C = k.e.C ? k.e.C + (k.e.split_k > 1 ? (size_t)slice * k.e.M * k.e.ldc : 0) : nullptr;
+  staged_epilogue<EDGE>(k, C, v, m0, n0, wm, wn, lane);
+}
+
+// the backward pair chained in one workgroup per CU (gemm_planes16.h CHAIN): grid = the number of dX tiles = dW items
+template <int MODE>
+__global__ __launch_bounds__(512) void planes_gemm_chain_kernel(PlanesKern k0, PlanesKern k1) {
+  __shared__ __attribute__((aligned(16))) char lds[ring_bytes<MODE>() + stage_bytes<32>()];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave & 3) >> 1, wn = wave & 1;
+  float* ldsw = reinterpret_cast<float*>(lds + ring_bytes<MODE>()) + (wave & 3) * 32 * 68;
+  auto epi0 = [&](plp::f32x4v (&acc)[plp::ModeCfg<MODE>::NACC][4][4], const int m0, const int n0, const int slice) {
+    acc_epilogue<MODE, 32, false>(k0, acc, ldsw, m0, n0, slice, wm, wn, lane);
+  };
+  auto epi1 = [&](plp::f32x4v (&acc)[plp::ModeCfg<MODE>::NACC][4][4], const int m0, const int n0, const int slice) {
+    acc_epilogue<MODE, 32, false>(k1, acc, ldsw, m0, n0, slice, wm, wn, lane);
+  };
+  plp::planes_run16_chain<MODE>(k0.p, k1.p, blockIdx.x, gridDim.x, lds, epi0, epi1);
+}
+
 // backward pair of one layer in one launch: workgroups [0, n0) run dX = dz W (NN), the rest dW = dz^T a (TN, split-K
 // slabs).  One workgroup per CU at a time (96 KB of LDS each): what the single launch saves is the launch boundary
 // and the tail of the first problem, which the second one's workgroups fill.
@@ -556,6 +599,17 @@ int launch_gemm_planes_pair(const PlanesGemmArgs& nn, const PlanesGemmArgs& tn, 
   const PlanesKern k0 = kern_of(kNN, nn), k1 = kern_of(kTN, tn);
   const int g0 = grid_of(nn), g1 = grid_of(tn);
   void* prof = prof_begin_flops(2.0 * nn.e.M * nn.e.N * nn.e.K + 2.0 * tn.e.M * tn.e.N * tn.e.K, s);
+  // chained form (round 3): one workgroup per dX tile that goes on to a dW item, operands streaming across
+  static const int chain_env = [] { const char* e = getenv("POSELIFT_CHAIN"); return e ? atoi(e) : 1; }();   // =0: same-box A/B
+  if (chain_env && mfma16_shape() && g0 == g1 && nn.e.K % 32 == 0 && nn.e.K >= 64 && tn.e.K % (32 * splits_of(tn.e)) == 0 &&
+      tn.e.K >= 32 * splits_of(tn.e)) {
+    const dim3 cg(g0), cb(512);
+    if (nn.mode == plp::kF16x3) hipLaunchKernelGGL((planes_gemm_chain_kernel<plp::kF16x3>), cg, cb, 0, s, k0, k1);
+    else hipLaunchKernelGGL((planes_gemm_chain_kernel<plp::kBf16>), cg, cb, 0, s, k0, k1);
+    prof_end(prof, s);
+    PL_CHECK_LAUNCH("gemm_planes_chain");
+    return PL_OK;
+  }
   const dim3 grid(g0 + g1), block(512);
   static const int xs_env = [] { const char* e = getenv("POSELIFT_DUAL_XSPLIT"); return e ? atoi(e) : 0; }();   // =1: same-box A/B (not kept)
   const int xs = (xs_env && g0 == g1 && (g0 & 7) == 0) ? 1 : 0;

@@ -408,6 +408,219 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// CHAIN (round 3): the backward pair of one layer -- dX = dz W (NN) and dW = dz^T a (TN, split-K) -- by ONE workgroup per
+// CU, one item of each, the operand stream running on from the first into the second.  The dual launch of round 2 ran the
+// two problems as two rounds of workgroups: when a CU's dX workgroup retired (after an epilogue that pulls the skip
+// gradient, the saved z and the bitmap: 50 MB chip-wide, no MFMA running anywhere) a dW workgroup had to be dispatched,
+// fetch its first k-tiles and fill its pipeline.  Here the loader waves issue dW's first k-tiles while the computing waves
+// are in dX's epilogue (which stages through LDS of its own, behind the ring), and nothing is re-dispatched.
+// Whole tiles, K0 and every K1 slice whole 32-k tiles, as many dX tiles as dW items (the host checks).
+template <int MODE, class Epi0, class Epi1>
+__device__ __forceinline__ void planes_run16_chain(const PlanesArgs& p0, const PlanesArgs& p1, const int block_id, const int nwork,
+                                                   char* __restrict__ lds, Epi0&& epi0, Epi1&& epi1) {
+  static_assert(MODE == kF16x3 || MODE == kBf16, "two fp16 planes or one bf16 plane");
+  constexpr int NPL = ModeCfg<MODE>::NPL, NACC = ModeCfg<MODE>::NACC;
+  using Cf = PlanesCfg<32, NPL, 3>;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= 4;
+  const int lw = wave & 3;
+  const int wm = (wave & 3) >> 1, wn = wave & 1;
+  int w = block_id;
+  if ((nwork & 7) == 0) w = (block_id & 7) * (nwork >> 3) + (block_id >> 3);   // XCD-aware: blocks b and b+8 share an L2
+  // item 0: tile w of the NN problem
+  const int tn0 = p0.N / 128;
+  const int m00 = (w / tn0) * 128, n00 = (w % tn0) * 128;
+  const int nk0 = p0.K / 32;
+  // item 1: (slice, tile) w of the TN problem, K-slice-major
+  const int tn1 = p1.N / 128;
+  const int splits = p1.split_k > 1 ? p1.split_k : 1;
+  const int ntiles1 = nwork / splits;
+  const int slice = w / ntiles1, t1 = w - slice * ntiles1;
+  const int m01 = (t1 / tn1) * 128, n01 = (t1 % tn1) * 128;
+  const int per = ((p1.K / 32 + splits - 1) / splits) * 32;
+  const int kbeg1 = min(slice * per, p1.K);
+  const int nk1 = (min(kbeg1 + per, p1.K) - kbeg1) / 32;
+  const int total = nk0 + nk1;
+
+  auto barrier = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto next_stage = [](const int o) { return o + Cf::STAGE == 3 * Cf::STAGE ? 0 : o + Cf::STAGE; };
+
+  if (loader) {
+    __amdgpu_buffer_rsrc_t ra0[NPL], rb0[NPL], ra1[NPL], rb1[NPL];
+    const __bf16* ta0 = p0.A + (size_t)m00 * p0.lda;                       // NN: A k-contiguous [M][K], B k-strided [K][N]
+    const __bf16* tb0 = p0.B + n00;
+    const __bf16* ta1 = p1.A + (size_t)kbeg1 * p1.lda + m01;               // TN: both k-strided
+    const __bf16* tb1 = p1.B + (size_t)kbeg1 * p1.ldb + n01;
+#pragma unroll
+    for (int pl = 0; pl < NPL; ++pl) {
+      ra0[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(ta0 + (size_t)pl * p0.a_plane), 0, 0x7fffffff, 0x00020000);
+      rb0[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(tb0 + (size_t)pl * p0.b_plane), 0, 0x7fffffff, 0x00020000);
+      ra1[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(ta1 + (size_t)pl * p1.a_plane), 0, 0x7fffffff, 0x00020000);
+      rb1[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(tb1 + (size_t)pl * p1.b_plane), 0, 0x7fffffff, 0x00020000);
+    }
+    int oa0[2], ob0[2], oa1[2], ob1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      oa0[j] = (int)glds_lane_off16<false>(lw + 4 * j, lane, p0.lda);
+      ob0[j] = (int)glds_lane_off16<true>(lw + 4 * j, lane, p0.ldb);
+      oa1[j] = (int)glds_lane_off16<true>(lw + 4 * j, lane, p1.lda);
+      ob1[j] = (int)glds_lane_off16<true>(lw + 4 * j, lane, p1.ldb);
+    }
+    const int ga0 = 64, gb0 = 32 * p0.ldb * 2, ga1 = 32 * p1.lda * 2, gb1 = 32 * p1.ldb * 2;
+    // (Two issue routines, each with its own descriptors, in loops of their own: one routine choosing the item at run time
+    //  made hipcc select between the descriptor sets per lane -- a waterfall loop around every DMA: 173 us per launch.)
+    int sw = 0;
+    auto issue0 = [&](const int kt) {
+      char* d = lds + sw + lw * 1024;
+      const int sa = kt * ga0, sb = kt * gb0;
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          PLP_BLDS16(ra0[pl], d + pl * Cf::OPP + j * 4096, oa0[j], sa);
+          PLP_BLDS16(rb0[pl], d + (NPL + pl) * Cf::OPP + j * 4096, ob0[j], sb);
+        }
+      sw = next_stage(sw);
+    };
+    auto issue1 = [&](const int kt) {
+      char* d = lds + sw + lw * 1024;
+      const int sa = kt * ga1, sb = kt * gb1;
+#pragma unroll
+      for (int pl = 0; pl < NPL; ++pl)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          PLP_BLDS16(ra1[pl], d + pl * Cf::OPP + j * 4096, oa1[j], sa);
+          PLP_BLDS16(rb1[pl], d + (NPL + pl) * Cf::OPP + j * 4096, ob1[j], sb);
+        }
+      sw = next_stage(sw);
+    };
+    // (host: nk0 >= 2, nk1 >= 1)  tile g+2 of the stream is issued before the barrier of step g
+    issue0(0);
+    issue0(1);
+    wait_vmcnt<Cf::NDMA>();
+    barrier();
+    for (int g = 0; g + 2 < nk0; ++g) { issue0(g + 2); wait_vmcnt<Cf::NDMA>(); barrier(); }
+    for (int kt = 0; kt < nk1; ++kt) { issue1(kt); wait_vmcnt<Cf::NDMA>(); barrier(); }       // steps nk0 - 2 .. total - 3
+    wait_vmcnt<0>(); barrier();
+    wait_vmcnt<0>(); barrier();
+    return;
+  }
+
+  FragAddr16<false> fa_kc;      // A of the NN item
+  FragAddr16<true> fa_ks;       // A of the TN item
+  FragAddr16<true> fb_ks;       // B of both
+  fa_kc.init(wm, lane);
+  fa_ks.init(wm, lane);
+  fb_ks.init(wn, lane);
+  s16x8 fa[4][NPL];
+  s16x8 fb[2][4][NPL];
+  f32x4v acc[NACC][4][4];
+  int st[2] = {0, Cf::STAGE};
+  auto rotate = [&]() { st[0] = st[1]; st[1] = next_stage(st[1]); };
+
+#define PLC_READ_A(AKS, stage_off, t0, t1)                                                   \
+  do {                                                                                       \
+    const char* q_ = lds + (stage_off);                                                      \
+    _Pragma("unroll") for (int t2 = (t0); t2 < (t1); ++t2)                                   \
+    _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl) {                                     \
+      if constexpr (AKS) fa[t2][pl] = read_frag16<true>(q_ + pl * Cf::OPP, fa_ks, t2);       \
+      else fa[t2][pl] = read_frag16<false>(q_ + pl * Cf::OPP, fa_kc, t2);                    \
+    }                                                                                        \
+  } while (0)
+#define PLC_READ_B(set, stage_off)                                                           \
+  do {                                                                                       \
+    const char* q_ = lds + (stage_off) + NPL * Cf::OPP;                                      \
+    _Pragma("unroll") for (int t2 = 0; t2 < 4; ++t2)                                         \
+    _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                       \
+      fb[set][t2][pl] = read_frag16<true>(q_ + pl * Cf::OPP, fb_ks, t2);                     \
+  } while (0)
+#define PLC_MFS(set, rt, ct)                                                                           \
+  do {                                                                                                 \
+    if constexpr (MODE == kF16x3) {                                                                    \
+      acc[1][rt][ct] = mfma16x16<MODE>(fa[rt][0], fb[set][ct][1], acc[1][rt][ct]);                      \
+      acc[1][rt][ct] = mfma16x16<MODE>(fa[rt][1], fb[set][ct][0], acc[1][rt][ct]);                      \
+    }                                                                                                  \
+    acc[0][rt][ct] = mfma16x16<MODE>(fa[rt][0], fb[set][ct][0], acc[0][rt][ct]);                        \
+  } while (0)
+#define PLC_ROWS(set, r0, r1)                                                                \
+  do {                                                                                       \
+    _Pragma("unroll") for (int rt = (r0); rt < (r1); ++rt)                                   \
+    _Pragma("unroll") for (int ct = 0; ct < 4; ++ct) PLC_MFS(set, rt, ct);                   \
+  } while (0)
+
+  constexpr int NMF = 8 * ModeCfg<MODE>::NPROD;
+  int nk = 0;
+  auto step = [&](const int kt, auto par, auto steady, auto aks) {
+    constexpr int P = decltype(par)::value;
+    constexpr bool STEADY = decltype(steady)::value;
+    constexpr bool AKS = decltype(aks)::value;
+    constexpr int RA = NPL * (AKS ? 2 : 1), RB = NPL * 2;
+    const bool has_next = STEADY || kt + 1 < nk;
+    PLC_READ_A(AKS, st[0], 2, 4);
+    PLC_ROWS(P, 0, 2);
+    if (STEADY) sched_half<2 * RA, 0, NMF>();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    barrier();
+    if (has_next) {
+      PLC_READ_A(AKS, st[1], 0, 2);
+      PLC_READ_B(1 - P, st[1]);
+    }
+    PLC_ROWS(P, 2, 4);
+    if (STEADY) sched_half<2 * RA + 4 * RB, 0, NMF>();
+    __builtin_amdgcn_sched_barrier(0);
+    rotate();
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  const f32x4v zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int c = 0; c < NACC; ++c)
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[c][a][b] = zero4;
+  };
+  auto run_item = [&](auto aks) {
+    constexpr bool AKS = decltype(aks)::value;
+    PLC_READ_A(AKS, st[0], 0, 2);
+    PLC_READ_B(0, st[0]);
+    int kt = 0;
+    for (; kt + 3 < nk; kt += 2) {
+      step(kt, P0{}, T_{}, aks);
+      step(kt + 1, P1{}, T_{}, aks);
+    }
+    for (; kt < nk; kt += 2) {
+      step(kt, P0{}, F_{}, aks);
+      if (kt + 1 < nk) step(kt + 1, P1{}, F_{}, aks);
+    }
+  };
+  if (total <= 0) return;
+  barrier();                                   // the stream's first k-tile has landed
+  zero_acc();
+  nk = nk0;
+  if (nk > 0) run_item(F_{});
+  epi0(acc, m00, n00, 0);
+  zero_acc();
+  nk = nk1;
+  if (nk > 0) run_item(T_{});
+  epi1(acc, m01, n01, slice);
+#undef PLC_READ_A
+#undef PLC_READ_B
+#undef PLC_MFS
+#undef PLC_ROWS
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // WIDE (round 3): the same loop with k-tiles staged in PAIRS, so that a k-contiguous operand is fetched in whole 128-byte
 // lines.  With one 32-k tile per stage a k-contiguous row contributes 64 bytes per tile: a DMA instruction covers 16 rows x
 // 64 B, i.e. 16 half lines, and every line crosses the L1 / texture-address path twice (once per tile).  The k-strided
