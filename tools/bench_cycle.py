@@ -70,7 +70,7 @@ def main():
     m2, m3 = m2.to(dev), m3.to(dev)
     lift = pkg.LinearModel(34, 51, linear_size=1024, p_dropout=0.5).to(dev).train()
     proj = pkg.LinearModel(51, 34, linear_size=64, p_dropout=0.5).to(dev).train()
-    opts = [torch.optim.Adam(m2.parameters(), lr=1e-4), torch.optim.Adam(m3.parameters(), lr=1e-4),
+    opts = [pkg.FlatAdam(m2, lr=1e-4), pkg.FlatAdam(m3, lr=1e-4),
             pkg.FlatAdamW(lift, lr=1e-4), pkg.FlatAdamW(proj, lr=1e-4)]
     frames = pkg.synth.seeded_frames(B, 63).to(dev)
     y1, y2 = pkg.synth.synthetic_batch(B, 64, dev)

@@ -14,10 +14,10 @@ with torch.no_grad():
 m = m.to("cuda")
 x = pkg.synth.seeded_frames(B, 5).to("cuda")
 t = torch.randn(B, 51, device="cuda")
-opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+opt = pkg.FlatAdam(m, lr=1e-3)
 for _ in range(iters):
     opt.zero_grad()
-    F.mse_loss(m(x), t).backward()
+    pkg.mse_loss(m(x), t).backward()
     opt.step()
 torch.cuda.synchronize()
 print("done")
