@@ -135,6 +135,13 @@ class _LifterFn(torch.autograd.Function):
 
 
 class LinearModel(nn.Module):
+    """compute_dtype: "fp32" (exact fp32 MFMA), "bf16x6" and "f16x3" (fp32-grade: meet the 1e-3 mm gate), "bf16" (bf16 operand
+    storage, ~1 mm).  Range contract of "f16x3": the 1024-wide layers' activations are stored as fp16 planes at scale 1, so a
+    hidden activation must stay below 65504 in magnitude (the conv path stores at 1/64: 4.2e6).  A training-mode BatchNorm
+    output is at most gamma * sqrt(B) + |beta| and the block adds two of them, so only weights in the thousands can get there;
+    nothing checks it at run time (an overflowing value becomes inf where "fp32" / "bf16x6" stay finite) -- use one of those
+    for models outside the contract.  Gradients have no such limit: dz is range-scaled on the device per layer and step."""
+
     def __init__(self, i_dim, o_dim, linear_size=1024, num_stage=2, p_dropout=0.5, BN=True,
                  compute_dtype="fp32"):
         super().__init__()
