@@ -157,7 +157,9 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
       m2.x = fmaf(dx, dx, m2.x); m2.y = fmaf(dy, dy, m2.y); m2.z = fmaf(dz, dz, m2.z); m2.w = fmaf(dw, dw, m2.w);
     }
     m2 = xadd_rows(m2);
-    if (lr == 0 && cok) {
+    // (the consumers walk 2 ceil(M / 128) groups, empty ones included -- gemm_stat_groups; a wave block of a 256-row tile
+    //  below that has no group)
+    if (lr == 0 && cok && (!EDGE || (m0 >> 6) + wm < 2 * ((e.M + 127) >> 7))) {
       const size_t o = (size_t)((m0 >> 6) + wm) * e.N + col0;
       *reinterpret_cast<float4*>(e.stat_sum + o) = s;
       *reinterpret_cast<float4*>(e.stat_m2 + o) = m2;
@@ -218,6 +220,8 @@ __device__ __forceinline__ void staged_epilogue(const PlanesKern& k, float* __re
 // PERSIST (16x16x32 loop only): the workgroup walks a run of work items, operands streaming across the item boundaries
 // (gemm_planes16.h); the epilogue then stages through LDS of its own behind the three-stage ring.
 template <int MODE, int NST = 3> constexpr int ring_bytes() { return plp::PlanesCfg<32, plp::ModeCfg<MODE>::NPL, NST>::LDS; }
+// the 256 x 64 tile (gemm_planes16.h T64): A image 256 rows, B image 64 rows of 64 B per plane and stage, three stages
+template <int MODE> constexpr int t64_ring_bytes() { return 3 * plp::ModeCfg<MODE>::NPL * (256 + 64) * 64; }
 // the staged epilogue takes the wave's 64x64 block through LDS in 64 / ER passes of ER rows x 68 floats per wave
 template <int ER> constexpr int stage_bytes() { return 4 * ER * 68 * 4; }
 // ring depth of the persistent form.  (Measured with 4 stages + 16-row staging passes for f16x3, 6 for bf16: the K = 64
@@ -227,8 +231,10 @@ constexpr int kPersistRows = 32;
 // LDS: the operand ring, and never less than the 4 x 17 KB the 32x32x16 loop's epilogue stages a whole block in
 template <int MODE> constexpr int wide_ring_bytes() { return plp::WideCfg<plp::ModeCfg<MODE>::NPL>::LDS; }
 constexpr int kWidePersistRows = 16;              // 2 x 64 KB of pair-stages leave 32 KB: the staged epilogue in 16-row passes
-template <int MODE, bool PERSIST = false, bool WIDE = false>
+template <int MODE, bool PERSIST = false, bool WIDE = false, bool T64 = false>
 constexpr int lds_bytes() {
+  if (T64) return PERSIST ? t64_ring_bytes<MODE>() + stage_bytes<kPersistRows>()
+                          : (t64_ring_bytes<MODE>() > stage_bytes<32>() ? t64_ring_bytes<MODE>() : stage_bytes<32>());
   if (WIDE) return PERSIST ? wide_ring_bytes<MODE>() + stage_bytes<kWidePersistRows>()
                            : (wide_ring_bytes<MODE>() > stage_bytes<32>() ? wide_ring_bytes<MODE>() : stage_bytes<32>());
   if (PERSIST) return ring_bytes<MODE, persist_nst<MODE>()>() + stage_bytes<kPersistRows>();
@@ -236,11 +242,13 @@ constexpr int lds_bytes() {
 }
 static_assert(lds_bytes<plp::kF16x3, true>() <= 160 * 1024 && lds_bytes<plp::kBf16, true>() <= 160 * 1024, "LDS per CU");
 static_assert(lds_bytes<plp::kF16x3, true, true>() <= 160 * 1024 && lds_bytes<plp::kF16x3, false, true>() <= 160 * 1024, "LDS per CU");
+static_assert(lds_bytes<plp::kF16x3, true, false, true>() <= 160 * 1024, "LDS per CU");
 
-template <bool A_KS, bool B_KS, int MODE, bool S16, bool EDGE = false, int CONV = 0, bool PERSIST = false, bool WIDE = false>
+template <bool A_KS, bool B_KS, int MODE, bool S16, bool EDGE = false, int CONV = 0, bool PERSIST = false, bool WIDE = false,
+          bool T64 = false>
 __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block_id, const int nblocks, const int nwork, char* lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = (wave & 3) >> 1, wn = wave & 1;
+  const int wm = T64 ? (wave & 3) : (wave & 3) >> 1, wn = T64 ? 0 : (wave & 1);
   // main + low / 2048, then back from the operands' power-of-two scales (exact unless the result under/overflows)
   const float os = MODE == plp::kF16x3 ? (k.dyn_inv ? k.out_scale * k.dyn_inv[0] : k.out_scale) : 1.f;
   if constexpr (S16) {
@@ -248,7 +256,7 @@ __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block
     // elements leaves with float4 rows (v[it] = row 4 it + (lane >> 4), columns 4 (lane & 15) ..)
     constexpr int NST = PERSIST ? persist_nst<MODE>() : 3;
     constexpr int ER = PERSIST ? (WIDE ? kWidePersistRows : kPersistRows) : 32;
-    constexpr int RING = WIDE ? wide_ring_bytes<MODE>() : ring_bytes<MODE, NST>();
+    constexpr int RING = T64 ? t64_ring_bytes<MODE>() : (WIDE ? wide_ring_bytes<MODE>() : ring_bytes<MODE, NST>());
     float* ldsw = reinterpret_cast<float*>(lds + (PERSIST ? RING : 0)) + (wave & 3) * ER * 68;
     const int q = lane >> 4, c = lane & 15, lc = c * 4;
     auto epi = [&](plp::f32x4v (&acc)[plp::ModeCfg<MODE>::NACC][4][4], const int m0, const int n0, const int slice) {
@@ -275,7 +283,7 @@ __device__ __forceinline__ void planes_body(const PlanesKern& k, const int block
       staged_epilogue<EDGE>(k, C, v, m0, n0, wm, wn, lane);
     };
     if constexpr (WIDE) plp::planes_run16w<A_KS, B_KS, MODE, EDGE, CONV, PERSIST>(k.p, block_id, nblocks, nwork, lds, epi);
-    else plp::planes_run16<A_KS, B_KS, MODE, EDGE, CONV, PERSIST, NST>(k.p, block_id, nblocks, nwork, lds, epi);
+    else plp::planes_run16<A_KS, B_KS, MODE, EDGE, CONV, PERSIST, NST, T64>(k.p, block_id, nblocks, nwork, lds, epi);
   } else {
     float* ldsw = reinterpret_cast<float*>(lds) + (wave & 3) * 64 * 68;
     int m0, n0, slice;
@@ -327,6 +335,13 @@ template <int MODE, bool EDGE, int CONV>
 __global__ __launch_bounds__(512) void planes_gemm_persistent_kernel(PlanesKern k, int nwork) {
   __shared__ __attribute__((aligned(16))) char lds[lds_bytes<MODE, true>()];
   planes_body<false, false, MODE, true, EDGE, CONV, true>(k, blockIdx.x, gridDim.x, nwork, lds);
+}
+
+// NT on 256-row x 64-column tiles (gemm_planes16.h T64): the 64-channel layers
+template <int MODE, bool EDGE, int CONV, bool PERSIST>
+__global__ __launch_bounds__(512) void planes_gemm_t64_kernel(PlanesKern k, int nwork) {
+  __shared__ __attribute__((aligned(16))) char lds[lds_bytes<MODE, PERSIST, false, true>()];
+  planes_body<false, false, MODE, true, EDGE, CONV, PERSIST, false, true>(k, blockIdx.x, gridDim.x, nwork, lds);
 }
 
 // NT with the k-tiles staged in pairs (whole 128-byte lines of both k-contiguous operands: gemm_planes16.h, WIDE);
@@ -543,7 +558,22 @@ int launch_gemm_planes(GemmLayout layout, const PlanesGemmArgs& a, hipStream_t s
   // forward GEMM 33.2 -> 32.7 us in the step), K <= 512 0-3 % MORE (a pair is a coarser unit at an item boundary)
   const bool wide = wide_env && mfma16_shape() && layout == kNT && splits_of(a.e) == 1 && a.e.K % 64 == 0 && a.e.K >= 1024 &&
                     (a.e.conv_cin == 0 || a.e.conv_cin % 64 == 0);
-  if (wide) {
+  // 64-channel outputs: 256-row x 64-column tiles (half of a 128-wide tile would be padding)
+  static const int t64_env = [] { const char* e = getenv("POSELIFT_T64"); return e ? atoi(e) : 1; }();       // =0: same-box A/B
+  const bool t64 = t64_env && mfma16_shape() && layout == kNT && a.e.N <= 64 && splits_of(a.e) == 1 && !a.e.scat_on;
+  if (t64) {
+    const int nwork = (int)(((a.e.M + 255) / 256) * ((a.e.N + 63) / 64));
+    const bool pers = persist_env && nwork >= 2 * ncu;
+    const dim3 tg(pers ? ncu : nwork);
+    const bool edge = (a.e.M % 256) != 0 || (a.e.N % 64) != 0 || a.e.conv_cin;
+#define PL_T64(MODE, P)                                                                                                  \
+    if (a.e.conv_cin) hipLaunchKernelGGL((planes_gemm_t64_kernel<MODE, true, 1, P>), tg, block, 0, s, k, nwork);          \
+    else if (edge) hipLaunchKernelGGL((planes_gemm_t64_kernel<MODE, true, 0, P>), tg, block, 0, s, k, nwork);             \
+    else hipLaunchKernelGGL((planes_gemm_t64_kernel<MODE, false, 0, P>), tg, block, 0, s, k, nwork);
+    if (pers) { if (a.mode == plp::kF16x3) { PL_T64(plp::kF16x3, true) } else { PL_T64(plp::kBf16, true) } }
+    else { if (a.mode == plp::kF16x3) { PL_T64(plp::kF16x3, false) } else { PL_T64(plp::kBf16, false) } }
+#undef PL_T64
+  } else if (wide) {
     const int nwork = (int)grid.x;
     const dim3 wg(persist ? ncu : nwork);
     const bool edge = is_edge(a) || a.e.conv_cin;

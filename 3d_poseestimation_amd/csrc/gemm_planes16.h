@@ -107,21 +107,29 @@ __device__ __forceinline__ f32x4v mfma16x16(const s16x8 a, const s16x8 b, const 
 constexpr int kDmaOutOfRange = 0x7ffffff0;     // >= num_records of the gathered operand's descriptor
 // NST: stages of the operand ring (3: a k-tile being read, one landed, one in flight; the persistent form of the short-K
 // layers runs deeper -- every barrier waits for the NEXT k-tile, so the ring depth is what HBM latency is hidden behind).
-template <bool A_KS, bool B_KS, int MODE, bool EDGE, int CONV, bool PERSIST, int NST, class Epi>
+template <bool A_KS, bool B_KS, int MODE, bool EDGE, int CONV, bool PERSIST, int NST, bool T64, class Epi>
 __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int block_id, const int nblocks, const int nwork,
                                              char* __restrict__ lds, Epi&& epi) {
   static_assert(MODE == kF16x3 || MODE == kBf16, "two fp16 planes or one bf16 plane");
   constexpr int NPL = ModeCfg<MODE>::NPL, NACC = ModeCfg<MODE>::NACC;
-  using Cf = PlanesCfg<32, NPL, NST>;
-  static_assert(NST >= 3 && (NST - 2) * Cf::NDMA <= 63, "ring depth: vmcnt counts at most 63 requests");
+  // T64 (NT only): a 256-row x 64-column tile -- four computing waves stacked along M, each still a 64 x 64 block (so the
+  // epilogue is unchanged) -- for the 64-channel layers, where half of every 128-wide tile was padding: half the MFMAs,
+  // no clamped B rows.  A image [256 rows][64 B], B image [64 rows][64 B] per plane and stage.
+  static_assert(!T64 || (!A_KS && !B_KS), "the 256 x 64 tile is an NT tile");
+  constexpr int TM = T64 ? 256 : 128, TNW = T64 ? 64 : 128;
+  constexpr int OPPA = (A_KS ? 128 : TM) * 64, OPPB = (B_KS ? 128 : TNW) * 64;      // bytes per plane, operand and stage
+  constexpr int STAGE = NPL * (OPPA + OPPB);
+  constexpr int JA = OPPA / 4096, JB = OPPB / 4096;                                  // DMA instructions per loader wave and plane
+  constexpr int NDMA = NPL * (JA + JB);
+  static_assert(NST >= 3 && (NST - 2) * NDMA <= 63, "ring depth: vmcnt counts at most 63 requests");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave >= 4;
   const int lw = wave & 3;
-  const int wm = (wave & 3) >> 1, wn = wave & 1;
+  const int wm = T64 ? (wave & 3) : (wave & 3) >> 1, wn = T64 ? 0 : (wave & 1);
 
-  const int tiles_n = EDGE ? (p.N + 127) / 128 : p.N / 128;
+  const int tiles_n = EDGE ? (p.N + TNW - 1) / TNW : p.N / TNW;
   const int splits = p.split_k > 1 ? p.split_k : 1;
   const int ntiles = nwork / splits;
   // this workgroup's items: one (the block id, XCD-aware: blocks b and b+8 share an L2), or a contiguous run of them
@@ -142,8 +150,8 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
   auto decode = [&](const int w, int& m0, int& n0, int& slice, int& kbeg) {
     slice = w / ntiles;
     const int t = w - slice * ntiles;
-    m0 = (t / tiles_n) * 128;
-    n0 = (t % tiles_n) * 128;
+    m0 = (t / tiles_n) * TM;
+    n0 = (t % tiles_n) * TNW;
     kbeg = 0;
     int kend = p.K;
     if (splits > 1) {
@@ -161,8 +169,8 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
     __builtin_amdgcn_sched_barrier(0);
   };
   // stage of k-tile g of the stream: (g % NST) * STAGE, kept as running offsets
-  auto next_stage = [](const int o) { return o + Cf::STAGE == NST * Cf::STAGE ? 0 : o + Cf::STAGE; };
-  int st[2] = {0, Cf::STAGE};                       // computing waves: the k-tile being read, the next one
+  auto next_stage = [](const int o) { return o + STAGE == NST * STAGE ? 0 : o + STAGE; };
+  int st[2] = {0, STAGE};                       // computing waves: the k-tile being read, the next one
   auto rotate = [&]() { st[0] = st[1]; st[1] = next_stage(st[1]); };
 
   if (loader) {
@@ -175,14 +183,14 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
     int it = item_lo, kt = 0, nk = 0, m0 = 0, n0 = 0, slice = 0, kbeg = 0;
     // one descriptor per plane (64-bit plane stride in the base: a plane of the conv head's 4.5 GB gradient is 2.3 GB away)
     __amdgpu_buffer_rsrc_t ra[NPL], rb[NPL];
-    int oa[2], ob[2];
+    int oa[JA], ob[JB];
     // ---- convolution gathers: descriptors on the whole tensor, offsets rebuilt per K tile by the (otherwise idle) loader VALU
     __amdgpu_buffer_rsrc_t rx[NPL];
 #pragma unroll
     for (int pl = 0; pl < NPL; ++pl)
       rx[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(CONV == 2 ? p.B + (size_t)pl * p.b_plane : p.A + (size_t)pl * p.a_plane),
                                                  0, 0x7fffffe0, 0x00020000);
-    int cih0[2] = {0, 0}, ciw0[2] = {0, 0}, cbase[2] = {0, 0};      // CONV 1: per DMA row of this lane
+    int cih0[JA] = {}, ciw0[JA] = {}, cbase[JA] = {};               // CONV 1: per DMA row of this lane
     int ctap = 0, cc0 = 0, ckh = 0, ckw = 0;                        // CONV 1: filter tap / channel offset of the next tile issued
     int wkh = 0, wkw = 0, wcol = 0;                                 // CONV 2: this lane's column chunk: tap and channel (fixed)
     auto setup = [&]() {
@@ -195,13 +203,12 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
         rb[pl] = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(tb + (size_t)pl * p.b_plane), 0, 0x7fffffff, 0x00020000);
       }
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        oa[j] = (int)glds_lane_off16<A_KS>(lw + 4 * j, lane, p.lda, EDGE ? p.M - m0 : 0x7fffffff);
-        ob[j] = (int)glds_lane_off16<B_KS>(lw + 4 * j, lane, p.ldb, EDGE ? p.N - n0 : 0x7fffffff);
-      }
+      for (int j = 0; j < JA; ++j) oa[j] = (int)glds_lane_off16<A_KS>(lw + 4 * j, lane, p.lda, EDGE ? p.M - m0 : 0x7fffffff);
+#pragma unroll
+      for (int j = 0; j < JB; ++j) ob[j] = (int)glds_lane_off16<B_KS>(lw + 4 * j, lane, p.ldb, EDGE ? p.N - n0 : 0x7fffffff);
       if (CONV == 1) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < JA; ++j) {
           const int row = (lw + 4 * j) * 16 + (lane >> 2);
           const int m = min(m0 + row, p.M - 1);
           const int ow = m % p.cv_wo, t2 = m / p.cv_wo;
@@ -226,11 +233,15 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
       if (p.abl & 2) return;
       const int sa = kt * ga_step, sb = kt * gb_step;
       char* d = lds + stage_off + lw * 1024;
-      int va[2] = {oa[0], oa[1]}, vb[2] = {ob[0], ob[1]};
+      int va[JA], vb[JB];
+#pragma unroll
+      for (int j = 0; j < JA; ++j) va[j] = oa[j];
+#pragma unroll
+      for (int j = 0; j < JB; ++j) vb[j] = ob[j];
       if (CONV == 1) {                                   // tiles are issued in K order: the tap advances incrementally
         const int toff = ((ckh * p.cv_w + ckw) * p.cv_cin + cc0) * 2;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < JA; ++j) {
           const bool ok = (unsigned)(cih0[j] + ckh) < (unsigned)p.cv_h && (unsigned)(ciw0[j] + ckw) < (unsigned)p.cv_w;
           va[j] = ok ? cbase[j] + toff : kDmaOutOfRange;
         }
@@ -240,7 +251,7 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
       if (CONV == 2) {
         // k rows = output pixels kbeg + 32 kt + 4 (lw + 4 j) + (lane >> 4): pixel -> (b, oh, ow) -> the tap's input pixel
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < JB; ++j) {
           const int pix = kbeg + kt * 32 + (lw + 4 * j) * 4 + (lane >> 4);
           const int ow = pix % p.cv_wo, t2 = pix / p.cv_wo;
           const int oh = t2 % p.cv_ho, b = t2 / p.cv_ho;
@@ -250,14 +261,18 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
         }
       }
 #pragma unroll
-      for (int pl = 0; pl < NPL; ++pl)
+      for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (CONV == 1) PLP_BLDS16(rx[pl], d + pl * Cf::OPP + j * 4096, va[j], 0);
-          else PLP_BLDS16(ra[pl], d + pl * Cf::OPP + j * 4096, va[j], sa);
-          if (CONV == 2) PLP_BLDS16(rx[pl], d + (NPL + pl) * Cf::OPP + j * 4096, vb[j], 0);
-          else PLP_BLDS16(rb[pl], d + (NPL + pl) * Cf::OPP + j * 4096, vb[j], sb);
+        for (int j = 0; j < JA; ++j) {
+          if (CONV == 1) PLP_BLDS16(rx[pl], d + pl * OPPA + j * 4096, va[j], 0);
+          else PLP_BLDS16(ra[pl], d + pl * OPPA + j * 4096, va[j], sa);
         }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+          if (CONV == 2) PLP_BLDS16(rx[pl], d + NPL * OPPA + pl * OPPB + j * 4096, vb[j], 0);
+          else PLP_BLDS16(rb[pl], d + NPL * OPPA + pl * OPPB + j * 4096, vb[j], sb);
+        }
+      }
     };
     // the stream: items in order, each one's k-tiles in order; an item without k-tiles (a K slice past the end) is skipped,
     // as the computing waves skip it
@@ -277,11 +292,11 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
     };
     // at most n k-tiles (the youngest) still in flight
     auto wait_tiles = [&](const int n) {
-      if (NST >= 7 && n >= 5) wait_vmcnt<5 * Cf::NDMA>();
-      else if (NST >= 6 && n == 4) wait_vmcnt<4 * Cf::NDMA>();
-      else if (NST >= 5 && n == 3) wait_vmcnt<3 * Cf::NDMA>();
-      else if (NST >= 4 && n == 2) wait_vmcnt<2 * Cf::NDMA>();
-      else if (n == 1) wait_vmcnt<Cf::NDMA>();
+      if (NST >= 7 && n >= 5) wait_vmcnt<5 * NDMA>();
+      else if (NST >= 6 && n == 4) wait_vmcnt<4 * NDMA>();
+      else if (NST >= 5 && n == 3) wait_vmcnt<3 * NDMA>();
+      else if (NST >= 4 && n == 2) wait_vmcnt<2 * NDMA>();
+      else if (n == 1) wait_vmcnt<NDMA>();
       else wait_vmcnt<0>();
     };
     static_assert(NST <= 7, "wait_tiles covers rings of up to seven stages");
@@ -311,14 +326,14 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
     const char* q_ = lds + (stage_off);                                                      \
     _Pragma("unroll") for (int t2 = (t0); t2 < (t1); ++t2)                                   \
     _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                       \
-      fa[t2][pl] = read_frag16<A_KS>(q_ + pl * Cf::OPP, fra, t2);                            \
+      fa[t2][pl] = read_frag16<A_KS>(q_ + pl * OPPA, fra, t2);                            \
   } while (0)
 #define PLP16_READ_B(set, stage_off)                                                         \
   do {                                                                                       \
-    const char* q_ = lds + (stage_off) + NPL * Cf::OPP;                                      \
+    const char* q_ = lds + (stage_off) + NPL * OPPA;                                         \
     _Pragma("unroll") for (int t2 = 0; t2 < 4; ++t2)                                         \
     _Pragma("unroll") for (int pl = 0; pl < NPL; ++pl)                                       \
-      fb[set][t2][pl] = read_frag16<B_KS>(q_ + pl * Cf::OPP, frb, t2);                       \
+      fb[set][t2][pl] = read_frag16<B_KS>(q_ + pl * OPPB, frb, t2);                       \
   } while (0)
   // one 16x16 output tile, one 32-deep k step: f16x3 = main product on accumulator 0, the two cross terms on 1
 #define PLP16_MFS(set, rt, ct)                                                                         \
@@ -375,8 +390,8 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
       if (splits > 1) {
         nk = decode(w, m0, n0, slice, kbeg);
       } else {
-        n0 += 128;
-        if (n0 >= tiles_n * 128) { n0 = 0; m0 += 128; }
+        n0 += TNW;
+        if (n0 >= tiles_n * TNW) { n0 = 0; m0 += TM; }
       }
     }
 #pragma unroll
