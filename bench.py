@@ -238,11 +238,12 @@ def read_rooflines(pkg, L, dtype, one, traffic):
         return r
     # dominant kernel by time: the backward dual launch (dX = dz W and dW = dz^T a of one layer,
     # 2 x 8.59 GFLOP); the forward single-GEMM kernel is reported beside it
-    kd = {"bf16x6": "gemm_x6_planes_dual_kernel", "f16x3": "planes_gemm_dual_kernel<f16x3>"}.get(
+    kd = {"bf16x6": "gemm_x6_planes_dual_kernel", "f16x3": "planes_gemm_chain_kernel<f16x3>"}.get(
         dtype, "gemm_f32_dual_kernel<%s>" % dtype)
     ks = {"bf16x6": "gemm_x6_planes_kernel<NT>", "f16x3": "planes_gemm_wide_kernel<f16x3> (NT, k-tiles staged in pairs)"}.get(
         dtype, "gemm_f32_kernel<NT,%s>" % dtype)
-    dual = read(1.9 * one, 2.1 * one, kd + " (4096x1024x1024 dX + 1024x1024x4096 dW in one launch, 4 launches/step)",
+    dual = read(1.9 * one, 2.1 * one, kd + " (4096x1024x1024 dX + 1024x1024x4096 dW in one launch -- f16x3 / bf16: one workgroup "
+                "per CU runs its dX tile, then a dW item, the operand stream running on; 4 launches/step)",
                 "gemm_f32_dual_hbm_bytes_per_launch")
     single = read(0.99 * one, 1.01 * one, ks + " (4096x1024x1024 forward, 4 launches/step)",
                   "gemm_f32_hbm_bytes_per_launch")

@@ -39,7 +39,10 @@ def main():
     f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
     if dtype in ("f16x3", "bf16"):
         # (round 3: the forward GEMM is the pair-staged NT kernel; round 2's name as the fallback)
-        names = {"dual": ("planes_gemm_dual_kernel",), "forward": ("planes_gemm_wide_kernel",)}
+        # (round 3: dX + dW run chained in one workgroup per CU; round 2's names as the fallback)
+        names = {"dual": ("planes_gemm_chain_kernel",), "forward": ("planes_gemm_wide_kernel",)}
+        if pick(f, "planes_gemm_chain_kernel") is None:
+            names["dual"] = ("planes_gemm_dual_kernel",)
         if pick(f, "planes_gemm_wide_kernel") is None:
             names["forward"] = ("planes_gemm_kernel", "Lb0ELb0E")
     else:
