@@ -77,6 +77,7 @@ SIGNATURES = {
     "pl_workspace_bytes": (_c.c_size_t, [_D, _c.c_int64]),
     "pl_workspace_view": (_c.c_int, [_D, _c.c_int64, _c.c_int, _c.c_int64,
                                      _c.POINTER(_c.c_size_t), _c.POINTER(_c.c_size_t)]),
+    "pl_workspace_bitmap_format": (_c.c_int, [_D, _c.c_int64, _c.c_int64]),
     "pl_lifter_fwd_eval": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _P]),
     "pl_lifter_fwd_train": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _c.c_uint64,
                                        _c.c_uint64, _P, _P]),

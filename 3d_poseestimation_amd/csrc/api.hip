@@ -103,6 +103,11 @@ inline bool bn_small_ok(const PLDesc* d, bool planes, int64_t B) {
   static const bool off = [] { const char* e = getenv("POSELIFT_BN_SMALL"); return e && e[0] == '0'; }();   // =0: same-box A/B
   return !off && d->bn && !planes && sync_world(d) == 1 && B >= 2 && B <= kBnSmallRows;
 }
+// ... and behind the first layer the Linear in front of it / the dX GEMM behind it ride in the same launch (small_layer.hip).
+// A pure function of (descriptor, batch): forward and backward agree on which bitmap format a layer has.
+inline bool small_layer_on(const PLDesc* d, bool planes, int64_t B) {
+  return bn_small_ok(d, planes, B) && small_layer_ok((int)B, d->hidden, d->hidden);
+}
 inline int arith_of(const PLDesc* d) { return d->dtype == PL_F16X3 ? (int)PL_BF16X6 : d->dtype; }
 
 struct ParamLayout {
@@ -174,7 +179,8 @@ Ws plan(const PLDesc* d, int64_t B) {
     return at;
   };
   w.act_bytes = (size_t)B * H * sizeof(float);
-  w.bits_bytes = (size_t)B * bitmap_words_per_row(H) * sizeof(uint64_t);
+  // (at least H words: the tile-format bitmap of the small-batch layer kernels, small_layer.hip)
+  w.bits_bytes = std::max((size_t)B * bitmap_words_per_row(H), (size_t)H) * sizeof(uint64_t);
   w.pkind = planes_kind(d, B);
   w.planes = w.pkind != 0;
   for (int l = 0; l < w.L; ++l) {
@@ -441,6 +447,12 @@ extern "C" int pl_workspace_view(const PLDesc* d, int64_t B, int which, int64_t 
   return PL_OK;
 }
 
+extern "C" int pl_workspace_bitmap_format(const PLDesc* d, int64_t B, int64_t layer) {
+  PL_TRY(check_desc(d, false));
+  if (B <= 0 || layer < 0 || layer >= 1 + 2 * (int64_t)d->num_stage) PL_FAIL(PL_EINVAL, "pl_workspace_bitmap_format: bad arguments");
+  return (layer > 0 && small_layer_on(d, planes_kind(d, B) != 0, B)) ? 1 : 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // forward, eval mode
 // ---------------------------------------------------------------------------------------
@@ -543,6 +555,16 @@ static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, 
     float* stat = f32(ws, w.stat);
     // small batches: statistics, finalize and apply in ONE launch straight from z (bn_small_fwd_kernel) -- no partials
     const bool small = bn_small(d, w, B) && !eval_bn;
+    if (small && l > 0 && small_layer_on(d, w.planes, B)) {
+      // ... and behind the first layer the Linear rides in the same launch
+      const float* resid = (l >= 2 && (l % 2) == 0) ? f32(ws, w.act[l - 2]) : nullptr;
+      PL_TRY(launch_small_layer_fwd(a_in, ly.W, ly.b, ly.gamma, ly.beta, d->bn_eps, d->bn_momentum, ly.rm, ly.rv, ly.nbt,
+                                    f32(ws, w.mean[l]), f32(ws, w.rstd[l]), resid, g.C, f32(ws, w.act[l]), u64(ws, w.bits[l]),
+                                    (int)B, H, ly.K, d->p_dropout, seed, step, l,
+                                    inject_keep ? inject_keep + (size_t)l * inj_stride : nullptr, s, d->step_dev));
+      a_in = f32(ws, w.act[l]);
+      continue;
+    }
     if (d->bn && !eval_bn && !small) {
       g.stat_sum = stat + (size_t)sync_rank(d) * 2 * groups * H;
       g.stat_m2 = g.stat_sum + (size_t)groups * H;
@@ -676,10 +698,17 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
     PlaneOut dzo = {nullptr, nullptr, 1.0f, dzs, 0};
     if (pl_layer) { dzo.h = u16(ws, w.dzp); dzo.l = dzo.h + BH; dzo.kind = w.pkind; }
     const bool small = bn_small(d, w, B) && !eval_bn;
-    if (small) {
+    // small batches, layer kernels (small_layer.hip): the dX launch of layer l + 1 already ran this layer's BatchNorm backward
+    // (dz_l sits in dzbuf(l)) unless this layer heads the range
+    const bool sl = small && small_layer_on(d, w.planes, B);
+    auto dzbuf = [&](int layer) { return (sl && (layer & 1)) ? GB : DZ; };   // (alternating: a launch reads dz_l and writes dz_{l-1})
+    float* DZl = dzbuf(l);
+    if (small && sl && l < l_hi) {
+      // (nothing: done by launch_small_layer_bwd of layer l + 1)
+    } else if (small) {
       // pass 1, the coefficients, dz, the bias gradient and dgamma / dbeta of this layer in one launch (small batches)
-      PL_TRY(launch_bn_small_bwd(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), ly.gamma, kscale, Bi, H, DZ, ly.ggamma,
-                                 ly.gbeta, ly.gb, s));
+      PL_TRY(launch_bn_small_bwd(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), ly.gamma, kscale, Bi, H, DZl, ly.ggamma,
+                                 ly.gbeta, ly.gb, s, sl && l > 0));
     } else if (d->bn) {
       // pass 1 (column sums of dy and dy*zhat): a streaming kernel of its own, or -- round 2 -- already done by the
       // LDS-staged epilogue of the planes GEMM that produced `gin` (round 1 tried it in the dword-per-lane epilogue of
@@ -731,6 +760,31 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
       tn.e.split_k = splits;
       PL_TRY(launch_gemm_planes_pair(nn, tn, s));
       if (splits > 1) job(wsl, ly.gW, splits, H * H, 1, 0);
+    } else if (l > 0 && sl) {
+      // small batches: dX = dz W (+ the skip gradient) and the BatchNorm backward of the layer below in one launch when that
+      // layer belongs to this range; the weight gradient is one whole-K launch (K = B <= 64)
+      GemmArgs t = {};
+      t.arith = arith_of(d);
+      t.A = DZl; t.B = a_in; t.M = H; t.N = H; t.K = Bi; t.lda = H; t.ldb = H; t.ldc = H; t.split_k = 1; t.C = ly.gW;
+      // (the weight gradient as extra workgroups of the same launch: POSELIFT_SMALL_DW=0 keeps it a launch of its own, A/B)
+      static const bool dw_off = [] { const char* e = getenv("POSELIFT_SMALL_DW"); return e && e[0] == '0'; }();
+      const bool dw_rides = !dw_off && H % 128 == 0;
+      if (l - 1 >= l_lo) {
+        const Layer lo = layer_of(d, P, grads, l - 1);
+        PL_TRY(launch_small_layer_bwd(DZl, ly.W, (l % 2 == 1) ? GA : nullptr, (l % 2 == 1) ? GA : nullptr, Bi, H, H,
+                                      f32(ws, w.z[l - 1]), u64(ws, w.bits[l - 1]), l - 1 == 0, f32(ws, w.mean[l - 1]),
+                                      f32(ws, w.rstd[l - 1]), lo.gamma, kscale, dzbuf(l - 1), lo.ggamma, lo.gbeta, lo.gb, s,
+                                      dw_rides ? a_in : nullptr, dw_rides ? ly.gW : nullptr));
+        if (dw_rides) continue;
+      } else {
+        GemmArgs g = {};
+        g.A = DZl; g.B = ly.W; g.M = Bi; g.N = H; g.K = H; g.lda = H; g.ldb = H; g.ldc = H; g.split_k = 1;
+        if (l % 2 == 1) { g.C = GA; g.addend = GA; } else { g.C = GB; }
+        g.arith = arith_of(d);
+        g.thin_scratch = slabs; g.thin_scratch_floats = w.slab_floats;
+        PL_TRY(launch_gemm_f32(kNN, g, s));
+      }
+      PL_TRY(launch_gemm_f32(kTN, t, s));
     } else if (l > 0) {
       // da_in = dz W and dW = dz^T a_in share dz and are independent: ONE launch.  A residual
       // block's first Linear also receives the skip gradient (in GA, added in the epilogue).

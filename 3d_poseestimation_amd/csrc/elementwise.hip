@@ -10,6 +10,7 @@
 // fully coalesced).  Every column reduction is a fixed-order two-stage sum (per-block
 // partials, then a small finalize kernel): results are bitwise reproducible, no float
 // atomics anywhere.
+#include "bn_pieces.h"
 #include "philox.h"
 #include <stdlib.h>
 
@@ -78,16 +79,7 @@ __device__ __forceinline__ float bn_m2_term(float gsum, float gm2, float fn, flo
   const float d = gsum / fn - mean;
   return gm2 + fn * d * d;
 }
-__device__ __forceinline__ float bn_shift_of(float beta, float mean, float sc) {
-#pragma clang fp contract(off)
-  return beta - mean * sc;
-}
-__device__ __forceinline__ void bn_running_update(float& rm, float& rv, float mean, float var, float Bt, float mo) {
-#pragma clang fp contract(off)
-  const float unbiased = var * (Bt / (Bt - 1.0f));
-  rm = (1.0f - mo) * rm + mo * mean;
-  rv = (1.0f - mo) * rv + mo * unbiased;
-}
+// (bn_shift_of, bn_running_update: bn_pieces.h)
 
 // BatchNorm statistics finalize: Chan merge of (sum, M2) over 64-row groups.
 // stat = [world][2][G][H] (rank-major: G rows of sums, then G rows of M2); Br rows per rank.  Walking
@@ -558,7 +550,8 @@ __global__ __launch_bounds__(kSmallThreads) void bn_small_fwd_kernel(
 
 // backward head of one hidden layer for a small batch: pass 1 (sum dy, sum dy zhat), the coefficients, dz = c0 (dy - c1 -
 // zhat c2), the bias gradient and dgamma / dbeta -- one workgroup per strip, the rows (masked dy and zhat) in registers
-template <int RU>
+// TILE: the bitmap is in the tile format of small_layer.hip (the layer's forward ran there)
+template <int RU, bool TILE>
 __global__ __launch_bounds__(kSmallThreads) void bn_small_bwd_kernel(
     const float* __restrict__ g, const uint64_t* __restrict__ bits, const float* __restrict__ z,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ gamma, float kscale, int B, int H,
@@ -580,7 +573,7 @@ __global__ __launch_bounds__(kSmallThreads) void bn_small_bwd_kernel(
       const int r = min(wave + 8 * u, B - 1);
       gv[u] = active ? ld4(g + (size_t)r * H + c) : zero;
       zv[u] = active ? ld4(z + (size_t)r * H + c) : zero;
-      const uint64_t* bw = bits + (size_t)r * wpr + strip * 4;
+      const uint64_t* bw = TILE ? bits + (size_t)(c >> 4) * 16 + (r >> 4) * 4 : bits + (size_t)r * wpr + strip * 4;
       b01[u] = *reinterpret_cast<const ulonglong2*>(bw);
       b23[u] = *reinterpret_cast<const ulonglong2*>(bw + 2);
     }
@@ -589,10 +582,11 @@ __global__ __launch_bounds__(kSmallThreads) void bn_small_bwd_kernel(
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
       const bool ok = wave + 8 * u < B;
-      dv[u].x = (ok && ((b01[u].x >> lane) & 1ull)) ? gv[u].x * kscale : 0.f;
-      dv[u].y = (ok && ((b01[u].y >> lane) & 1ull)) ? gv[u].y * kscale : 0.f;
-      dv[u].z = (ok && ((b23[u].x >> lane) & 1ull)) ? gv[u].z * kscale : 0.f;
-      dv[u].w = (ok && ((b23[u].y >> lane) & 1ull)) ? gv[u].w * kscale : 0.f;
+      const int bit = TILE ? ((min(wave + 8 * u, B - 1) & 15) * 4 + (lane & 3)) : lane;
+      dv[u].x = (ok && ((b01[u].x >> bit) & 1ull)) ? gv[u].x * kscale : 0.f;
+      dv[u].y = (ok && ((b01[u].y >> bit) & 1ull)) ? gv[u].y * kscale : 0.f;
+      dv[u].z = (ok && ((b23[u].x >> bit) & 1ull)) ? gv[u].z * kscale : 0.f;
+      dv[u].w = (ok && ((b23[u].y >> bit) & 1ull)) ? gv[u].w * kscale : 0.f;
       zh[u] = ok ? make_float4((zv[u].x - mu.x) * rs.x, (zv[u].y - mu.y) * rs.y, (zv[u].z - mu.z) * rs.z, (zv[u].w - mu.w) * rs.w) : zero;
     }
   }
@@ -1487,12 +1481,17 @@ int launch_bn_small_fwd(const float* z, const float* gamma, const float* beta, f
 
 int launch_bn_small_bwd(const float* g, const uint64_t* bits, const float* z, const float* mean, const float* rstd,
                         const float* gamma, float keep_scale, int B, int H, float* dz, float* dgamma, float* dbeta, float* dbias,
-                        hipStream_t s) {
+                        hipStream_t s, bool tile_bits) {
   if (!g || !bits || !z || !dz || !dgamma || !dbeta || !dbias || B < 1 || (H & 3)) PL_FAIL(PL_EINVAL, "bn_small_bwd: bad arguments");
   if (B > kBnSmallRows) PL_FAIL(PL_ESHAPE, "bn_small_bwd: B=%d", B);
   const dim3 grid((H + 255) / 256), block(kSmallThreads);
-  hipLaunchKernelGGL((bn_small_bwd_kernel<8>), grid, block, 0, s, g, bits, z, mean, rstd, gamma, keep_scale, B, H, dz, dgamma,
-                     dbeta, dbias);
+  if (tile_bits && (H & 255)) PL_FAIL(PL_ESHAPE, "bn_small_bwd: tile-format bitmap with H=%d", H);
+  if (tile_bits)
+    hipLaunchKernelGGL((bn_small_bwd_kernel<8, true>), grid, block, 0, s, g, bits, z, mean, rstd, gamma, keep_scale, B, H, dz,
+                       dgamma, dbeta, dbias);
+  else
+    hipLaunchKernelGGL((bn_small_bwd_kernel<8, false>), grid, block, 0, s, g, bits, z, mean, rstd, gamma, keep_scale, B, H, dz,
+                       dgamma, dbeta, dbias);
   PL_CHECK_LAUNCH("bn_small_bwd");
   return PL_OK;
 }

@@ -197,7 +197,20 @@ int launch_bn_small_fwd(const float* z, const float* gamma, const float* beta, f
                         const uint64_t* step_dev);
 int launch_bn_small_bwd(const float* g, const uint64_t* bits, const float* z, const float* mean, const float* rstd,
                         const float* gamma, float keep_scale, int B, int H, float* dz, float* dgamma, float* dbeta, float* dbias,
-                        hipStream_t s);
+                        hipStream_t s, bool tile_bits = false);
+// Small batches, hidden layers behind the first (small_layer.hip): a workgroup owns 16 columns for all B <= 64 rows, so one
+// launch is Linear + BatchNorm1d (batch statistics) + ReLU + Dropout (+ skip) forward, and one launch is dX = dz W (+ skip
+// gradient) followed by the BatchNorm backward of the layer below.  Their ReLU & keep bitmap is in the "tile format" of
+// small_layer.hip (tile_bits above: bn_small_bwd reading such a layer).  POSELIFT_SMALL_LAYER=0 switches them off (A/B).
+bool small_layer_ok(int B, int H, int K);
+int launch_small_layer_fwd(const float* a, const float* W, const float* bias, const float* gamma, const float* beta, float eps,
+                           float momentum, float* rm, float* rv, int64_t* nbt, float* mean, float* rstd, const float* resid,
+                           float* z, float* act, uint64_t* bits, int B, int H, int K, float pdrop, uint64_t seed, uint64_t step,
+                           int layer, const uint64_t* inject_keep, hipStream_t s, const uint64_t* step_dev);
+int launch_small_layer_bwd(const float* dz, const float* W, const float* addend, float* gout, int B, int H, int K,
+                           const float* z_lo, const uint64_t* bits_lo, bool rowbits, const float* mean_lo, const float* rstd_lo,
+                           const float* gamma_lo, float kscale, float* dz_lo, float* dgamma, float* dbeta, float* dbias,
+                           hipStream_t s, const float* a_in = nullptr, float* dW = nullptr);   // dW != NULL: + dW = dz^T a_in
 // eval-mode BatchNorm for the saved-state forward: mean := running mean, rstd := rsqrt(running var + eps), scale, shift
 int launch_bn_eval_stats(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int H,
                          float* mean, float* rstd, float* scale, float* shift, hipStream_t s);

@@ -85,3 +85,15 @@ def unpack_bitmap(words, hidden):
     l = np.arange(64, dtype=np.uint64)[None, None, :, None]
     bits = ((w >> l) & np.uint64(1)).astype(bool)                   # [b][q][l][j]
     return bits.reshape(B, strips * 256)[:, :hidden]
+
+
+def unpack_bitmap_tile(words, rows, hidden):
+    """The tile-format bitmap of the small-batch layer kernels (include/poselift.h, pl_workspace_bitmap_format = 1):
+    `hidden` words -> (rows, hidden) bool."""
+    import numpy as np
+    words = np.asarray(words, dtype=np.uint64).reshape(-1)
+    r = np.arange(rows)[:, None]
+    c = np.arange(hidden)[None, :]
+    w = words[(c >> 4) * 16 + (r >> 4) * 4 + (c & 3)]
+    bit = ((r & 15) * 4 + ((c >> 2) & 3)).astype(np.uint64)
+    return ((w >> bit) & np.uint64(1)).astype(bool)

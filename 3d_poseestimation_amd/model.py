@@ -437,7 +437,15 @@ class LinearModel(nn.Module):
         if which in (0, 1):
             return raw.view(torch.float32).view(ws["B"], H)
         if which == 2:
-            return raw.view(torch.int64).view(ws["B"], bitmap_words_per_row(H))
+            # always handed out in the row format (layout.unpack_bitmap); small batches keep a tile format on the device
+            fmt = _lib.lib().pl_workspace_bitmap_format(ctypes.byref(self._desc), ws["B"], layer)
+            _lib.check(min(fmt, 0), "pl_workspace_bitmap_format")
+            words = raw.view(torch.int64)
+            if fmt == 1:
+                from .layout import pack_keep_bitmap, unpack_bitmap_tile
+                on = unpack_bitmap_tile(words[:H].cpu().numpy().view("uint64"), ws["B"], H)
+                return torch.from_numpy(pack_keep_bitmap(on).view("int64")).to(raw.device)
+            return words[:ws["B"] * bitmap_words_per_row(H)].view(ws["B"], bitmap_words_per_row(H))
         return raw.view(torch.float32)
 
     # ------------------------------------------------------------------ launches

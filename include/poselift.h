@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PL_VERSION 106 /* 0.1.6: + pl_counter_add; 0.1.5: + pl_flip_pose_ex, pl_flip_w_nhwc (phase5 Flip branch); 0.1.4: + pl_planes_split_strided; 0.1.3: + pl_bn_join_bwd (0.1.2: operand-plane outputs of the BatchNorm / join kernels, pl_gemm_planes_raw) */
+#define PL_VERSION 107 /* 0.1.7: + pl_workspace_bitmap_format (small-batch layer kernels); 0.1.6: + pl_counter_add; 0.1.5: + pl_flip_pose_ex, pl_flip_w_nhwc (phase5 Flip branch); 0.1.4: + pl_planes_split_strided; 0.1.3: + pl_bn_join_bwd (0.1.2: operand-plane outputs of the BatchNorm / join kernels, pl_gemm_planes_raw) */
 
 typedef enum PLStatus {
   PL_OK = 0,
@@ -128,6 +128,12 @@ size_t pl_workspace_bytes(const PLDesc* d, int64_t B);
  * output incl. residual), 2 keep&relu bitmap, 3 batch mean, 4 batch rstd.           */
 int pl_workspace_view(const PLDesc* d, int64_t B, int which, int64_t layer,
                       size_t* offset_bytes, size_t* size_bytes);
+/* Layout of the bitmap of hidden layer `layer` after a training forward of B rows (which = 2 above):
+ *   0  row format: [B][4*ceil(H/256)] words; row r, 256-column strip q, word j: bit l <-> column 256 q + 4 l + j;
+ *   1  tile format (batches of <= 64 rows whose hidden layers run as ONE launch each, csrc/small_layer.hip): H words;
+ *      element (r, c) is bit (r & 15) * 4 + ((c >> 2) & 3) of word (c >> 4) * 16 + (r >> 4) * 4 + (c & 3).
+ * Negative = error code.  (Debug / test only: the backward pass knows by itself.) */
+int pl_workspace_bitmap_format(const PLDesc* d, int64_t B, int64_t layer);
 
 /* ---- forward ------------------------------------------------------------------- */
 /* model.eval(); model(x)   phase1_lifting/baselineModel.py:87-102 under

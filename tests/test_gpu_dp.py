@@ -69,6 +69,31 @@ def test_cut_backward_is_bitwise_the_one_call_backward(cuts):
         m.set_grad_sync(None, [7])
 
 
+@pytest.mark.parametrize("cuts", [[3], [4, 2], [5, 4, 3, 2, 1, 0], [0]])
+def test_cut_backward_of_a_small_batch(cuts):
+    """B <= 64: a hidden layer's dX GEMM and the BatchNorm backward of the layer below share a launch (small_layer.hip)
+    unless a cut separates them -- then the stand-alone kernels run.  Same gradients to round-off wherever the cuts are."""
+    import __graft_entry__ as ge
+    pkg = ge.build()
+    torch.manual_seed(0)
+    m = pkg.LinearModel(34, 51, linear_size=256, p_dropout=0.5).to("cuda:0").train()
+    x, y = pkg.synth.synthetic_batch(48, 3, "cuda:0")
+    grads = []
+    for sync in (None, _FakeSync()):
+        m.set_grad_sync(sync, cuts)
+        m.zero_grad(set_to_none=True)
+        m.manual_seed(4, step=0)
+        xr = x.clone().requires_grad_(True)
+        pkg.mse_loss(m(xr).reshape(y.shape), y).backward()
+        grads.append((m.flat_grads.clone(), xr.grad.clone()))
+    for a, b in zip(grads[0], grads[1]):
+        assert (a - b).norm() <= 2e-5 * a.norm(), ((a - b).norm() / a.norm()).item()
+    for s, p in zip(m._slots, m._param_list):          # per tensor, the pre-BatchNorm biases (true gradient 0) aside
+        a, b = grads[0][0][s.offset:s.offset + s.numel], grads[1][0][s.offset:s.offset + s.numel]
+        if a.norm() > 1e-6 * grads[0][0].norm():
+            assert (a - b).norm() <= 5e-5 * a.norm(), (s.name, ((a - b).norm() / a.norm()).item())
+
+
 @pytest.mark.parametrize("rank", [0, 1])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16x6", "f16x3", "bf16"])
 def test_sync_bn_with_a_mirror_rank_is_the_doubled_batch(rank, dtype):

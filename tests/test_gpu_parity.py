@@ -498,6 +498,11 @@ def test_full_size_properties(pkg, full):
     (2, 64, 2, 34, 51, True, "fp32"),        # smallest batch BatchNorm accepts
     (3, 128, 1, 34, 51, True, "fp32"),
     (63, 128, 2, 34, 51, True, "fp32"),      # one short statistics group
+    (64, 1024, 2, 34, 51, True, "fp32"),     # the reference's own batch (train_1.py:194): one launch per hidden layer and
+    (37, 256, 2, 34, 51, True, "fp32"),      #   direction (small_layer.hip), ragged rows,
+    (2, 256, 1, 34, 51, True, "fp32"),       #   two rows,
+    (5, 256, 1, 34, 51, True, "fp32"),
+    (16, 512, 3, 51, 34, True, "f16x3"),     #   three stages, the other K split
     (65, 256, 2, 34, 51, True, "fp32"),      # 64 + 1 rows
     (100, 64, 2, 51, 34, True, "fp32"),      # the phase5 projector LinearModel(51, 34, linear_size=64)
     (129, 1024, 2, 34, 51, True, "fp32"),    # full width, ragged rows: whole-tile GEMMs fall back to edge path
@@ -532,8 +537,13 @@ def test_ragged_shapes_vs_oracle(pkg, B, H, S, i_dim, o_dim, bn, dtype):
     ograds, odx = orc.backward(st, cache, dpred)
     tol = 8e-2 if bf else 2e-4      # bf16-sized: the worst tensor (a BatchNorm weight gradient) sits at 4-7 %
     scale = np.abs(opred).max()
-    _close(pred.detach().cpu().numpy() / scale, opred / scale, 0, 3e-2 if bf else 2e-5)
-    _close(loss.item(), oloss, 2e-2 if bf else 2e-5, 0)
+    # (two rows of 256 columns: BatchNorm maps z0, z1 to +-d / sqrt(d^2 + eps) with d = (z0 - z1) / 2 -- where d is small the
+    #  round-off of z is amplified by up to 1 / sqrt(eps) = 316, once per BatchNorm on the way: the stand-alone kernels sit at
+    #  7e-5 on this case's forward, too; the case is here for the two-row code paths, (5, 256) for their accuracy)
+    two_rows = 30.0 if (B == 2 and H >= 256) else 1.0
+    tol *= two_rows
+    _close(pred.detach().cpu().numpy() / scale, opred / scale, 0, 3e-2 if bf else 2e-5 * two_rows)
+    _close(loss.item(), oloss, 2e-2 if bf else 2e-5 * two_rows, 0)
     got = _grads(m)
     for k, v in ograds.items():
         if bn and k.endswith(".bias") and "batch_norm" not in k and k != "w2.bias":
@@ -548,7 +558,7 @@ def test_ragged_shapes_vs_oracle(pkg, B, H, S, i_dim, o_dim, bn, dtype):
         ye = m(x.detach()).cpu().numpy()
     st2 = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
     yo, _ = orc.forward(st2, xn, num_stage=S, train=False, use_bn=bn)
-    _close(ye / scale, yo / scale, 0, 3e-2 if bf else 2e-5)
+    _close(ye / scale, yo / scale, 0, 3e-2 if bf else 2e-5 * two_rows)
 
 
 # ---------------------------------------------------------------------------- bf16 arithmetic mode
