@@ -108,6 +108,13 @@ inline bool bn_small_ok(const PLDesc* d, bool planes, int64_t B) {
 inline bool small_layer_on(const PLDesc* d, bool planes, int64_t B) {
   return bn_small_ok(d, planes, B) && small_layer_ok((int)B, d->hidden, d->hidden);
 }
+// ... the first layer's forward likewise (tile-format bitmap for layer 0, too), and the top of the backward pass in one launch
+inline bool small_first_on(const PLDesc* d, bool planes, int64_t B) { return small_layer_on(d, planes, B) && small_first_ok(d->in_dim); }
+inline bool small_top_on(const PLDesc* d, bool planes, int64_t B) { return small_layer_on(d, planes, B) && small_top_ok(d->out_dim); }
+// the fused train step at small batch: no launch for the output Linear (the last hidden layer's launch leaves its slabs)
+inline bool small_head_on(const PLDesc* d, bool planes, int64_t B) {
+  return small_top_on(d, planes, B) && (d->num_stage > 0 || small_first_on(d, planes, B));
+}
 inline int arith_of(const PLDesc* d) { return d->dtype == PL_F16X3 ? (int)PL_BF16X6 : d->dtype; }
 
 struct ParamLayout {
@@ -221,12 +228,13 @@ Ws plan(const PLDesc* d, int64_t B) {
     slab = std::max(slab, (size_t)skinny_chunks((int)B) * std::max(d->in_dim, d->out_dim) * H * 4);
     slab = std::max(slab, skinny_narrow_out_part_floats((int)B, H) * 4);
     if (B <= thin_gemm_max_m() && B % 128) slab = std::max(slab, thin_gemm_scratch_floats((int)B, H, H) * 4);
+    if (B <= kBnSmallRows) slab = std::max(slab, (size_t)(H / 16 + 1) * B * 64 * 4);    // output-layer slabs of small_layer.hip
   }
   w.slab_floats = slab / 4;
   w.slabs = take(slab);
   w.outpart = take((size_t)std::max(colsum_chunks((int)B), skinny_in_chunks((int)B)) * d->out_dim * 4);
   w.dyout = take((size_t)B * d->out_dim * 4);                 // d loss / d y of the fused train step
-  w.mse = take(pl_mse_scratch_bytes(B * d->out_dim));
+  w.mse = take(std::max(pl_mse_scratch_bytes(B * d->out_dim), (size_t)256));        // (64 partials of launch_small_mse)
   w.dzp = w.amax = w.dzscale = 0;
   w.skp_out = take((size_t)skinny_in_chunks((int)B) * d->out_dim * H * 4);
   w.skp_in = take((size_t)skinny_in_chunks((int)B) * d->in_dim * H * 4);
@@ -450,7 +458,8 @@ extern "C" int pl_workspace_view(const PLDesc* d, int64_t B, int which, int64_t 
 extern "C" int pl_workspace_bitmap_format(const PLDesc* d, int64_t B, int64_t layer) {
   PL_TRY(check_desc(d, false));
   if (B <= 0 || layer < 0 || layer >= 1 + 2 * (int64_t)d->num_stage) PL_FAIL(PL_EINVAL, "pl_workspace_bitmap_format: bad arguments");
-  return (layer > 0 && small_layer_on(d, planes_kind(d, B) != 0, B)) ? 1 : 0;
+  const bool planes = planes_kind(d, B) != 0;
+  return (layer > 0 ? small_layer_on(d, planes, B) : small_first_on(d, planes, B)) ? 1 : 0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -543,6 +552,8 @@ static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, 
   const float* a_in = x;
   const int64_t BH = B * H;
   if (w.planes) PL_TRY(split_weight_planes(d, P, w, ws, s));
+  // (small batches, fused train step: the last hidden layer's launch leaves the output Linear's slabs -- small_layer.hip)
+  const bool head_slabs = defer_out_reduce && !eval_bn && bn_small(d, w, B) && small_head_on(d, w.planes, B);
   for (int l = 0; l < w.L; ++l) {
     const Layer ly = layer_of(d, P, nullptr, l);
     GemmArgs g = {};
@@ -555,13 +566,16 @@ static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, 
     float* stat = f32(ws, w.stat);
     // small batches: statistics, finalize and apply in ONE launch straight from z (bn_small_fwd_kernel) -- no partials
     const bool small = bn_small(d, w, B) && !eval_bn;
-    if (small && l > 0 && small_layer_on(d, w.planes, B)) {
-      // ... and behind the first layer the Linear rides in the same launch
+    if (small && (l > 0 ? small_layer_on(d, w.planes, B) : small_first_on(d, w.planes, B))) {
+      // ... and the Linear rides in the same launch
       const float* resid = (l >= 2 && (l % 2) == 0) ? f32(ws, w.act[l - 2]) : nullptr;
+      const bool slabs_here = head_slabs && l == w.L - 1;
       PL_TRY(launch_small_layer_fwd(a_in, ly.W, ly.b, ly.gamma, ly.beta, d->bn_eps, d->bn_momentum, ly.rm, ly.rv, ly.nbt,
                                     f32(ws, w.mean[l]), f32(ws, w.rstd[l]), resid, g.C, f32(ws, w.act[l]), u64(ws, w.bits[l]),
                                     (int)B, H, ly.K, d->p_dropout, seed, step, l,
-                                    inject_keep ? inject_keep + (size_t)l * inj_stride : nullptr, s, d->step_dev));
+                                    inject_keep ? inject_keep + (size_t)l * inj_stride : nullptr, s, d->step_dev, l == 0,
+                                    slabs_here ? d->params + P.off[4 * w.L] : nullptr, slabs_here ? f32(ws, w.slabs) : nullptr,
+                                    d->out_dim));
       a_in = f32(ws, w.act[l]);
       continue;
     }
@@ -612,6 +626,7 @@ static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, 
                            eval_bn ? nullptr : d->step_dev));
     a_in = act;
   }
+  if (head_slabs) return PL_OK;
   if (defer_out_reduce)   // (the fused train step: y = bias + slabs is formed by the MSE pass, mse_partial_from_slabs)
     return launch_skinny_narrow_out(a_in, d->params + P.off[4 * w.L], d->params + P.off[4 * w.L + 1], y, (int)B, H, d->out_dim,
                                     f32(ws, w.slabs), s, false);
@@ -630,7 +645,7 @@ static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, 
 // mse_final_kernel's sum) and the device step counter ticks there, instead of in a launch of their own after the forward.
 static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B, void* ws, size_t ws_bytes,
                     float* dx, float* grads, void* stream, bool do_output, int l_hi, int l_lo, bool eval_bn = false,
-                    float* loss_out = nullptr) {
+                    float* loss_out = nullptr, int loss_partials = 0) {
   PL_TRY(check_desc(d, true));
   if (!x || !dy || !grads) PL_FAIL(PL_EINVAL, "pl_lifter_bwd: null x/dy/flat_grads");
   if (B <= 0) PL_FAIL(PL_ESHAPE, "pl_lifter_bwd: B=%lld", (long long)B);
@@ -652,7 +667,23 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
     jpart.push_back(part); jout.push_back(out); jR.push_back(R); jH.push_back(Hj); jkind.push_back(kind); jtrans.push_back(transK);
   };
 
-  if (do_output) {
+  // small batches (small_layer.hip): which layers' forward left a tile-format bitmap, and what describes a layer's BatchNorm
+  const bool sl_all = bn_small(d, w, B) && !eval_bn && small_layer_on(d, w.planes, B);
+  const bool sl_first = sl_all && small_first_on(d, w.planes, B);
+  auto bn_layer = [&](int l) {
+    const Layer y = layer_of(d, P, grads, l);
+    SmallBnLayer b = {f32(ws, w.z[l]), f32(ws, w.mean[l]), f32(ws, w.rstd[l]), y.gamma, u64(ws, w.bits[l]),
+                      l == 0 && !sl_first, y.ggamma, y.gbeta, y.gb};
+    return b;
+  };
+  // the output layer and the BatchNorm backward of the top hidden layer in one launch (dz of that layer: DZ)
+  const int n_loss_part = loss_partials > 0 ? loss_partials : mse_partials(B * O);   // partial sums of the loss in w.mse
+  const bool top_fused = do_output && sl_all && small_top_on(d, w.planes, B) && l_hi == w.L - 1 && l_hi >= l_lo;
+  if (top_fused) {
+    PL_TRY(launch_small_top_bwd(dy, d->params + P.off[4 * w.L], f32(ws, w.act[w.L - 1]), Bi, H, O, GA, grads + P.off[4 * w.L],
+                                grads + P.off[4 * w.L + 1], bn_layer(w.L - 1), kscale, DZ, s, f32(ws, w.mse),
+                                n_loss_part, 1.0f / (float)(B * O), loss_out, const_cast<uint64_t*>(d->step_dev)));
+  } else if (do_output) {
   // final Linear (LinearModel.w2): dW = dy^T h, db = sum dy, g = dy W
   const float* W5 = d->params + P.off[4 * w.L];
   const float* h_last = f32(ws, w.act[w.L - 1]);
@@ -687,6 +718,7 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
   }
   }  // do_output
 
+  bool first_wgrad_done = false;
   for (int l = l_hi; l >= l_lo; --l) {
     const Layer ly = layer_of(d, P, grads, l);
     // gradient w.r.t. this layer's activation: GA for layer 0 and even layers, GB for odd ones
@@ -703,12 +735,12 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
     const bool sl = small && small_layer_on(d, w.planes, B);
     auto dzbuf = [&](int layer) { return (sl && (layer & 1)) ? GB : DZ; };   // (alternating: a launch reads dz_l and writes dz_{l-1})
     float* DZl = dzbuf(l);
-    if (small && sl && l < l_hi) {
-      // (nothing: done by launch_small_layer_bwd of layer l + 1)
+    if (small && sl && (l < l_hi || top_fused)) {
+      // (nothing: done by launch_small_layer_bwd of layer l + 1 / by launch_small_top_bwd)
     } else if (small) {
       // pass 1, the coefficients, dz, the bias gradient and dgamma / dbeta of this layer in one launch (small batches)
       PL_TRY(launch_bn_small_bwd(gin, bits, z, f32(ws, w.mean[l]), f32(ws, w.rstd[l]), ly.gamma, kscale, Bi, H, DZl, ly.ggamma,
-                                 ly.gbeta, ly.gb, s, sl && l > 0));
+                                 ly.gbeta, ly.gb, s, sl && (l > 0 || sl_first)));
     } else if (d->bn) {
       // pass 1 (column sums of dy and dy*zhat): a streaming kernel of its own, or -- round 2 -- already done by the
       // LDS-staged epilogue of the planes GEMM that produced `gin` (round 1 tried it in the dword-per-lane epilogue of
@@ -770,11 +802,12 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
       static const bool dw_off = [] { const char* e = getenv("POSELIFT_SMALL_DW"); return e && e[0] == '0'; }();
       const bool dw_rides = !dw_off && H % 128 == 0;
       if (l - 1 >= l_lo) {
-        const Layer lo = layer_of(d, P, grads, l - 1);
+        // (l == 1: the first layer's weight gradient dW1 = dz_0^T x follows its BatchNorm backward in the same workgroups)
+        first_wgrad_done = l == 1 && small_first_ok(d->in_dim);
         PL_TRY(launch_small_layer_bwd(DZl, ly.W, (l % 2 == 1) ? GA : nullptr, (l % 2 == 1) ? GA : nullptr, Bi, H, H,
-                                      f32(ws, w.z[l - 1]), u64(ws, w.bits[l - 1]), l - 1 == 0, f32(ws, w.mean[l - 1]),
-                                      f32(ws, w.rstd[l - 1]), lo.gamma, kscale, dzbuf(l - 1), lo.ggamma, lo.gbeta, lo.gb, s,
-                                      dw_rides ? a_in : nullptr, dw_rides ? ly.gW : nullptr));
+                                      bn_layer(l - 1), kscale, dzbuf(l - 1), s, dw_rides ? a_in : nullptr,
+                                      dw_rides ? ly.gW : nullptr, first_wgrad_done ? x : nullptr,
+                                      first_wgrad_done ? grads + P.off[0] : nullptr, d->in_dim));
         if (dw_rides) continue;
       } else {
         GemmArgs g = {};
@@ -803,6 +836,8 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
       t.split_k = splits; t.C = splits > 1 ? slabs : ly.gW;
       PL_TRY(launch_gemm_f32_pair(g, t, s));
       if (splits > 1) PL_TRY(launch_reduce_slabs(slabs, splits, (int64_t)H * H, ly.gW, s));
+    } else if (first_wgrad_done) {
+      // (layer 0's weight gradient came with its BatchNorm backward, small_layer.hip)
     } else if (skinny_supported(ly.K, H)) {
       PL_TRY(launch_skinny_wide_in(a_in, DZ, ly.gW, Bi, ly.K, H, true, f32(ws, w.skp_in), s, false));
       job(f32(ws, w.skp_in), ly.gW, skinny_in_chunks(Bi), ly.K * H, 0, ly.K);
@@ -818,9 +853,9 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
   }
   float inv_n = 0.f;
   uint64_t* tick = nullptr;
-  if (loss_out) {
+  if (loss_out && !top_fused) {
     const int64_t n = B * O;
-    job(f32(ws, w.mse), loss_out, mse_partials(n), 1, 2, 0);
+    job(f32(ws, w.mse), loss_out, n_loss_part, 1, 2, 0);
     inv_n = 1.0f / (float)n;
     tick = const_cast<uint64_t*>(d->step_dev);
   }
@@ -1136,11 +1171,19 @@ extern "C" int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const fl
   PL_TRY(check_ws(w, ws, ws_bytes));
   float* dy = f32(ws, w.dyout);
   const int L = 1 + 2 * d->num_stage;
+  bool small_head = false;      // the loss partials in w.mse are launch_small_mse's
   if (hi == L) {
     const int H = d->hidden, O = d->out_dim;
     static const bool head_off = [] { const char* e = getenv("POSELIFT_HEAD_UNFUSED"); return e && e[0] == '1'; }();
     const int so = skinny_narrow_out_supported(H, O) ? skinny_narrow_out_splits((int)B, H) : 0;
-    if (!head_off && so && mse_from_slabs_supported(so, O)) {
+    if (!head_off && bn_small(d, w, B) && small_head_on(d, w.planes, B)) {
+      // small batches: the output Linear's slabs come from the last hidden layer's launch (small_layer.hip)
+      PL_TRY(fwd_saved_impl(d, x, y, B, ws, ws_bytes, seed, step, nullptr, stream, false, true));
+      const ParamLayout P = param_layout(d);
+      PL_TRY(launch_small_mse(f32(ws, w.slabs), H / 16, (int)B, O, d->params + P.off[4 * L + 1], target, 1.0f, y, dy,
+                              f32(ws, w.mse), (hipStream_t)stream));
+      small_head = true;
+    } else if (!head_off && so && mse_from_slabs_supported(so, O)) {
       // the output Linear's slab reduce folded into the MSE pass: one launch less, the same bits
       PL_TRY(fwd_saved_impl(d, x, y, B, ws, ws_bytes, seed, step, nullptr, stream, false, true));
       const ParamLayout P = param_layout(d);
@@ -1152,5 +1195,5 @@ extern "C" int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const fl
     }
   }
   return bwd_impl(d, x, dy, B, ws, ws_bytes, nullptr, grads, stream, hi == L, hi == L ? L - 1 : hi, lo, false,
-                  hi == L ? loss : nullptr);
+                  hi == L ? loss : nullptr, small_head ? small_mse_partials((int)B, d->out_dim) : 0);
 }

@@ -203,14 +203,38 @@ int launch_bn_small_bwd(const float* g, const uint64_t* bits, const float* z, co
 // gradient) followed by the BatchNorm backward of the layer below.  Their ReLU & keep bitmap is in the "tile format" of
 // small_layer.hip (tile_bits above: bn_small_bwd reading such a layer).  POSELIFT_SMALL_LAYER=0 switches them off (A/B).
 bool small_layer_ok(int B, int H, int K);
+// ... the first layer (K = in_dim <= 256 inputs: contraction on the vector unit) forward, its weight gradient in the backward
+// launch of the layer above, and the whole top of the backward pass (g = dy W2, BatchNorm backward of the last hidden layer,
+// dW2, db2; out_dim <= 64) as one launch.  POSELIFT_SMALL_ENDS=0 switches these off (A/B).
+bool small_first_ok(int K);
+bool small_top_ok(int O);
 int launch_small_layer_fwd(const float* a, const float* W, const float* bias, const float* gamma, const float* beta, float eps,
                            float momentum, float* rm, float* rv, int64_t* nbt, float* mean, float* rstd, const float* resid,
                            float* z, float* act, uint64_t* bits, int B, int H, int K, float pdrop, uint64_t seed, uint64_t step,
-                           int layer, const uint64_t* inject_keep, hipStream_t s, const uint64_t* step_dev);
+                           int layer, const uint64_t* inject_keep, hipStream_t s, const uint64_t* step_dev, bool first = false,
+                           const float* W2 = nullptr, float* ypart = nullptr, int O = 0);
+// ypart != NULL (the last hidden layer of a fused train step): the launch also leaves its share of the output Linear,
+// ypart [H / 16][B][64] (columns < O); launch_small_mse adds the slabs up: y, dpred = grad_scale * 2 (y - t) / (B O) and
+// small_mse_partials(B, O) partial sums of (y - t)^2 -- no launch for the output layer, none for its slab reduce
+int small_mse_partials(int B, int O);     // partial sums launch_small_mse leaves in mpart (<= 64)
+int launch_small_mse(const float* ypart, int NS, int B, int O, const float* bias, const float* tgt, float grad_scale, float* y,
+                     float* dpred, float* mpart, hipStream_t s);
+// what the BatchNorm backward of a layer reads and writes (besides its incoming gradient and dz)
+struct SmallBnLayer {
+  const float *z, *mean, *rstd, *gamma;
+  const uint64_t* bits;
+  bool rowbits;                           // bitmap in the row format (the layer's forward was bn_small_fwd_kernel)
+  float *dgamma, *dbeta, *dbias;
+};
+// g = dz W (+ addend) -> gout (or NULL), then the BatchNorm backward of the layer below -> dz_lo;
+// dW != NULL: + dW = dz^T a_in (extra workgroups); dW1 != NULL: the layer below is the first one, + dW1 = dz_lo^T x1
 int launch_small_layer_bwd(const float* dz, const float* W, const float* addend, float* gout, int B, int H, int K,
-                           const float* z_lo, const uint64_t* bits_lo, bool rowbits, const float* mean_lo, const float* rstd_lo,
-                           const float* gamma_lo, float kscale, float* dz_lo, float* dgamma, float* dbeta, float* dbias,
-                           hipStream_t s, const float* a_in = nullptr, float* dW = nullptr);   // dW != NULL: + dW = dz^T a_in
+                           const SmallBnLayer& below, float kscale, float* dz_lo, hipStream_t s, const float* a_in = nullptr,
+                           float* dW = nullptr, const float* x1 = nullptr, float* dW1 = nullptr, int K1 = 0);
+int launch_small_top_bwd(const float* dy, const float* W2, const float* h, int B, int H, int O, float* gout, float* dW2,
+                         float* db2, const SmallBnLayer& top, float kscale, float* dz_top, hipStream_t s,
+                         const float* mpart = nullptr, int np = 0, float inv_n = 0.f, float* loss = nullptr,
+                         uint64_t* tick = nullptr);   // loss != NULL: + loss = inv_n * sum of the np partials, tick += 1
 // eval-mode BatchNorm for the saved-state forward: mean := running mean, rstd := rsqrt(running var + eps), scale, shift
 int launch_bn_eval_stats(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int H,
                          float* mean, float* rstd, float* scale, float* shift, hipStream_t s);

@@ -174,26 +174,22 @@ struct FwdArgs {
   float eps, momentum, kscale;
   int B, H, K, mode;
   uint32_t thr, k0, k1, c3, layer, seed_hi;
+  // the last hidden layer of a fused train step: this workgroup's share of the output Linear, ypart[blk][B][64] (columns < O) =
+  // act[:, its 16 columns] W2[:, those columns]^T -- the slabs small_mse_kernel adds up (no launch for the output layer)
+  const float* W2;
+  float* ypart;
+  int O;
 };
 
-template <int STEPS, int ABL = 0>
-__global__ __launch_bounds__(NTHR) void small_fwd_kernel(FwdArgs p) {
-  __shared__ float part[NWAVE * ROWS * COLS];
-  __shared__ float stage[NWAVE * STAGE];
-  __shared__ float4 sm[4][4];
-  const int blk = col_block(blockIdx.x, gridDim.x);
-  const int c0 = blk * COLS;
-  if (ABL != 1) contract<STEPS, false, ABL>(p.a, p.K, p.B, p.W, p.K, c0, part, stage);
-  __syncthreads();
+// everything behind the Linear: z (bias included; thread tid < 256 holds row tid >> 2, columns c .. c + 3 of block blk)
+// Returns the thread's four outputs (zeros outside the batch and for threads >= 256).
+__device__ __forceinline__ float4 fwd_tail(const FwdArgs& p, float4 z, int blk, int c, float4 (*sm)[4]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = tid >> 2, c = c0 + 4 * (tid & 3);
+  const int r = tid >> 2;
   const bool live = tid < 256 && r < p.B;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 z = zero, ga = zero, be = zero, rv = zero;
+  float4 ga = zero, be = zero, rv = zero;
   if (tid < 256) {
-    z = gather_part(part);
-    const float4 b = ld4(p.bias + c);
-    z.x += b.x; z.y += b.y; z.z += b.z; z.w += b.w;
     ga = ld4(p.gamma + c); be = ld4(p.beta + c);
     if (p.resid && live) rv = ld4(p.resid + (size_t)r * p.H + c);
   }
@@ -209,7 +205,7 @@ __global__ __launch_bounds__(NTHR) void small_fwd_kernel(FwdArgs p) {
     q[0] = make_float4(dx * dx, dy * dy, dz * dz, dw * dw);
   }
   colsum<1>(q, sm);
-  if (tid >= 256) return;
+  if (tid >= 256) return zero;
   const float var[4] = {q[0].x / Bt, q[0].y / Bt, q[0].z / Bt, q[0].w / Bt};
   const float mu[4] = {mean.x, mean.y, mean.z, mean.w};
   const float g4[4] = {ga.x, ga.y, ga.z, ga.w}, b4[4] = {be.x, be.y, be.z, be.w};
@@ -272,7 +268,82 @@ __global__ __launch_bounds__(NTHR) void small_fwd_kernel(FwdArgs p) {
     if (lane == j) word = bal;
   }
   if (lane < 4) p.bits[(size_t)blk * 16 + wave * 4 + lane] = word;
-  if (live) st4(p.act + (size_t)r * p.H + c, make_float4(o[0] + rv.x, o[1] + rv.y, o[2] + rv.z, o[3] + rv.w));
+  const float4 out = make_float4(o[0] + rv.x, o[1] + rv.y, o[2] + rv.z, o[3] + rv.w);
+  if (live) st4(p.act + (size_t)r * p.H + c, out);
+  return live ? out : zero;
+}
+
+// the workgroup's slab of the output Linear (FwdArgs.ypart): hs = the act tile [64][16] from the threads' registers, ws = the
+// 16 columns of W2 [O][17] (odd stride: lanes walk o); thread t handles (row idx >> 6, output idx & 63), an fmaf chain over the
+// 16 columns in order.  Every thread of the workgroup calls it.
+__device__ __forceinline__ void head_slab(const FwdArgs& p, float4 out, int blk, int c0, float* hs, float* ws) {
+  const int tid = threadIdx.x;
+  if (tid < 256) st4(hs + tid * 4, out);
+  for (int idx = tid; idx < p.O * COLS; idx += NTHR) ws[(idx >> 4) * 17 + (idx & 15)] = p.W2[(size_t)(idx >> 4) * p.H + c0 + (idx & 15)];
+  __syncthreads();
+  float* mine = p.ypart + (size_t)blk * p.B * 64;
+  for (int idx = tid; idx < p.B * 64; idx += NTHR) {
+    const int r = idx >> 6, o = idx & 63;
+    if (o >= p.O) continue;
+    float acc = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < COLS; ++cc) acc = fmaf(hs[r * COLS + cc], ws[o * 17 + cc], acc);
+    mine[idx] = acc;
+  }
+}
+
+template <int STEPS, int ABL = 0>
+__global__ __launch_bounds__(NTHR) void small_fwd_kernel(FwdArgs p) {
+  __shared__ float part[NWAVE * ROWS * COLS];
+  __shared__ float stage[NWAVE * STAGE];
+  __shared__ float4 sm[4][4];
+  const int blk = col_block(blockIdx.x, gridDim.x);
+  const int c0 = blk * COLS;
+  if (ABL != 1) contract<STEPS, false, ABL>(p.a, p.K, p.B, p.W, p.K, c0, part, stage);
+  __syncthreads();
+  const int tid = threadIdx.x;
+  const int c = c0 + 4 * (tid & 3);
+  float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < 256) {
+    z = gather_part(part);
+    const float4 b = ld4(p.bias + c);
+    z.x += b.x; z.y += b.y; z.z += b.z; z.w += b.w;
+  }
+  const float4 out = fwd_tail(p, z, blk, c, sm);
+  if (p.ypart) head_slab(p, out, blk, c0, part, stage);     // (part and stage are free behind the barriers of fwd_tail)
+}
+
+// The FIRST hidden layer (LinearModel.w1: in_dim = 34 or 51 inputs, baselineModel.py:76,90-94): the contraction is 34 steps,
+// so x (all rows) and the workgroup's 16 rows of W1 sit in LDS and a thread forms its four outputs on the vector unit (an fmaf
+// chain over k in index order); the tail is the other layers'.  K <= kFirstMaxK.
+constexpr int kFirstMaxK = 256;                        // (64 + 16) rows of K floats in the stage array
+__global__ __launch_bounds__(NTHR) void small_first_fwd_kernel(FwdArgs p) {
+  __shared__ float stage[NWAVE * STAGE];
+  __shared__ float4 sm[4][4];
+  static_assert((ROWS + COLS) * kFirstMaxK <= NWAVE * STAGE, "stage array");
+  const int blk = col_block(blockIdx.x, gridDim.x);
+  const int c0 = blk * COLS;
+  const int tid = threadIdx.x, K = p.K;
+  float* xs = stage;
+  float* ws = stage + ROWS * K;
+  for (int idx = tid; idx < ROWS * K; idx += NTHR) xs[idx] = idx < p.B * K ? p.a[idx] : 0.f;
+  for (int idx = tid; idx < COLS * K; idx += NTHR) ws[idx] = p.W[(size_t)c0 * K + idx];
+  __syncthreads();
+  const int c = c0 + 4 * (tid & 3);
+  float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < 256) {
+    const float* xr = xs + (tid >> 2) * K;
+    const float* w0 = ws + 4 * (tid & 3) * K;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float xv = xr[k];
+      a0 = fmaf(xv, w0[k], a0); a1 = fmaf(xv, w0[K + k], a1); a2 = fmaf(xv, w0[2 * K + k], a2); a3 = fmaf(xv, w0[3 * K + k], a3);
+    }
+    const float4 b = ld4(p.bias + c);
+    z = make_float4(a0 + b.x, a1 + b.y, a2 + b.z, a3 + b.w);
+  }
+  const float4 out = fwd_tail(p, z, blk, c, sm);
+  if (p.ypart) head_slab(p, out, blk, c0, stage, stage + ROWS * COLS);     // (num_stage = 0: the first layer is the last)
 }
 
 // The weight gradient of the same layer rides in the backward launch as extra workgroups (it needs dz and the layer's input,
@@ -314,58 +385,36 @@ __device__ __forceinline__ void dw_tile(const float* __restrict__ dz, const floa
       for (int v = 0; v < 4; ++v) dW[(size_t)(n0 + 16 * x + 4 * kq + v) * Kin + k0 + 16 * y + i] = acc[x][y][v];
 }
 
-struct BwdArgs {
-  const float *a_in;                      // the layer's input [B][H] and
-  float* dW;                              //   its weight gradient [K][H] = dz^T a_in (extra workgroups), or NULL
-  int nblk_dx;                            // workgroups of the dX part (H / 16)
-  const float *dz, *W, *addend;           // g = dz W (+ addend) on the workgroup's columns
-  float* gout;                            // g is kept here when something later reads it (the skip gradient), or NULL
-  // the layer below
+// BatchNorm backward of one layer on the workgroup's columns, from the layer's incoming gradient g (thread tid < 256: row
+// tid >> 2, columns c .. c + 3 of block blk): sum dy, sum dy zhat, the coefficients, dz (stored, and returned: zeros outside the
+// batch), dgamma, dbeta and the gradient of the bias in front of the BatchNorm.  Every thread of the workgroup calls it.
+struct BnLo {
   const float *z, *mean, *rstd, *gamma;
   const uint64_t* bits;
-  float *dz_lo, *dgamma, *dbeta, *dbias;
+  float *dz, *dgamma, *dbeta, *dbias;
   float kscale;
-  int B, H, K, rowbits;                   // rowbits: the lower layer's bitmap is in the row format of bn_apply_row
+  int B, H, rowbits;                      // rowbits: the bitmap is in the row format of bn_apply_row (elementwise.hip)
 };
-
-template <int STEPS>
-__global__ __launch_bounds__(NTHR) void small_bwd_kernel(BwdArgs p) {
-  __shared__ float part[NWAVE * ROWS * COLS];
-  __shared__ float stage[NWAVE * STAGE];
-  __shared__ float4 sm[12][4];
-  if ((int)blockIdx.x >= p.nblk_dx) {       // (workgroup-uniform)
-    dw_tile(p.dz, p.a_in, p.dW, p.B, p.K, p.H, blockIdx.x - p.nblk_dx);
-    return;
-  }
-  const int blk = col_block(blockIdx.x, p.nblk_dx);
-  const int c0 = blk * COLS;
-  contract<STEPS, true>(p.dz, p.K, p.B, p.W, p.H, c0, part, stage);
-  __syncthreads();
+__device__ __forceinline__ float4 bnbwd_tail(const BnLo& p, float4 g, int blk, int c, float4 (*sm)[4]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r = tid >> 2, c = c0 + 4 * (tid & 3);
+  const int r = tid >> 2;
   const bool live = tid < 256 && r < p.B;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 g = zero, zl = zero, mu = zero, rs = zero, ga = zero;
+  float4 zl = zero, mu = zero, rs = zero, ga = zero;
   uint64_t bw[4] = {0, 0, 0, 0};
   int bit = lane;
   if (tid < 256) {
     mu = ld4(p.mean + c); rs = ld4(p.rstd + c); ga = ld4(p.gamma + c);
     if (live) {
       zl = ld4(p.z + (size_t)r * p.H + c);
+      const uint64_t* q = p.bits + (size_t)blk * 16 + wave * 4;
       if (p.rowbits) {
-        const uint64_t* q = p.bits + (size_t)r * (((p.H + 255) >> 8) * 4) + (c >> 8) * 4;
-        const ulonglong2 b01 = *reinterpret_cast<const ulonglong2*>(q), b23 = *reinterpret_cast<const ulonglong2*>(q + 2);
-        bw[0] = b01.x; bw[1] = b01.y; bw[2] = b23.x; bw[3] = b23.y;
+        q = p.bits + (size_t)r * (((p.H + 255) >> 8) * 4) + (c >> 8) * 4;
         bit = (c >> 2) & 63;
-      } else {
-        const uint64_t* q = p.bits + (size_t)blk * 16 + wave * 4;
-        const ulonglong2 b01 = *reinterpret_cast<const ulonglong2*>(q), b23 = *reinterpret_cast<const ulonglong2*>(q + 2);
-        bw[0] = b01.x; bw[1] = b01.y; bw[2] = b23.x; bw[3] = b23.y;
       }
+      const ulonglong2 b01 = *reinterpret_cast<const ulonglong2*>(q), b23 = *reinterpret_cast<const ulonglong2*>(q + 2);
+      bw[0] = b01.x; bw[1] = b01.y; bw[2] = b23.x; bw[3] = b23.y;
     }
-    g = gather_part(part);
-    if (p.addend && live) { const float4 t = ld4(p.addend + (size_t)r * p.H + c); g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w; }
-    if (p.gout && live) st4(p.gout + (size_t)r * p.H + c, g);
   }
   float4 dv = zero, zh = zero;
   if (live) {
@@ -380,7 +429,6 @@ __global__ __launch_bounds__(NTHR) void small_bwd_kernel(BwdArgs p) {
   s[1] = make_float4(dv.x * zh.x, dv.y * zh.y, dv.z * zh.z, dv.w * zh.w);
   s[2] = zh;
   colsum<3>(s, sm);
-  if (tid >= 256) return;
   const float Bt = (float)p.B;
   const float4 s1 = s[0], s2 = s[1], sz = s[2];
   const float4 k0 = make_float4(ga.x * rs.x, ga.y * rs.y, ga.z * rs.z, ga.w * rs.w);
@@ -394,34 +442,207 @@ __global__ __launch_bounds__(NTHR) void small_bwd_kernel(BwdArgs p) {
     db.z = k0.z * ((s1.z - Bt * k1.z) - k2.z * sz.z); db.w = k0.w * ((s1.w - Bt * k1.w) - k2.w * sz.w);
     st4(p.dbias + c, db);
   }
-  if (!live) return;
-  float4 d;
-  d.x = k0.x * (dv.x - k1.x - zh.x * k2.x); d.y = k0.y * (dv.y - k1.y - zh.y * k2.y);
-  d.z = k0.z * (dv.z - k1.z - zh.z * k2.z); d.w = k0.w * (dv.w - k1.w - zh.w * k2.w);
-  st4(p.dz_lo + (size_t)r * p.H + c, d);
+  float4 d = zero;
+  if (live) {
+    d.x = k0.x * (dv.x - k1.x - zh.x * k2.x); d.y = k0.y * (dv.y - k1.y - zh.y * k2.y);
+    d.z = k0.z * (dv.z - k1.z - zh.z * k2.z); d.w = k0.w * (dv.w - k1.w - zh.w * k2.w);
+    st4(p.dz + (size_t)r * p.H + c, d);
+  }
+  return d;
+}
+
+struct BwdArgs {
+  const float *a_in;                      // the layer's input [B][H] and
+  float* dW;                              //   its weight gradient [K][H] = dz^T a_in (extra workgroups), or NULL
+  int nblk_dx;                            // workgroups of the dX part (H / 16)
+  const float *dz, *W, *addend;           // g = dz W (+ addend) on the workgroup's columns
+  float* gout;                            // g is kept here when something later reads it (the skip gradient), or NULL
+  BnLo lo;                                // the layer below
+  // the layer below is the FIRST layer: its weight gradient dW1 [H][K1] = dz_lo^T x follows in the same workgroup, or NULL
+  const float* x1;
+  float* dW1;
+  int K1;
+  int B, H, K;
+};
+
+// dW [16 columns of this workgroup][K1] = d^T x over the rows: d (this workgroup's dz of the first layer, from the threads'
+// registers) and x through LDS; thread o handles (column o / K1, input o % K1), an fmaf chain over the rows in order
+__device__ __forceinline__ void first_wgrad(float4 d, const float* __restrict__ x, float* __restrict__ dW1, int B, int K1, int c0,
+                                            float* ds, float* xs) {
+  const int tid = threadIdx.x;
+  if (tid < 256) st4(ds + tid * 4, d);                   // [row][16]
+  for (int idx = tid; idx < B * K1; idx += NTHR) xs[idx] = x[idx];
+  __syncthreads();
+  for (int o = tid; o < COLS * K1; o += NTHR) {
+    const int cc = o / K1, k = o - cc * K1;
+    float acc = 0.f;
+    for (int r = 0; r < B; ++r) acc = fmaf(ds[r * COLS + cc], xs[r * K1 + k], acc);
+    dW1[(size_t)(c0 + cc) * K1 + k] = acc;
+  }
+}
+
+template <int STEPS>
+__global__ __launch_bounds__(NTHR) void small_bwd_kernel(BwdArgs p) {
+  __shared__ float part[NWAVE * ROWS * COLS];
+  __shared__ float stage[NWAVE * STAGE];
+  __shared__ float4 sm[12][4];
+  if ((int)blockIdx.x >= p.nblk_dx) {       // (workgroup-uniform)
+    dw_tile(p.dz, p.a_in, p.dW, p.B, p.K, p.H, blockIdx.x - p.nblk_dx);
+    return;
+  }
+  const int blk = col_block(blockIdx.x, p.nblk_dx);
+  const int c0 = blk * COLS;
+  contract<STEPS, true>(p.dz, p.K, p.B, p.W, p.H, c0, part, stage);
+  __syncthreads();
+  const int tid = threadIdx.x;
+  const int r = tid >> 2, c = c0 + 4 * (tid & 3);
+  const bool live = tid < 256 && r < p.B;
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < 256) {
+    g = gather_part(part);
+    if (p.addend && live) { const float4 t = ld4(p.addend + (size_t)r * p.H + c); g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w; }
+    if (p.gout && live) st4(p.gout + (size_t)r * p.H + c, g);
+  }
+  const float4 d = bnbwd_tail(p.lo, g, blk, c, sm);
+  // (part and stage are free: every thread is past the barriers of bnbwd_tail)
+  if (p.dW1) first_wgrad(d, p.x1, p.dW1, p.B, p.K1, c0, part, stage);
+}
+
+// The TOP of the backward pass: the output Linear (LinearModel.w2, out_dim = 51 or 34 outputs) and the BatchNorm backward of
+// the last hidden layer, from dy [B][O]:  g = dy W2 on the workgroup's 16 columns (O steps on the vector unit, dy and the W2
+// columns in LDS; kept in gout: it is also the skip gradient of the last residual block), the BatchNorm backward of the top
+// layer, dW2[:, columns] = dy^T h, and -- workgroup 0 -- the output bias gradient = column sums of dy.   O <= 64.
+struct TopArgs {
+  const float *dy, *W2, *h;
+  float *gout, *dW2, *db2;
+  BnLo lo;
+  int B, H, O;
+  // the fused train step: the MSE loss = inv_n * (sum of the np partials, in order), and the device step counter ticks here
+  // (every dropout kernel of the forward ran before this launch, AdamW runs after it) -- mse_final_kernel's job
+  const float* mpart;
+  float* loss;
+  uint64_t* tick;
+  float inv_n;
+  int np;
+};
+__global__ __launch_bounds__(NTHR) void small_top_bwd_kernel(TopArgs p) {
+  __shared__ float stage[ROWS * 64 + 64 * COLS + ROWS * COLS];
+  __shared__ float4 sm[12][4];
+  const int blk = col_block(blockIdx.x, gridDim.x);
+  const int c0 = blk * COLS;
+  const int tid = threadIdx.x, O = p.O;
+  float* dys = stage;                    // [64][O]
+  float* ws = stage + ROWS * 64;         // [O][16]
+  float* hs = ws + 64 * COLS;            // [64][16]
+  for (int idx = tid; idx < ROWS * O; idx += NTHR) dys[idx] = idx < p.B * O ? p.dy[idx] : 0.f;
+  for (int idx = tid; idx < O * COLS; idx += NTHR) ws[idx] = p.W2[(size_t)(idx >> 4) * p.H + c0 + (idx & 15)];
+  for (int idx = tid; idx < ROWS * COLS; idx += NTHR) hs[idx] = (idx >> 4) < p.B ? p.h[(size_t)(idx >> 4) * p.H + c0 + (idx & 15)] : 0.f;
+  __syncthreads();
+  const int r = tid >> 2, c = c0 + 4 * (tid & 3);
+  float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < 256) {
+    const float* dr = dys + r * O;
+    const float* w0 = ws + 4 * (tid & 3);
+    for (int o = 0; o < O; ++o) {
+      const float dv = dr[o];
+      const float4 wv = ld4(w0 + o * COLS);
+      g.x = fmaf(dv, wv.x, g.x); g.y = fmaf(dv, wv.y, g.y); g.z = fmaf(dv, wv.z, g.z); g.w = fmaf(dv, wv.w, g.w);
+    }
+    if (r < p.B) st4(p.gout + (size_t)r * p.H + c, g);
+  }
+  (void)bnbwd_tail(p.lo, g, blk, c, sm);
+  for (int o = tid; o < O * COLS; o += NTHR) {
+    const int oo = o >> 4, cc = o & 15;
+    float acc = 0.f;
+    for (int rr = 0; rr < p.B; ++rr) acc = fmaf(dys[rr * O + oo], hs[rr * COLS + cc], acc);
+    p.dW2[(size_t)oo * p.H + c0 + cc] = acc;
+  }
+  if (blockIdx.x == 0 && tid < O) {
+    float acc = 0.f;
+    for (int rr = 0; rr < p.B; ++rr) acc += dys[rr * O + tid];
+    p.db2[tid] = acc;
+  }
+  if (p.loss && blockIdx.x == 0 && tid == 64) {
+    float acc = 0.f;
+    for (int i = 0; i < p.np; ++i) acc += p.mpart[i];
+    p.loss[0] = acc * p.inv_n;
+    if (p.tick) p.tick[0] += 1;
+  }
+}
+
+// y = bias + the NS slabs of the output Linear (FwdArgs.ypart: [NS][B][64]), dpred = coef (y - t), and per workgroup the
+// partial sum of (y - t)^2: the MSE forward + backward of the fused train step at small batch (nn.MSELoss, train_1.py:64-66).
+// Four lanes per element, a quarter of the slabs each (all of a lane's loads in flight: one round trip), combined in a fixed
+// order: (q0 + q1) + (q2 + q3).  64 elements per workgroup.
+constexpr int kMseElems = 64;
+__global__ __launch_bounds__(256) void small_mse_kernel(const float* __restrict__ ypart, int NS, int B, int O,
+                                                        const float* __restrict__ bias, const float* __restrict__ tgt, float coef,
+                                                        float* __restrict__ y, float* __restrict__ dpred, float* __restrict__ mpart) {
+  __shared__ float red[4];
+  const int n = B * O, tid = threadIdx.x;
+  const int i = blockIdx.x * kMseElems + (tid >> 2), q = tid & 3;
+  const bool ok = i < n;
+  const int r = ok ? i / O : 0, o = ok ? i - r * O : 0;
+  const size_t slab = (size_t)B * 64;
+  const int per = (NS + 3) >> 2;
+  const float* src = ypart + (size_t)r * 64 + o + (size_t)(q * per) * slab;
+  float a = 0.f;
+  for (int s0 = 0; s0 < per; s0 += 16) {
+    float u[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) u[j] = (ok && s0 + j < per && q * per + s0 + j < NS) ? src[(size_t)(s0 + j) * slab] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a += u[j];
+  }
+  a += __shfl_xor(a, 1);
+  a += __shfl_xor(a, 2);
+  float acc = 0.f;
+  if (ok && q == 0) {
+    if (bias) a += bias[o];
+    y[i] = a;
+    const float d = a - tgt[i];
+    acc = d * d;
+    dpred[i] = d * coef;
+  }
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) acc += __shfl_xor(acc, w);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) mpart[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 }  // namespace
 
-// shapes the two kernels take: B rows in one tile, 16-column blocks, K split over eight waves in 32-k steps
+// shapes the layer kernels take: B rows in one tile, 16-column blocks, K split over eight waves in 32-k steps
 bool small_layer_ok(int B, int H, int K) {
   static const bool off = [] { const char* e = getenv("POSELIFT_SMALL_LAYER"); return e && e[0] == '0'; }();   // =0: same-box A/B
   if (off || B < 2 || B > ROWS || (H & 15) || H < 16) return false;
   const int steps = K / (NWAVE * 32);
   return K % (NWAVE * 32) == 0 && (steps == 1 || steps == 2 || steps == 4);
 }
+// ... and the first layer (K = in_dim inputs) / the output layer (O = out_dim outputs) beside such hidden layers
+bool small_first_ok(int K) {
+  static const bool off = [] { const char* e = getenv("POSELIFT_SMALL_ENDS"); return e && e[0] == '0'; }();    // =0: same-box A/B
+  return !off && K >= 1 && K <= kFirstMaxK;
+}
+bool small_top_ok(int O) {
+  static const bool off = [] { const char* e = getenv("POSELIFT_SMALL_ENDS"); return e && e[0] == '0'; }();
+  return !off && O >= 1 && O <= 64;
+}
 
 int launch_small_layer_fwd(const float* a, const float* W, const float* bias, const float* gamma, const float* beta, float eps,
                            float momentum, float* rm, float* rv, int64_t* nbt, float* mean, float* rstd, const float* resid,
                            float* z, float* act, uint64_t* bits, int B, int H, int K, float pdrop, uint64_t seed, uint64_t step,
-                           int layer, const uint64_t* inject_keep, hipStream_t s, const uint64_t* step_dev) {
-  if (!small_layer_ok(B, H, K)) PL_FAIL(PL_ESHAPE, "small_layer_fwd: B=%d H=%d K=%d", B, H, K);
+                           int layer, const uint64_t* inject_keep, hipStream_t s, const uint64_t* step_dev, bool first,
+                           const float* W2, float* ypart, int O) {
+  if (first ? !(small_layer_ok(B, H, H) && small_first_ok(K)) : !small_layer_ok(B, H, K))
+    PL_FAIL(PL_ESHAPE, "small_layer_fwd: B=%d H=%d K=%d first=%d", B, H, K, (int)first);
   if (!a || !W || !bias || !gamma || !beta || !mean || !rstd || !z || !act || !bits || (rm != nullptr) != (rv != nullptr))
     PL_FAIL(PL_EINVAL, "small_layer_fwd: bad arguments");
-  if (!al16(a) || !al16(W) || !al16(bias) || !al16(gamma) || !al16(beta) || !al16(mean) || !al16(rstd) || !al16(z) || !al16(act) ||
-      !al16(resid) || !al16(rm) || !al16(rv) || !al16(bits))
+  if ((!first && (!al16(a) || !al16(W))) || !al16(bias) || !al16(gamma) || !al16(beta) || !al16(mean) || !al16(rstd) || !al16(z) ||
+      !al16(act) || !al16(resid) || !al16(rm) || !al16(rv) || !al16(bits))
     PL_FAIL(PL_EINVAL, "small_layer_fwd: 16-byte alignment");
   FwdArgs p = {};
   p.a = a; p.W = W; p.bias = bias; p.gamma = gamma; p.beta = beta; p.resid = resid;
@@ -435,17 +656,25 @@ int launch_small_layer_fwd(const float* a, const float* W, const float* bias, co
   p.k0 = (uint32_t)seed; p.seed_hi = (uint32_t)(seed >> 32);
   p.k1 = step_dev ? (uint32_t)(step >> 32) : p.seed_hi ^ (uint32_t)(step >> 32);
   p.c3 = (uint32_t)step; p.layer = (uint32_t)layer;
+  if (ypart) {
+    if (!W2 || !small_top_ok(O)) PL_FAIL(PL_EINVAL, "small_layer_fwd: output-layer slabs (O=%d)", O);
+    p.W2 = W2; p.ypart = ypart; p.O = O;
+  }
   const dim3 grid(H / COLS), block(NTHR);
   void* prof = prof_begin_flops(2.0 * B * H * K, s);
-  switch (K / (NWAVE * 32)) {
-    case 1: hipLaunchKernelGGL(small_fwd_kernel<1>, grid, block, 0, s, p); break;
-    case 2: hipLaunchKernelGGL(small_fwd_kernel<2>, grid, block, 0, s, p); break;
-    default: {
-      static const int abl = [] { const char* e = getenv("POSELIFT_SL_ABL"); return e ? atoi(e) : 0; }();   // timing only
-      if (abl == 1) hipLaunchKernelGGL((small_fwd_kernel<4, 1>), grid, block, 0, s, p);
-      else if (abl == 2) hipLaunchKernelGGL((small_fwd_kernel<4, 2>), grid, block, 0, s, p);
-      else hipLaunchKernelGGL((small_fwd_kernel<4, 0>), grid, block, 0, s, p);
-      break;
+  if (first) {
+    hipLaunchKernelGGL(small_first_fwd_kernel, grid, block, 0, s, p);
+  } else {
+    switch (K / (NWAVE * 32)) {
+      case 1: hipLaunchKernelGGL(small_fwd_kernel<1>, grid, block, 0, s, p); break;
+      case 2: hipLaunchKernelGGL(small_fwd_kernel<2>, grid, block, 0, s, p); break;
+      default: {
+        static const int abl = [] { const char* e = getenv("POSELIFT_SL_ABL"); return e ? atoi(e) : 0; }();   // timing only
+        if (abl == 1) hipLaunchKernelGGL((small_fwd_kernel<4, 1>), grid, block, 0, s, p);
+        else if (abl == 2) hipLaunchKernelGGL((small_fwd_kernel<4, 2>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((small_fwd_kernel<4, 0>), grid, block, 0, s, p);
+        break;
+      }
     }
   }
   prof_end(prof, s);
@@ -453,26 +682,39 @@ int launch_small_layer_fwd(const float* a, const float* W, const float* bias, co
   return PL_OK;
 }
 
+namespace {
+int fill_lo(BnLo& lo, const SmallBnLayer& b, int B, int H, float kscale, float* dz_lo, const char* who) {
+  if (!b.z || !b.bits || !b.mean || !b.rstd || !b.gamma || !dz_lo || !b.dgamma || !b.dbeta || !b.dbias)
+    PL_FAIL(PL_EINVAL, "%s: bad arguments (layer below)", who);
+  if (!al16(b.z) || !al16(b.bits) || !al16(b.mean) || !al16(b.rstd) || !al16(b.gamma) || !al16(dz_lo) || !al16(b.dgamma) ||
+      !al16(b.dbeta) || !al16(b.dbias))
+    PL_FAIL(PL_EINVAL, "%s: 16-byte alignment (layer below)", who);
+  lo.z = b.z; lo.mean = b.mean; lo.rstd = b.rstd; lo.gamma = b.gamma; lo.bits = b.bits; lo.dz = dz_lo;
+  lo.dgamma = b.dgamma; lo.dbeta = b.dbeta; lo.dbias = b.dbias; lo.kscale = kscale; lo.B = B; lo.H = H; lo.rowbits = b.rowbits ? 1 : 0;
+  return PL_OK;
+}
+}  // namespace
+
 int launch_small_layer_bwd(const float* dz, const float* W, const float* addend, float* gout, int B, int H, int K,
-                           const float* z_lo, const uint64_t* bits_lo, bool rowbits, const float* mean_lo, const float* rstd_lo,
-                           const float* gamma_lo, float kscale, float* dz_lo, float* dgamma, float* dbeta, float* dbias,
-                           hipStream_t s, const float* a_in, float* dW) {
+                           const SmallBnLayer& below, float kscale, float* dz_lo, hipStream_t s, const float* a_in, float* dW,
+                           const float* x1, float* dW1, int K1) {
   if (!small_layer_ok(B, H, K)) PL_FAIL(PL_ESHAPE, "small_layer_bwd: B=%d H=%d K=%d", B, H, K);
-  if (!dz || !W || !z_lo || !bits_lo || !mean_lo || !rstd_lo || !gamma_lo || !dz_lo || !dgamma || !dbeta || !dbias || dz_lo == dz)
-    PL_FAIL(PL_EINVAL, "small_layer_bwd: bad arguments");
-  if (!al16(dz) || !al16(W) || !al16(addend) || !al16(gout) || !al16(z_lo) || !al16(bits_lo) || !al16(mean_lo) || !al16(rstd_lo) ||
-      !al16(gamma_lo) || !al16(dz_lo) || !al16(dgamma) || !al16(dbeta) || !al16(dbias))
-    PL_FAIL(PL_EINVAL, "small_layer_bwd: 16-byte alignment");
+  if (!dz || !W || dz_lo == dz) PL_FAIL(PL_EINVAL, "small_layer_bwd: bad arguments");
+  if (!al16(dz) || !al16(W) || !al16(addend) || !al16(gout)) PL_FAIL(PL_EINVAL, "small_layer_bwd: 16-byte alignment");
   BwdArgs p = {};
-  p.dz = dz; p.W = W; p.addend = addend; p.gout = gout; p.z = z_lo; p.mean = mean_lo; p.rstd = rstd_lo; p.gamma = gamma_lo;
-  p.bits = bits_lo; p.dz_lo = dz_lo; p.dgamma = dgamma; p.dbeta = dbeta; p.dbias = dbias; p.kscale = kscale;
-  p.B = B; p.H = H; p.K = K; p.rowbits = rowbits ? 1 : 0;
+  PL_TRY(fill_lo(p.lo, below, B, H, kscale, dz_lo, "small_layer_bwd"));
+  p.dz = dz; p.W = W; p.addend = addend; p.gout = gout;
+  p.B = B; p.H = H; p.K = K;
   p.nblk_dx = H / COLS;
   int extra = 0;
   if (dW) {
     if (!a_in || !al16(a_in) || !al16(dW) || (K & 127) || (H & 63)) PL_FAIL(PL_EINVAL, "small_layer_bwd: weight-gradient part (K=%d H=%d)", K, H);
     p.a_in = a_in; p.dW = dW;
     extra = (K / 128) * (H / 64);
+  }
+  if (dW1) {
+    if (!x1 || !small_first_ok(K1)) PL_FAIL(PL_EINVAL, "small_layer_bwd: first-layer weight gradient (K1=%d)", K1);
+    p.x1 = x1; p.dW1 = dW1; p.K1 = K1;
   }
   const dim3 grid(H / COLS + extra), block(NTHR);
   void* prof = prof_begin_flops(2.0 * B * H * K * (dW ? 2 : 1), s);
@@ -483,6 +725,36 @@ int launch_small_layer_bwd(const float* dz, const float* W, const float* addend,
   }
   prof_end(prof, s);
   PL_CHECK_LAUNCH("small_layer_bwd");
+  return PL_OK;
+}
+
+int small_mse_partials(int B, int O) { return (B * O + kMseElems - 1) / kMseElems; }
+
+int launch_small_mse(const float* ypart, int NS, int B, int O, const float* bias, const float* tgt, float grad_scale, float* y,
+                     float* dpred, float* mpart, hipStream_t s) {
+  if (!ypart || !tgt || !y || !dpred || !mpart || NS < 1 || B < 1 || B > ROWS || !small_top_ok(O))
+    PL_FAIL(PL_EINVAL, "small_mse: bad arguments");
+  const int np = small_mse_partials(B, O);
+  const float coef = grad_scale * 2.0f / (float)(B * O);
+  hipLaunchKernelGGL(small_mse_kernel, dim3(np), dim3(256), 0, s, ypart, NS, B, O, bias, tgt, coef, y, dpred, mpart);
+  PL_CHECK_LAUNCH("small_mse");
+  return PL_OK;
+}
+
+int launch_small_top_bwd(const float* dy, const float* W2, const float* h, int B, int H, int O, float* gout, float* dW2,
+                         float* db2, const SmallBnLayer& top, float kscale, float* dz_top, hipStream_t s, const float* mpart,
+                         int np, float inv_n, float* loss, uint64_t* tick) {
+  if (!small_layer_ok(B, H, H) || !small_top_ok(O)) PL_FAIL(PL_ESHAPE, "small_top_bwd: B=%d H=%d O=%d", B, H, O);
+  if (!dy || !W2 || !h || !gout || !dW2 || !db2 || !al16(gout) || !al16(h)) PL_FAIL(PL_EINVAL, "small_top_bwd: bad arguments");
+  TopArgs p = {};
+  PL_TRY(fill_lo(p.lo, top, B, H, kscale, dz_top, "small_top_bwd"));
+  p.dy = dy; p.W2 = W2; p.h = h; p.gout = gout; p.dW2 = dW2; p.db2 = db2; p.B = B; p.H = H; p.O = O;
+  if (loss) {
+    if (!mpart || np < 1) PL_FAIL(PL_EINVAL, "small_top_bwd: loss partials");
+    p.mpart = mpart; p.np = np; p.inv_n = inv_n; p.loss = loss; p.tick = tick;
+  }
+  hipLaunchKernelGGL(small_top_bwd_kernel, dim3(H / COLS), dim3(NTHR), 0, s, p);
+  PL_CHECK_LAUNCH("small_top_bwd");
   return PL_OK;
 }
 

@@ -24,7 +24,13 @@ One JSON line on rank 0 (contract in the task statement).  Also in that line:
                 ATen kernels the reference dispatches to) timed on this node's host cores as BASELINE.md
                 section 4 plans it: 20 warm-up steps, then the MEDIAN of >= 50 timed steps, at B = 4096 (the
                 value) and B = 64 (batch_64) -- rank 0, N=1 only.  A reported baseline, not the target.
-  batch_64      the HIP step's latency at the reference's own batch size (config 0), same protocol.
+  batch_64      the HIP step's latency at the reference's own batch size (config 0), same protocol, issued as one hipGraph
+                replay and as an eager train_step (the lower of the two; both are in the entry).
+  config.launch how the timed steps were issued at N = 1: "eager" (one call per kernel) or "hipgraph" (one replay of the
+                captured step, train.GraphedTrainStep) -- --launch auto times a few untimed steps of each during warm-up
+                and takes the faster (a busy host core makes the eager loop launch-bound: 0.95 instead of 0.61 ms per
+                step on one box of round 3).  Under hipgraph the roofline's HIP events bracket eager steps right behind
+                the timed region (events cannot be read out of a replayed graph); N > 1 is always eager.
   parity        eval-forward MPJPE (mm) of the HIP path against the numpy oracle on the bench
                 batch, in the same run (gate 1e-3 mm, BASELINE.json).
   other_modes   this library's other arithmetic modes and stock PyTorch-ROCm eager of the same module
@@ -78,6 +84,10 @@ def parse():
                     help="N>1 only: BatchNorm statistics over the global batch (10 small all-gathers per step); "
                          "off by default = statistics per shard, the DDP convention")
     ap.add_argument("--no-extras", action="store_true", help="skip the bf16-mode and PyTorch-eager side measurements")
+    ap.add_argument("--launch", choices=["auto", "eager", "hipgraph"], default="auto",
+                    help="how the timed steps are issued at N=1: one Python call per launch (eager), one hipGraph replay per "
+                         "step (GraphedTrainStep), or whichever a short calibration during warm-up finds faster (auto: a slow "
+                         "or busy host core makes the eager loop launch-bound)")
     ap.add_argument("--workload", choices=["lifter", "cycle"], default="lifter",
                     help="lifter (default): BASELINE configs[1]/[2], the headline.  cycle: BASELINE configs[4], one phase5 "
                          "cycle step (Model_2D + Model_3D on 256x256 frames, lifter x2, projector, TriangleLoss, Adam x4) at "
@@ -333,23 +343,31 @@ def side_measurements(pkg, a, dev, x_eval, y_oracle):
 
 
 def batch64_latency(pkg, a, dev, warm=20, steps=50):
-    """BASELINE configs[0]'s batch on the GPU: one train_1.py step at B = 64 (launch-bound), median of `steps`."""
+    """BASELINE configs[0]'s batch on the GPU: one train_1.py step at B = 64 (launch-bound), median of `steps` synchronised
+    steps -- issued as one hipGraph replay (train.GraphedTrainStep) and as an eager train_step; the lower one is the entry."""
     import torch
-    torch.manual_seed(0)
-    m = pkg.LinearModel(34, 51, compute_dtype=a.dtype).to(dev).train()
-    opt = pkg.FlatAdamW(m, lr=1e-4)
-    x, y = pkg.synth.synthetic_batch(64, 77, dev)
-    ts = []
-    for i in range(warm + steps):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        pkg.train_step(m, opt, x, y)
-        torch.cuda.synchronize()
-        if i >= warm:
-            ts.append(time.perf_counter() - t0)
-    t = _median(ts)
-    return {"ms_per_step": round(1e3 * t, 4), "poses_per_s": round(64 / t, 1),
-            "how": f"median of {steps} synchronised steps after {warm} warm-ups (host launch latency included)"}
+    res = {}
+    for how in ("hipgraph", "eager"):
+        torch.manual_seed(0)
+        m = pkg.LinearModel(34, 51, compute_dtype=a.dtype).to(dev).train()
+        opt = pkg.FlatAdamW(m, lr=1e-4)
+        x, y = pkg.synth.synthetic_batch(64, 77, dev)
+        step = pkg.GraphedTrainStep(m, opt, x, y) if how == "hipgraph" else (lambda p, q: pkg.train_step(m, opt, p, q))
+        ts = []
+        for i in range(warm + steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            step(x, y)
+            torch.cuda.synchronize()
+            if i >= warm:
+                ts.append(time.perf_counter() - t0)
+        res[how] = _median(ts)
+    best = min(res, key=res.get)
+    t = res[best]
+    return {"ms_per_step": round(1e3 * t, 4), "poses_per_s": round(64 / t, 1), "launch": best,
+            "ms_per_step_eager": round(1e3 * res["eager"], 4), "ms_per_step_hipgraph": round(1e3 * res["hipgraph"], 4),
+            "how": f"median of {steps} synchronised steps after {warm} warm-ups (host launch latency included), issued as one "
+                   "hipGraph replay (GraphedTrainStep) and as an eager train_step: the lower of the two"}
 
 
 def conv_macs_per_frame(model, size=256):
@@ -532,14 +550,45 @@ def main():
             dist.all_reduce(model.flat_grads[lo:hi])        # whatever --warmup says
         model.flat_grads.zero_()
     run(a.warmup)
-    if not a.no_prof:
+    # N = 1: the same step as ONE hipGraph replay (train.GraphedTrainStep: zero_grad + forward + MSE + backward + AdamW, dropout
+    # stream and Adam's t advanced on the device).  Which way of issuing it is used for the timed region is decided here, on
+    # `cal` untimed steps of each -- on a healthy host the eager loop keeps ahead of the GPU at B = 4096 and is as fast.
+    launch, gstep = "eager", None
+    if world == 1 and a.launch != "eager":
+        cal = max(10, min(a.warmup, 30))
+
+        def run_graph(n, first=0):
+            for i in range(first, first + n):
+                gstep(*pool[i % len(pool)])
+        try:
+            gstep = pkg.GraphedTrainStep(model, opt, *pool[0])
+            tc = []
+            for fn in (run, run_graph):
+                fn(3); torch.cuda.synchronize()
+                tq = time.perf_counter(); fn(cal); torch.cuda.synchronize()
+                tc.append((time.perf_counter() - tq) / cal)
+            if a.launch == "hipgraph" or tc[1] < 0.98 * tc[0]:
+                launch = "hipgraph"
+        except Exception as e:                              # (capture refused: stay eager, say why)
+            print(f"# hipgraph capture unavailable: {e}", file=sys.stderr)
+            gstep = None
+            if a.launch == "hipgraph":
+                raise
+    timed = run if launch == "eager" else run_graph
+    if not a.no_prof and launch == "eager":
         L.pl_prof_enable(prof_every(a.steps))
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(a.steps, a.warmup)
+    timed(a.steps, a.warmup)
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     roofline = roofline_single = None
+    if not a.no_prof and launch == "hipgraph":
+        # (events cannot be read out of a replayed graph: the same kernels are sampled on eager steps right behind the timed region)
+        n_prof = min(a.steps, 64)
+        L.pl_prof_enable(prof_every(n_prof))
+        run(n_prof, a.warmup + a.steps)
+        torch.cuda.synchronize()
     if not a.no_prof:
         one = 2.0 * a.batch * 1024 * 1024                  # one 1024-wide GEMM: 8.59 GFLOP at B=4096
         traffic = None
@@ -620,6 +669,7 @@ def main():
                                    "LinearModel 34-1024-2x(1024-1024)-51, BN+ReLU+Dropout(0.5), one train_1.py "
                                    "step = zero_grad+forward+MSE+backward+AdamW"
                                    + (f"+{dist.get_backend()} grad all-reduce" if world > 1 else ""),
+                       "launch": launch + (" (one hipGraph replay per step)" if launch == "hipgraph" else " (one call per kernel)"),
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world,
                        "parallelism": f"dp{world}" + ("+syncbn" if a.sync_bn and world > 1 else ""),
                        "gemm_arith": {
@@ -636,6 +686,10 @@ def main():
             "roofline": roofline,
             "roofline_forward_gemm": roofline_single,
         }
+        if launch == "hipgraph":
+            for rf in (roofline, roofline_single):
+                if rf:
+                    rf["sampling"] += " -- of eager steps right behind the timed region (the timed steps are graph replays)"
         if world > 1:
             out["allreduce"] = {"overlap": not a.no_overlap, "exposed_us_per_step": exposed_us,
                                 "bytes": int(model.flat_grads.numel()) * 4,

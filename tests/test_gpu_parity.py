@@ -636,6 +636,47 @@ def test_eval_forward_is_graph_capturable(pkg):
         assert torch.equal(ys, want)
 
 
+@pytest.mark.parametrize("B,H,S", [(64, 1024, 2), (37, 256, 2), (9, 512, 0)])
+def test_small_batch_fused_step_vs_autograd_route(pkg, monkeypatch, B, H, S):
+    """B <= 64 (the reference's batch, train_1.py:194): the fused step runs one launch per hidden layer and direction and has
+    no launch for the output Linear (its slabs come from the last hidden layer's launch, csrc/small_layer.hip); the autograd
+    route runs the output layer and the loss as kernels of their own.  Same step to round-off: loss, prediction, every
+    gradient, the BatchNorm running statistics -- and the device step counter ticks once per step under graph replay."""
+    results = []
+    for fused in (True, False):
+        torch.manual_seed(0)
+        m = pkg.LinearModel(34, 51, linear_size=H, num_stage=S, p_dropout=0.5).to(DEV).train()
+        m.manual_seed(3)
+        opt = pkg.FlatAdamW(m, lr=1e-3)
+        if not fused:
+            monkeypatch.setattr(pkg.train, "_fusable", lambda *a: False)
+        x, y = pkg.synth.synthetic_batch(B, 40, DEV)
+        loss, pred = pkg.train_step(m, opt, x, y)
+        results.append((loss.clone(), pred.clone(), m.flat_grads.clone(), m._bn_running.clone(), m))
+    (l0, p0, g0, r0, m0), (l1, p1, g1, r1, _) = results
+    assert abs(l0.item() - l1.item()) <= 2e-6 * abs(l1.item())
+    assert (p0 - p1).abs().max().item() <= 1e-5 * p1.abs().max().item()
+    assert torch.equal(r0, r1)                                   # (the hidden layers run the same kernels on both routes)
+    for sl, prm in zip(m0._slots, m0._param_list):
+        a, b = g0[sl.offset:sl.offset + sl.numel], g1[sl.offset:sl.offset + sl.numel]
+        if b.norm() > 1e-6 * g1.norm():                          # (pre-BatchNorm biases: true gradient 0)
+            assert (a - b).norm() <= 2e-5 * b.norm(), (sl.name, ((a - b).norm() / b.norm()).item())
+    # captured: the replayed steps draw new dropout masks and step Adam on (the device counter ticks in the backward's top
+    # launch at this size): three replays follow three eager steps of a twin model
+    monkeypatch.undo()
+    losses = []
+    for graphed in (True, False):
+        torch.manual_seed(0)
+        m = pkg.LinearModel(34, 51, linear_size=H, num_stage=S, p_dropout=0.5).to(DEV).train()
+        m.manual_seed(3)
+        opt = pkg.FlatAdamW(m, lr=1e-3)
+        x, y = pkg.synth.synthetic_batch(B, 40, DEV)
+        step = pkg.GraphedTrainStep(m, opt, x, y) if graphed else (lambda a, b: pkg.train_step(m, opt, a, b))
+        losses.append([step(x, y)[0].item() for _ in range(3)])
+    assert len(set(losses[0])) == 3
+    np.testing.assert_allclose(losses[0], losses[1], rtol=1e-5)
+
+
 def test_fused_train_step_is_bitwise_the_autograd_route(pkg, monkeypatch):
     """train_step's fast path (pl_lifter_train_fwd_bwd + pl_adamw_flat) and the autograd route
     (LinearModel.forward -> mse_loss -> backward -> optimizer.step) run the same kernels."""
