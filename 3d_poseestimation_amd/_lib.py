@@ -57,6 +57,12 @@ class PLAdamWPlanes(ctypes.Structure):
                 ("reserved", ctypes.c_int32), ("seg", PLAdamWSeg * ADAMW_MAX_SEGS)]
 
 
+class PLAdamWStep(ctypes.Structure):
+    _fields_ = [("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("lr", ctypes.c_float), ("lr_dev", ctypes.c_void_p),
+                ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float), ("weight_decay", ctypes.c_float),
+                ("t", ctypes.c_int64), ("t_dev", ctypes.c_void_p)]
+
+
 class PLPlanesEpilogue(ctypes.Structure):
     _fields_ = [("bias", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("resid", ctypes.c_void_p),
                 ("relu", ctypes.c_int32), ("reserved", ctypes.c_int32), ("y_planes", ctypes.c_void_p)]
@@ -87,6 +93,9 @@ SIGNATURES = {
     "pl_lifter_bwd_layers": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _P, _P, _c.c_int, _c.c_int, _P]),
     "pl_lifter_train_fwd_bwd": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _c.c_uint64, _c.c_uint64,
                                            _P, _P, _P, _c.c_int, _c.c_int, _P]),
+    "pl_lifter_step_carries_adamw": (_c.c_int, [_D, _c.c_int64]),
+    "pl_lifter_train_step": (_c.c_int, [_D, _P, _P, _c.c_int64, _P, _c.c_size_t, _c.c_uint64, _c.c_uint64,
+                                        _P, _P, _P, _c.POINTER(PLAdamWStep), _P]),
     "pl_mse_scratch_bytes": (_c.c_size_t, [_c.c_int64]),
     "pl_mse_fwd_bwd": (_c.c_int, [_P, _P, _c.c_int64, _c.c_float, _P, _P, _P, _P]),
     "pl_l1_scratch_bytes": (_c.c_size_t, [_c.c_int]),

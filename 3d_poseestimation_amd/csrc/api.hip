@@ -11,6 +11,7 @@
 
 #include <vector>
 
+#include "adamw.h"
 #include "pl_internal.h"
 
 namespace pl {
@@ -114,6 +115,10 @@ inline bool small_top_on(const PLDesc* d, bool planes, int64_t B) { return small
 // the fused train step at small batch: no launch for the output Linear (the last hidden layer's launch leaves its slabs)
 inline bool small_head_on(const PLDesc* d, bool planes, int64_t B) {
   return small_top_on(d, planes, B) && (d->num_stage > 0 || small_first_on(d, planes, B));
+}
+inline bool adam_ride_on() {        // POSELIFT_SMALL_ADAM=0: the AdamW step of pl_lifter_train_step as one launch of its own (A/B)
+  static const bool off = [] { const char* e = getenv("POSELIFT_SMALL_ADAM"); return e && e[0] == '0'; }();
+  return !off;
 }
 inline int arith_of(const PLDesc* d) { return d->dtype == PL_F16X3 ? (int)PL_BF16X6 : d->dtype; }
 
@@ -645,7 +650,7 @@ static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, 
 // mse_final_kernel's sum) and the device step counter ticks there, instead of in a launch of their own after the forward.
 static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B, void* ws, size_t ws_bytes,
                     float* dx, float* grads, void* stream, bool do_output, int l_hi, int l_lo, bool eval_bn = false,
-                    float* loss_out = nullptr, int loss_partials = 0) {
+                    float* loss_out = nullptr, int loss_partials = 0, const PLAdamWStep* adam = nullptr) {
   PL_TRY(check_desc(d, true));
   if (!x || !dy || !grads) PL_FAIL(PL_EINVAL, "pl_lifter_bwd: null x/dy/flat_grads");
   if (B <= 0) PL_FAIL(PL_ESHAPE, "pl_lifter_bwd: B=%lld", (long long)B);
@@ -679,6 +684,16 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
   // the output layer and the BatchNorm backward of the top hidden layer in one launch (dz of that layer: DZ)
   const int n_loss_part = loss_partials > 0 ? loss_partials : mse_partials(B * O);   // partial sums of the loss in w.mse
   const bool top_fused = do_output && sl_all && small_top_on(d, w.planes, B) && l_hi == w.L - 1 && l_hi >= l_lo;
+  // the AdamW step carried by the backward launches (pl_lifter_train_step): which slice of the arena rides with layer l
+  static const bool dw_off = [] { const char* e = getenv("POSELIFT_SMALL_DW"); return e && e[0] == '0'; }();
+  const bool adam_rides = adam && top_fused && l_lo == 0 && !dw_off && H % 128 == 0 && adam_ride_on();
+  auto ride = [&](int64_t lo, int64_t hi) {
+    AdamWRide r = {};
+    r.p = const_cast<float*>(d->params) + lo; r.g = grads + lo; r.m = adam->m + lo; r.v = adam->v + lo; r.n = hi - lo;
+    r.lr = adam->lr; r.beta1 = adam->beta1; r.beta2 = adam->beta2; r.eps = adam->eps; r.wd = adam->weight_decay; r.gscale = 1.0f;
+    r.t = adam->t; r.lr_dev = adam->lr_dev; r.t_dev = adam->t_dev;
+    return r;
+  };
   if (top_fused) {
     PL_TRY(launch_small_top_bwd(dy, d->params + P.off[4 * w.L], f32(ws, w.act[w.L - 1]), Bi, H, O, GA, grads + P.off[4 * w.L],
                                 grads + P.off[4 * w.L + 1], bn_layer(w.L - 1), kscale, DZ, s, f32(ws, w.mse),
@@ -799,15 +814,19 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
       t.arith = arith_of(d);
       t.A = DZl; t.B = a_in; t.M = H; t.N = H; t.K = Bi; t.lda = H; t.ldb = H; t.ldc = H; t.split_k = 1; t.C = ly.gW;
       // (the weight gradient as extra workgroups of the same launch: POSELIFT_SMALL_DW=0 keeps it a launch of its own, A/B)
-      static const bool dw_off = [] { const char* e = getenv("POSELIFT_SMALL_DW"); return e && e[0] == '0'; }();
       const bool dw_rides = !dw_off && H % 128 == 0;
       if (l - 1 >= l_lo) {
         // (l == 1: the first layer's weight gradient dW1 = dz_0^T x follows its BatchNorm backward in the same workgroups)
         first_wgrad_done = l == 1 && small_first_ok(d->in_dim);
+        // AdamW on this launch's spare workgroups: this layer's bias and BatchNorm parameters (their gradients came with the
+        // launch before) and everything above them up to where the launch before started -- the weight matrix of layer
+        // l + 1 (its gradient, too), or the output layer behind the top hidden layer
+        AdamWRide ar = {};
+        if (adam_rides) ar = ride(P.off[4 * l + 1], l == w.L - 1 ? P.total : P.off[4 * (l + 1) + 1]);
         PL_TRY(launch_small_layer_bwd(DZl, ly.W, (l % 2 == 1) ? GA : nullptr, (l % 2 == 1) ? GA : nullptr, Bi, H, H,
                                       bn_layer(l - 1), kscale, dzbuf(l - 1), s, dw_rides ? a_in : nullptr,
                                       dw_rides ? ly.gW : nullptr, first_wgrad_done ? x : nullptr,
-                                      first_wgrad_done ? grads + P.off[0] : nullptr, d->in_dim));
+                                      first_wgrad_done ? grads + P.off[0] : nullptr, d->in_dim, adam_rides ? &ar : nullptr));
         if (dw_rides) continue;
       } else {
         GemmArgs g = {};
@@ -859,9 +878,21 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
     inv_n = 1.0f / (float)n;
     tick = const_cast<uint64_t*>(d->step_dev);
   }
-  if (jpart.empty()) return PL_OK;
-  return launch_reduce_rows_multi(jpart.data(), jR.data(), jH.data(), jout.data(), (int)jpart.size(), s, jkind.data(),
-                                  jtrans.data(), inv_n, tick);
+  if (!jpart.empty())
+    PL_TRY(launch_reduce_rows_multi(jpart.data(), jR.data(), jH.data(), jout.data(), (int)jpart.size(), s, jkind.data(),
+                                    jtrans.data(), inv_n, tick));
+  if (adam) {
+    // what no backward launch carried: the bottom of the arena (first layer and the first residual Linear) -- or all of it
+    const int64_t n = adam_rides ? (w.L > 1 ? P.off[4 * 1 + 1] : P.total) : P.total;
+    float* p = const_cast<float*>(d->params);
+    if (adam->lr_dev)
+      PL_TRY(pl_adamw_flat_dev(p, grads, adam->m, adam->v, n, adam->lr_dev, adam->beta1, adam->beta2, adam->eps,
+                               adam->weight_decay, adam->t, adam->t_dev, 1.0f, stream));
+    else
+      PL_TRY(pl_adamw_flat(p, grads, adam->m, adam->v, n, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->weight_decay,
+                           adam->t, 1.0f, stream));
+  }
+  return PL_OK;
 }
 
 extern "C" int pl_lifter_bwd(const PLDesc* d, const float* x, const float* dy, int64_t B, void* ws,
@@ -1160,9 +1191,36 @@ extern "C" int pl_prof_read(double min_flops, double max_flops, double* ms_total
 // ---------------------------------------------------------------------------------------
 // fused train step: forward (training mode) + MSE(mean) + backward in one call
 // ---------------------------------------------------------------------------------------
+static int train_fwd_bwd_impl(const PLDesc* d, const float* x, const float* target, int64_t B, void* ws, size_t ws_bytes,
+                              uint64_t seed, uint64_t step, float* y, float* loss, float* grads, int hi, int lo, void* stream,
+                              const PLAdamWStep* adam);
+
 extern "C" int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const float* target, int64_t B, void* ws,
                                        size_t ws_bytes, uint64_t seed, uint64_t step, float* y, float* loss,
                                        float* grads, int hi, int lo, void* stream) {
+  return train_fwd_bwd_impl(d, x, target, B, ws, ws_bytes, seed, step, y, loss, grads, hi, lo, stream, nullptr);
+}
+
+extern "C" int pl_lifter_step_carries_adamw(const PLDesc* d, int64_t B) {
+  PL_TRY(check_desc(d, false));
+  if (B <= 0) return 0;
+  const bool planes = planes_kind(d, B) != 0;
+  static const bool dw_off = [] { const char* e = getenv("POSELIFT_SMALL_DW"); return e && e[0] == '0'; }();
+  return (bn_small_ok(d, planes, B) && small_head_on(d, planes, B) && !dw_off && d->hidden % 128 == 0 && adam_ride_on()) ? 1 : 0;
+}
+
+extern "C" int pl_lifter_train_step(const PLDesc* d, const float* x, const float* target, int64_t B, void* ws, size_t ws_bytes,
+                                    uint64_t seed, uint64_t step, float* y, float* loss, float* grads, const PLAdamWStep* opt,
+                                    void* stream) {
+  if (!opt || !opt->m || !opt->v || (opt->lr_dev != nullptr) != (opt->t_dev != nullptr) || opt->t < (opt->t_dev ? 0 : 1))
+    PL_FAIL(PL_EINVAL, "pl_lifter_train_step: bad optimizer description");
+  if (!d) PL_FAIL(PL_EINVAL, "descriptor is NULL");
+  return train_fwd_bwd_impl(d, x, target, B, ws, ws_bytes, seed, step, y, loss, grads, 1 + 2 * d->num_stage, 0, stream, opt);
+}
+
+static int train_fwd_bwd_impl(const PLDesc* d, const float* x, const float* target, int64_t B, void* ws, size_t ws_bytes,
+                              uint64_t seed, uint64_t step, float* y, float* loss, float* grads, int hi, int lo, void* stream,
+                              const PLAdamWStep* adam) {
   PL_TRY(check_desc(d, true));
   if (!x || !target || !y || !loss || !grads) PL_FAIL(PL_EINVAL, "pl_lifter_train_fwd_bwd: null pointer");
   if (B <= 0) PL_FAIL(PL_ESHAPE, "pl_lifter_train_fwd_bwd: B=%lld", (long long)B);
@@ -1195,5 +1253,5 @@ extern "C" int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const fl
     }
   }
   return bwd_impl(d, x, dy, B, ws, ws_bytes, nullptr, grads, stream, hi == L, hi == L ? L - 1 : hi, lo, false,
-                  hi == L ? loss : nullptr, small_head ? small_mse_partials((int)B, d->out_dim) : 0);
+                  hi == L ? loss : nullptr, small_head ? small_mse_partials((int)B, d->out_dim) : 0, adam);
 }

@@ -10,6 +10,7 @@
 // fully coalesced).  Every column reduction is a fixed-order two-stage sum (per-block
 // partials, then a small finalize kernel): results are bitwise reproducible, no float
 // atomics anywhere.
+#include "adamw.h"
 #include "bn_pieces.h"
 #include "philox.h"
 #include <stdlib.h>
@@ -1286,58 +1287,7 @@ __global__ void gather_rows2_kernel(const float* __restrict__ a, int wa, const f
   else ob[i * wb + (c - wa)] = b[r * wb + (c - wa)];
 }
 
-// ---- flat AdamW (torch single-tensor update order) ----------------------------------------
-struct AdamWK {
-  float decay;       // 1 - lr*wd
-  float one_m_b1, b2, one_m_b2;
-  float step_size;   // lr / (1 - b1^t)
-  float bc2_sqrt;    // sqrt(1 - b2^t)
-  float eps, gscale;
-};
-
-// What the step is given; the per-step constants are derived ON THE DEVICE (every thread, once: two double pow),
-// so that a captured graph advances them by itself: t = t_base + *t_dev, lr = *lr_dev when the pointers are set
-// (the eager call passes them by value through the same code, hence the same bits).
-struct AdamWIn {
-  float lr, beta1, beta2, eps, wd, gscale;
-  int64_t t;
-  const float* lr_dev;
-  const uint64_t* t_dev;
-  // GEMM operand planes of the 1024-wide weight matrices, refreshed by the step that changes them (PLAdamWPlanes):
-  // the forward then needs no split pass of its own
-  int nseg, kind;
-  float pscale;
-  int64_t seg_off[PL_ADAMW_MAX_SEGS], seg_n[PL_ADAMW_MAX_SEGS];
-  unsigned short* seg_h[PL_ADAMW_MAX_SEGS];
-  unsigned short* seg_l[PL_ADAMW_MAX_SEGS];
-};
-
-__device__ __forceinline__ AdamWK adamw_consts(const AdamWIn& a) {
-  const double lr = a.lr_dev ? (double)a.lr_dev[0] : (double)a.lr;
-  const double t = (double)(a.t + (a.t_dev ? (int64_t)a.t_dev[0] : 0));
-  const double bc1 = 1.0 - pow((double)a.beta1, t);
-  const double bc2 = 1.0 - pow((double)a.beta2, t);
-  AdamWK k;
-  k.decay = (float)(1.0 - lr * (double)a.wd);
-  k.one_m_b1 = (float)(1.0 - (double)a.beta1);
-  k.b2 = a.beta2;
-  k.one_m_b2 = (float)(1.0 - (double)a.beta2);
-  k.step_size = (float)(lr / bc1);
-  k.bc2_sqrt = (float)sqrt(bc2);
-  k.eps = a.eps;
-  k.gscale = a.gscale;
-  return k;
-}
-
-__device__ __forceinline__ void adamw_one(float& p, float g, float& m, float& v, const AdamWK& k) {
-  g *= k.gscale;
-  p *= k.decay;
-  m = m + (g - m) * k.one_m_b1;
-  v = v * k.b2 + (k.one_m_b2 * g) * g;
-  const float denom = sqrtf(v) / k.bc2_sqrt + k.eps;
-  p = p - k.step_size * (m / denom);
-}
-
+// ---- flat AdamW (torch single-tensor update order): AdamWIn, adamw_consts, adamw_one in adamw.h ---------
 __global__ __launch_bounds__(NTHR) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                      float* __restrict__ m, float* __restrict__ v,
                                                      int64_t n, AdamWIn in, int vec) {

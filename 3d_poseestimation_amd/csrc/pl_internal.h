@@ -230,7 +230,8 @@ struct SmallBnLayer {
 // dW != NULL: + dW = dz^T a_in (extra workgroups); dW1 != NULL: the layer below is the first one, + dW1 = dz_lo^T x1
 int launch_small_layer_bwd(const float* dz, const float* W, const float* addend, float* gout, int B, int H, int K,
                            const SmallBnLayer& below, float kscale, float* dz_lo, hipStream_t s, const float* a_in = nullptr,
-                           float* dW = nullptr, const float* x1 = nullptr, float* dW1 = nullptr, int K1 = 0);
+                           float* dW = nullptr, const float* x1 = nullptr, float* dW1 = nullptr, int K1 = 0,
+                           const struct AdamWRide* adam = nullptr);   // adam: a slice of the AdamW step on spare workgroups (adamw.h)
 int launch_small_top_bwd(const float* dy, const float* W2, const float* h, int B, int H, int O, float* gout, float* dW2,
                          float* db2, const SmallBnLayer& top, float kscale, float* dz_top, hipStream_t s,
                          const float* mpart = nullptr, int np = 0, float inv_n = 0.f, float* loss = nullptr,

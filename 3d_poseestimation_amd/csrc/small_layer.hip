@@ -18,6 +18,9 @@
 // (c >> 4) * 16 + (r >> 4) * 4 + (c & 3) -- what a ballot over the epilogue's lanes yields.
 #include <stdlib.h>
 
+#include <algorithm>
+
+#include "adamw.h"
 #include "bn_pieces.h"
 #include "philox.h"
 #include "pl_internal.h"
@@ -181,18 +184,27 @@ struct FwdArgs {
   int O;
 };
 
-// everything behind the Linear: z (bias included; thread tid < 256 holds row tid >> 2, columns c .. c + 3 of block blk)
+// everything behind the Linear: z (bias NOT yet added; thread tid < 256 holds row tid >> 2, columns c .. c + 3 of block blk)
+// what the tail reads from memory besides z: requested BEFORE the contraction, so that its round trip is not the tail's
+struct FwdPre { float4 bias, ga, be, rv; };
+__device__ __forceinline__ FwdPre fwd_prefetch(const FwdArgs& p, int c) {
+  const int tid = threadIdx.x, r = tid >> 2;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  FwdPre q = {zero, zero, zero, zero};
+  if (tid < 256) {
+    q.bias = ld4(p.bias + c); q.ga = ld4(p.gamma + c); q.be = ld4(p.beta + c);
+    if (p.resid && r < p.B) q.rv = ld4(p.resid + (size_t)r * p.H + c);
+  }
+  return q;
+}
 // Returns the thread's four outputs (zeros outside the batch and for threads >= 256).
-__device__ __forceinline__ float4 fwd_tail(const FwdArgs& p, float4 z, int blk, int c, float4 (*sm)[4]) {
+__device__ __forceinline__ float4 fwd_tail(const FwdArgs& p, float4 z, const FwdPre& pre, int blk, int c, float4 (*sm)[4]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = tid >> 2;
   const bool live = tid < 256 && r < p.B;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 ga = zero, be = zero, rv = zero;
-  if (tid < 256) {
-    ga = ld4(p.gamma + c); be = ld4(p.beta + c);
-    if (p.resid && live) rv = ld4(p.resid + (size_t)r * p.H + c);
-  }
+  const float4 ga = pre.ga, be = pre.be, rv = pre.rv;
+  z.x += pre.bias.x; z.y += pre.bias.y; z.z += pre.bias.z; z.w += pre.bias.w;
   if (!live) z = zero;
   if (live) st4(p.z + (size_t)r * p.H + c, z);
   const float Bt = (float)p.B;
@@ -299,17 +311,14 @@ __global__ __launch_bounds__(NTHR) void small_fwd_kernel(FwdArgs p) {
   __shared__ float4 sm[4][4];
   const int blk = col_block(blockIdx.x, gridDim.x);
   const int c0 = blk * COLS;
-  if (ABL != 1) contract<STEPS, false, ABL>(p.a, p.K, p.B, p.W, p.K, c0, part, stage);
-  __syncthreads();
   const int tid = threadIdx.x;
   const int c = c0 + 4 * (tid & 3);
+  const FwdPre pre = fwd_prefetch(p, c);
+  if (ABL != 1) contract<STEPS, false, ABL>(p.a, p.K, p.B, p.W, p.K, c0, part, stage);
+  __syncthreads();
   float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (tid < 256) {
-    z = gather_part(part);
-    const float4 b = ld4(p.bias + c);
-    z.x += b.x; z.y += b.y; z.z += b.z; z.w += b.w;
-  }
-  const float4 out = fwd_tail(p, z, blk, c, sm);
+  if (tid < 256) z = gather_part(part);
+  const float4 out = fwd_tail(p, z, pre, blk, c, sm);
   if (p.ypart) head_slab(p, out, blk, c0, part, stage);     // (part and stage are free behind the barriers of fwd_tail)
 }
 
@@ -324,6 +333,7 @@ __global__ __launch_bounds__(NTHR) void small_first_fwd_kernel(FwdArgs p) {
   const int blk = col_block(blockIdx.x, gridDim.x);
   const int c0 = blk * COLS;
   const int tid = threadIdx.x, K = p.K;
+  const FwdPre pre = fwd_prefetch(p, c0 + 4 * (tid & 3));
   float* xs = stage;
   float* ws = stage + ROWS * K;
   for (int idx = tid; idx < ROWS * K; idx += NTHR) xs[idx] = idx < p.B * K ? p.a[idx] : 0.f;
@@ -339,10 +349,9 @@ __global__ __launch_bounds__(NTHR) void small_first_fwd_kernel(FwdArgs p) {
       const float xv = xr[k];
       a0 = fmaf(xv, w0[k], a0); a1 = fmaf(xv, w0[K + k], a1); a2 = fmaf(xv, w0[2 * K + k], a2); a3 = fmaf(xv, w0[3 * K + k], a3);
     }
-    const float4 b = ld4(p.bias + c);
-    z = make_float4(a0 + b.x, a1 + b.y, a2 + b.z, a3 + b.w);
+    z = make_float4(a0, a1, a2, a3);
   }
-  const float4 out = fwd_tail(p, z, blk, c, sm);
+  const float4 out = fwd_tail(p, z, pre, blk, c, sm);
   if (p.ypart) head_slab(p, out, blk, c0, stage, stage + ROWS * COLS);     // (num_stage = 0: the first layer is the last)
 }
 
@@ -395,27 +404,36 @@ struct BnLo {
   float kscale;
   int B, H, rowbits;                      // rowbits: the bitmap is in the row format of bn_apply_row (elementwise.hip)
 };
-__device__ __forceinline__ float4 bnbwd_tail(const BnLo& p, float4 g, int blk, int c, float4 (*sm)[4]) {
+// what the tail reads from memory besides g: requested before the contraction that produces g
+struct BnPre { float4 zl, mu, rs, ga; uint64_t bw[4]; int bit; };
+__device__ __forceinline__ BnPre bn_prefetch(const BnLo& p, int blk, int c) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = tid >> 2;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  BnPre q = {zero, zero, zero, zero, {0, 0, 0, 0}, lane};
+  if (tid < 256) {
+    q.mu = ld4(p.mean + c); q.rs = ld4(p.rstd + c); q.ga = ld4(p.gamma + c);
+    if (r < p.B) {
+      q.zl = ld4(p.z + (size_t)r * p.H + c);
+      const uint64_t* w = p.bits + (size_t)blk * 16 + wave * 4;
+      if (p.rowbits) {
+        w = p.bits + (size_t)r * (((p.H + 255) >> 8) * 4) + (c >> 8) * 4;
+        q.bit = (c >> 2) & 63;
+      }
+      const ulonglong2 b01 = *reinterpret_cast<const ulonglong2*>(w), b23 = *reinterpret_cast<const ulonglong2*>(w + 2);
+      q.bw[0] = b01.x; q.bw[1] = b01.y; q.bw[2] = b23.x; q.bw[3] = b23.y;
+    }
+  }
+  return q;
+}
+__device__ __forceinline__ float4 bnbwd_tail(const BnLo& p, float4 g, const BnPre& pre, int blk, int c, float4 (*sm)[4]) {
+  const int tid = threadIdx.x;
   const int r = tid >> 2;
   const bool live = tid < 256 && r < p.B;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 zl = zero, mu = zero, rs = zero, ga = zero;
-  uint64_t bw[4] = {0, 0, 0, 0};
-  int bit = lane;
-  if (tid < 256) {
-    mu = ld4(p.mean + c); rs = ld4(p.rstd + c); ga = ld4(p.gamma + c);
-    if (live) {
-      zl = ld4(p.z + (size_t)r * p.H + c);
-      const uint64_t* q = p.bits + (size_t)blk * 16 + wave * 4;
-      if (p.rowbits) {
-        q = p.bits + (size_t)r * (((p.H + 255) >> 8) * 4) + (c >> 8) * 4;
-        bit = (c >> 2) & 63;
-      }
-      const ulonglong2 b01 = *reinterpret_cast<const ulonglong2*>(q), b23 = *reinterpret_cast<const ulonglong2*>(q + 2);
-      bw[0] = b01.x; bw[1] = b01.y; bw[2] = b23.x; bw[3] = b23.y;
-    }
-  }
+  const float4 zl = pre.zl, mu = pre.mu, rs = pre.rs, ga = pre.ga;
+  const uint64_t bw[4] = {pre.bw[0], pre.bw[1], pre.bw[2], pre.bw[3]};
+  const int bit = pre.bit;
   float4 dv = zero, zh = zero;
   if (live) {
     dv.x = ((bw[0] >> bit) & 1ull) ? g.x * p.kscale : 0.f;
@@ -463,6 +481,10 @@ struct BwdArgs {
   float* dW1;
   int K1;
   int B, H, K;
+  // a slice of the AdamW step (parameters whose gradients earlier launches finished and which nothing reads any more) on
+  // nblk_adam further workgroups behind the weight-gradient ones: HBM streaming beside the latency-bound layer work
+  AdamWRide adam;
+  int nblk_dw, nblk_adam;
 };
 
 // dW [16 columns of this workgroup][K1] = d^T x over the rows: d (this workgroup's dz of the first layer, from the threads'
@@ -486,24 +508,33 @@ __global__ __launch_bounds__(NTHR) void small_bwd_kernel(BwdArgs p) {
   __shared__ float part[NWAVE * ROWS * COLS];
   __shared__ float stage[NWAVE * STAGE];
   __shared__ float4 sm[12][4];
-  if ((int)blockIdx.x >= p.nblk_dx) {       // (workgroup-uniform)
+  if ((int)blockIdx.x >= p.nblk_dx + p.nblk_dw) {       // (workgroup-uniform)
+    const AdamWK k = adamw_consts(p.adam);
+    adamw_span(p.adam.p, p.adam.g, p.adam.m, p.adam.v, p.adam.n >> 2,
+               (int64_t)(blockIdx.x - p.nblk_dx - p.nblk_dw) * NTHR + threadIdx.x, (int64_t)p.nblk_adam * NTHR, k);
+    return;
+  }
+  if ((int)blockIdx.x >= p.nblk_dx) {
     dw_tile(p.dz, p.a_in, p.dW, p.B, p.K, p.H, blockIdx.x - p.nblk_dx);
     return;
   }
   const int blk = col_block(blockIdx.x, p.nblk_dx);
   const int c0 = blk * COLS;
-  contract<STEPS, true>(p.dz, p.K, p.B, p.W, p.H, c0, part, stage);
-  __syncthreads();
   const int tid = threadIdx.x;
   const int r = tid >> 2, c = c0 + 4 * (tid & 3);
   const bool live = tid < 256 && r < p.B;
+  const BnPre pre = bn_prefetch(p.lo, blk, c);
+  float4 add = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.addend && live) add = ld4(p.addend + (size_t)r * p.H + c);
+  contract<STEPS, true>(p.dz, p.K, p.B, p.W, p.H, c0, part, stage);
+  __syncthreads();
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
   if (tid < 256) {
     g = gather_part(part);
-    if (p.addend && live) { const float4 t = ld4(p.addend + (size_t)r * p.H + c); g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w; }
+    g.x += add.x; g.y += add.y; g.z += add.z; g.w += add.w;
     if (p.gout && live) st4(p.gout + (size_t)r * p.H + c, g);
   }
-  const float4 d = bnbwd_tail(p.lo, g, blk, c, sm);
+  const float4 d = bnbwd_tail(p.lo, g, pre, blk, c, sm);
   // (part and stage are free: every thread is past the barriers of bnbwd_tail)
   if (p.dW1) first_wgrad(d, p.x1, p.dW1, p.B, p.K1, c0, part, stage);
 }
@@ -531,6 +562,7 @@ __global__ __launch_bounds__(NTHR) void small_top_bwd_kernel(TopArgs p) {
   const int blk = col_block(blockIdx.x, gridDim.x);
   const int c0 = blk * COLS;
   const int tid = threadIdx.x, O = p.O;
+  const BnPre pre = bn_prefetch(p.lo, blk, c0 + 4 * (tid & 3));
   float* dys = stage;                    // [64][O]
   float* ws = stage + ROWS * 64;         // [O][16]
   float* hs = ws + 64 * COLS;            // [64][16]
@@ -550,7 +582,7 @@ __global__ __launch_bounds__(NTHR) void small_top_bwd_kernel(TopArgs p) {
     }
     if (r < p.B) st4(p.gout + (size_t)r * p.H + c, g);
   }
-  (void)bnbwd_tail(p.lo, g, blk, c, sm);
+  (void)bnbwd_tail(p.lo, g, pre, blk, c, sm);
   for (int o = tid; o < O * COLS; o += NTHR) {
     const int oo = o >> 4, cc = o & 15;
     float acc = 0.f;
@@ -697,7 +729,7 @@ int fill_lo(BnLo& lo, const SmallBnLayer& b, int B, int H, float kscale, float* 
 
 int launch_small_layer_bwd(const float* dz, const float* W, const float* addend, float* gout, int B, int H, int K,
                            const SmallBnLayer& below, float kscale, float* dz_lo, hipStream_t s, const float* a_in, float* dW,
-                           const float* x1, float* dW1, int K1) {
+                           const float* x1, float* dW1, int K1, const AdamWRide* adam) {
   if (!small_layer_ok(B, H, K)) PL_FAIL(PL_ESHAPE, "small_layer_bwd: B=%d H=%d K=%d", B, H, K);
   if (!dz || !W || dz_lo == dz) PL_FAIL(PL_EINVAL, "small_layer_bwd: bad arguments");
   if (!al16(dz) || !al16(W) || !al16(addend) || !al16(gout)) PL_FAIL(PL_EINVAL, "small_layer_bwd: 16-byte alignment");
@@ -715,6 +747,16 @@ int launch_small_layer_bwd(const float* dz, const float* W, const float* addend,
   if (dW1) {
     if (!x1 || !small_first_ok(K1)) PL_FAIL(PL_EINVAL, "small_layer_bwd: first-layer weight gradient (K1=%d)", K1);
     p.x1 = x1; p.dW1 = dW1; p.K1 = K1;
+  }
+  p.nblk_dw = extra;
+  if (adam && adam->n > 0) {
+    if (!adam->p || !adam->g || !adam->m || !adam->v || (adam->n & 3) || !al16(adam->p) || !al16(adam->g) || !al16(adam->m) ||
+        !al16(adam->v) || (adam->lr_dev != nullptr) != (adam->t_dev != nullptr))
+      PL_FAIL(PL_EINVAL, "small_layer_bwd: AdamW slice");
+    p.adam = *adam;
+    // ~2 K float4 per workgroup pass: 1 M parameters on 64 workgroups
+    p.nblk_adam = (int)std::min<int64_t>(64, (adam->n / 4 + NTHR - 1) / NTHR);
+    extra += p.nblk_adam;
   }
   const dim3 grid(H / COLS + extra), block(NTHR);
   void* prof = prof_begin_flops(2.0 * B * H * K * (dW ? 2 : 1), s);

@@ -513,12 +513,19 @@ class LinearModel(nn.Module):
         return dx
 
     # ------------------------------------------------------------------ fused train step
-    def fused_train_fwd_bwd(self, x2, target, sync=None, step_dev=None):
+    def step_carries_adamw(self, B):
+        """Does a fused step of B rows carry the AdamW update inside its backward launches (pl_lifter_train_step: batches of
+        <= 64 rows whose hidden layers run as one launch each)?"""
+        return _lib.lib().pl_lifter_step_carries_adamw(ctypes.byref(self._desc), int(B)) == 1
+
+    def fused_train_fwd_bwd(self, x2, target, sync=None, step_dev=None, adamw=None):
         """forward + MSE(mean) + backward in one library call (two when a data-parallel sync wants
         the upper layers' gradients early).  Returns (loss, y) device tensors; parameter gradients
         land in the flat arena and stay attached as .grad views.
         step_dev (graph capture, train.GraphedTrainStep): device counter of completed steps; the dropout stream
-        of the captured launches uses (the step number at capture) + *step_dev."""
+        of the captured launches uses (the step number at capture) + *step_dev.
+        adamw (a _lib.PLAdamWStep from FlatAdamW._step_struct; no sync): the optimizer step as well, in the same call
+        (pl_lifter_train_step) -- the parameters are updated in place."""
         B = x2.shape[0]
         ws = self._acquire_workspace(B)
         try:
@@ -528,14 +535,27 @@ class LinearModel(nn.Module):
             self._step += 1
             L = _lib.lib()
             self._desc.step_dev = step_dev.data_ptr() if step_dev is not None else None
-            self._mark_wplanes()
+            if adamw is not None and self.step_carries_adamw(B):
+                # (a batch of <= 64 rows never takes the operand-planes path: no refresh before it; the update below leaves
+                #  the persistent planes stale and the next call that wants them refreshes them)
+                self._desc.wplanes_valid = 0
+            else:
+                self._mark_wplanes()
 
             def call(hi, lo):
                 self._guarded(ws, lambda: L.pl_lifter_train_fwd_bwd(
                     ctypes.byref(self._desc), x2.data_ptr(), target.data_ptr(), B, ws["buf"].data_ptr(), ws["bytes"],
                     self._seed, self._step, y.data_ptr(), loss.data_ptr(), grads.data_ptr(), hi, lo,
                     _lib.current_stream_ptr()), "pl_lifter_train_fwd_bwd")
-            if sync is not None and sync.world() > 1 and _overlap_ok(sync):
+            if adamw is not None:
+                if sync is not None:
+                    raise _lib.PoseliftError("fused_train_fwd_bwd: the in-call AdamW step and a gradient sync exclude each other")
+                self._guarded(ws, lambda: L.pl_lifter_train_step(
+                    ctypes.byref(self._desc), x2.data_ptr(), target.data_ptr(), B, ws["buf"].data_ptr(), ws["bytes"],
+                    self._seed, self._step, y.data_ptr(), loss.data_ptr(), grads.data_ptr(), ctypes.byref(adamw),
+                    _lib.current_stream_ptr()), "pl_lifter_train_step")
+                self._wplanes_ver = None          # the parameters changed under the persistent weight planes
+            elif sync is not None and sync.world() > 1 and _overlap_ok(sync):
                 for hi, lo, a_lo, a_hi in self._bwd_ranges():
                     call(hi, lo)
                     sync.launch_bucket(grads[a_lo:a_hi])

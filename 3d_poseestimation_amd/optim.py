@@ -109,6 +109,20 @@ class FlatAdamW(torch.optim.Optimizer):
         # the raw-pointer write bumps no version counter: say explicitly what the planes now are
         model._wplanes_ver = model._planes_key() if planes is not None else None
 
+    # ---- the step inside the model's fused call (pl_lifter_train_step) ------------------------------------------
+    def _step_struct(self, lr, lr_dev, t, t_dev):
+        """PLAdamWStep for LinearModel.fused_train_fwd_bwd(adamw=...), or None when this optimizer does not update the
+        whole arena (frozen tensors, BN=False: torch skips grad-less parameters)."""
+        self._bind()
+        n = self._model.flat_params.numel()
+        if self._active_ranges() != [(0, n)]:
+            return None
+        g = self.param_groups[0]
+        return _lib.PLAdamWStep(self._m.data_ptr(), self._v.data_ptr(), float(lr),
+                                lr_dev.data_ptr() if lr_dev is not None else None, float(g["betas"][0]), float(g["betas"][1]),
+                                float(g["eps"]), float(g["weight_decay"]), int(t),
+                                t_dev.data_ptr() if t_dev is not None else None)
+
     # ---- graph replay (train.GraphedTrainStep): the step with t and lr read from device memory ----------------
     def _enqueue_dev(self, lr_dev, t_base, t_dev, grad_scale=1.0):
         """Enqueue (or capture) one step whose t = t_base + *t_dev and lr = *lr_dev; host-side counters are the

@@ -160,9 +160,15 @@ def train_step(model, optimizer, y1, y2, grad_sync=None):
         # the whole step is three library calls: fwd+loss+bwd, [all-reduce], AdamW.  Same kernels,
         # same results as the autograd route below; `zero_grad` is implicit (gradients are overwritten)
         with _lib.on_device(y1.device):
-            loss, y2_hat = model.fused_train_fwd_bwd(y1.reshape(y1.shape[0], -1).contiguous(),
-                                                     y2.reshape(y2.shape[0], -1).contiguous(),
-                                                     grad_sync if model._grad_sync is grad_sync else None)
+            x2, t2 = y1.reshape(y1.shape[0], -1).contiguous(), y2.reshape(y2.shape[0], -1).contiguous()
+            if grad_sync is None and model._grad_sync is None and model.step_carries_adamw(x2.shape[0]):
+                # small batches: AdamW rides in the backward launches (pl_lifter_train_step) -- one library call per step
+                adamw = optimizer._step_struct(float(optimizer.param_groups[0]["lr"]), None, optimizer._t + 1, None)
+                if adamw is not None:
+                    loss, y2_hat = model.fused_train_fwd_bwd(x2, t2, None, adamw=adamw)
+                    optimizer._advance_host(1)
+                    return loss, y2_hat.reshape(y2.shape)
+            loss, y2_hat = model.fused_train_fwd_bwd(x2, t2, grad_sync if model._grad_sync is grad_sync else None)
         optimizer.step(grad_scale=grad_sync(model) if grad_sync is not None else 1.0)
         return loss, y2_hat.reshape(y2.shape)
     optimizer.zero_grad()
@@ -217,9 +223,13 @@ class GraphedTrainStep:
             model._ensure_wplanes()          # restoring the snapshot made the persistent weight planes stale
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
+            adamw = optimizer._step_struct(0.0, self._lr_dev, t0, self._tick) if model.step_carries_adamw(B) else None
             with torch.cuda.graph(self.graph):
-                self.loss, y_hat = model.fused_train_fwd_bwd(self._x, self._y, None, step_dev=self._tick)
-                optimizer._enqueue_dev(self._lr_dev, t0, self._tick)
+                if adamw is not None:        # small batches: the optimizer step is inside the same call's launches
+                    self.loss, y_hat = model.fused_train_fwd_bwd(self._x, self._y, None, step_dev=self._tick, adamw=adamw)
+                else:
+                    self.loss, y_hat = model.fused_train_fwd_bwd(self._x, self._y, None, step_dev=self._tick)
+                    optimizer._enqueue_dev(self._lr_dev, t0, self._tick)
             self.y_hat = y_hat.reshape(self._out_shape)
             model._step = step0                                              # capturing ran nothing
         # the graph owns the dropout-stream step and AdamW's t (both = the capture-time base + the device counter):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PL_VERSION 107 /* 0.1.7: + pl_workspace_bitmap_format (small-batch layer kernels); 0.1.6: + pl_counter_add; 0.1.5: + pl_flip_pose_ex, pl_flip_w_nhwc (phase5 Flip branch); 0.1.4: + pl_planes_split_strided; 0.1.3: + pl_bn_join_bwd (0.1.2: operand-plane outputs of the BatchNorm / join kernels, pl_gemm_planes_raw) */
+#define PL_VERSION 108 /* 0.1.8: + pl_lifter_train_step, pl_lifter_step_carries_adamw; 0.1.7: + pl_workspace_bitmap_format (small-batch layer kernels); 0.1.6: + pl_counter_add; 0.1.5: + pl_flip_pose_ex, pl_flip_w_nhwc (phase5 Flip branch); 0.1.4: + pl_planes_split_strided; 0.1.3: + pl_bn_join_bwd (0.1.2: operand-plane outputs of the BatchNorm / join kernels, pl_gemm_planes_raw) */
 
 typedef enum PLStatus {
   PL_OK = 0,
@@ -190,6 +190,29 @@ int pl_lifter_bwd_layers(const PLDesc* d, const float* x, const float* dy, int64
 int pl_lifter_train_fwd_bwd(const PLDesc* d, const float* x, const float* target, int64_t B,
                             void* workspace, size_t workspace_bytes, uint64_t seed, uint64_t step,
                             float* y, float* loss, float* flat_grads, int hi, int lo, void* stream);
+
+/* The WHOLE train_1.py:75-100 iteration body in one call: pl_lifter_train_fwd_bwd(.., L, 0, ..) and optimizer.step()
+ * (train_1.py:39,89: torch.optim.AdamW) on d->params IN PLACE -- m, v: the exp_avg / exp_avg_sq arenas laid out like the
+ * parameters; t the step number (>= 1); lr_dev / t_dev != NULL (graph replay): lr = *lr_dev and t = t + *t_dev, read on
+ * the device.  At batches of <= 64 rows (the reference's own 64) whose hidden layers run as one launch each
+ * (pl_lifter_step_carries_adamw = 1) the update has no launch of its own: each backward launch carries, on spare
+ * workgroups, the slice of the arena whose gradients the launches before it finished and which nothing reads any more, and
+ * one small launch updates the bottom of the arena (first layer, first residual Linear).  Otherwise: one pl_adamw_flat(_dev)
+ * launch behind the backward pass.  Same element arithmetic as pl_adamw_flat either way.  The caller's persistent weight
+ * planes (PLDesc.wplanes) are stale afterwards. */
+typedef struct PLAdamWStep {
+  float* m;
+  float* v;
+  float lr;
+  const float* lr_dev;
+  float beta1, beta2, eps, weight_decay;
+  int64_t t;
+  const uint64_t* t_dev;
+} PLAdamWStep;
+int pl_lifter_step_carries_adamw(const PLDesc* d, int64_t B);
+int pl_lifter_train_step(const PLDesc* d, const float* x, const float* target, int64_t B, void* workspace,
+                         size_t workspace_bytes, uint64_t seed, uint64_t step, float* y, float* loss, float* flat_grads,
+                         const PLAdamWStep* opt, void* stream);
 
 /* The 3-D head forward on NHWC logits [B][H][W][J*64] (depth_dim 64, the conv path's layout): same
  * coords [B*J][3] and stats [B*J][5] as pl_softargmax_fwd(ncoord 3, centred 1).  Model.py:94-133. */

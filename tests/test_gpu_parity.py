@@ -677,6 +677,35 @@ def test_small_batch_fused_step_vs_autograd_route(pkg, monkeypatch, B, H, S):
     np.testing.assert_allclose(losses[0], losses[1], rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,H,S", [(64, 1024, 2), (20, 256, 1), (9, 512, 0)])
+def test_small_batch_adamw_inside_the_backward_launches_is_bitwise_the_separate_launch(pkg, B, H, S):
+    """pl_lifter_train_step at B <= 64: each backward launch carries a slice of the AdamW step on spare workgroups and one
+    small launch updates the bottom of the arena.  Against fused_train_fwd_bwd + optimizer.step() (one AdamW launch over the
+    whole arena): the same kernels produce the gradients, the element arithmetic is the same -- parameters, both moment
+    arenas and the losses of three steps are equal bit for bit."""
+    out = []
+    for in_call in (True, False):
+        torch.manual_seed(0)
+        m = pkg.LinearModel(34, 51, linear_size=H, num_stage=S, p_dropout=0.5).to(DEV).train()
+        m.manual_seed(3)
+        opt = pkg.FlatAdamW(m, lr=1e-3, weight_decay=0.02)
+        assert m.step_carries_adamw(B) and not m.step_carries_adamw(128)
+        losses = []
+        for i in range(3):
+            x, y = pkg.synth.synthetic_batch(B, 40 + i, DEV)
+            if in_call:
+                loss, _ = pkg.train_step(m, opt, x, y)
+            else:
+                loss, _ = m.fused_train_fwd_bwd(x.reshape(B, -1).contiguous(), y.reshape(B, -1).contiguous())
+                opt.step()
+            losses.append(loss.clone())
+        assert opt.state_dict()["state"][0]["step"] == 3
+        out.append((torch.stack(losses), m.flat_params.clone(), opt._m.clone(), opt._v.clone(), m.flat_grads.clone()))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert not torch.equal(out[0][1], pkg.LinearModel(34, 51, linear_size=H, num_stage=S).to(DEV).flat_params)
+
+
 def test_fused_train_step_is_bitwise_the_autograd_route(pkg, monkeypatch):
     """train_step's fast path (pl_lifter_train_fwd_bwd + pl_adamw_flat) and the autograd route
     (LinearModel.forward -> mse_loss -> backward -> optimizer.step) run the same kernels."""
