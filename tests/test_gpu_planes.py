@@ -392,3 +392,32 @@ def test_graphed_train_step_follows_or_refuses_host_side_counter_changes(pkg):
     mg.manual_seed(5, step=mg._step)
     with pytest.raises(pkg.PoseliftError, match="capture a new"):
         step(*batches[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graphed", [False, True])
+def test_weight_planes_follow_small_batch_steps(graphed):
+    """Training at the reference's batch of 64 (AdamW inside the backward launches: pl_lifter_train_step) never touches the
+    persistent weight planes; an evaluation at a batch on the planes path afterwards must see the NEW weights -- eager steps
+    and replayed ones (a replay bumps no tensor version: GraphedTrainStep says so itself)."""
+    import __graft_entry__ as ge
+    pkg = ge.build()
+    torch.manual_seed(0)
+    m = pkg.LinearModel(34, 51, p_dropout=0.5, compute_dtype="f16x3").to("cuda:0").train()
+    opt = pkg.FlatAdamW(m, lr=1e-2)
+    x, y = pkg.synth.synthetic_batch(64, 5, "cuda:0")
+    xe, _ = pkg.synth.synthetic_batch(256, 6, "cuda:0")
+    m.eval()
+    with torch.no_grad():
+        y0 = m(xe).clone()                      # (writes the planes of the initial weights)
+    m.train()
+    step = pkg.GraphedTrainStep(m, opt, x, y) if graphed else (lambda a, b: pkg.train_step(m, opt, a, b))
+    for _ in range(3):
+        step(x, y)
+    m.eval()
+    with torch.no_grad():
+        y1 = m(xe).clone()
+        m._wplanes_ver = None                   # force a refresh: what the planes must have been
+        y2 = m(xe).clone()
+    assert torch.equal(y1, y2)
+    assert (y1 - y0).abs().max().item() > 1e-3  # the three steps moved the weights

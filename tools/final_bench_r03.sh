@@ -9,8 +9,8 @@ python bench.py > $O/bench_1gpu.json 2> $O/bench_1gpu.err; echo bench rc=$?
 POSELIFT_DIST_BACKEND=gloo python bench.py --gpus 2 --steps 20 --warmup 5 --no-extras > $O/dp2_gloo.json 2> $O/dp2.err; echo dp2 rc=$?
 POSELIFT_DIST_BACKEND=gloo python bench.py --gpus 2 --workload cycle --batch 16 --steps 3 --warmup 1 > $O/cycle_dp2_gloo.json 2> $O/cycle_dp2.err; echo cycle-dp2 rc=$?
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-prof > $O/pmc_fetch.json 2> $O/pmc_fetch.err; echo fetch rc=$?
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-prof > $O/pmc_write.json 2> $O/pmc_write.err; echo write rc=$?
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-prof --launch eager > $O/pmc_fetch.json 2> $O/pmc_fetch.err; echo fetch rc=$?
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-prof --launch eager > $O/pmc_write.json 2> $O/pmc_write.err; echo write rc=$?
 cd $R
 python tools/pmc_traffic.py $(find $O/pmc_fetch -name "*counter_collection.csv") $(find $O/pmc_write -name "*counter_collection.csv") f16x3 $O/traffic.json > $O/traffic_summary.txt 2>&1; echo traffic rc=$?
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete

@@ -8,10 +8,10 @@ rm -rf $O; mkdir -p $O
 cd $R
 python bench.py > $O/bench_1gpu.json 2> $O/bench_1gpu.err; echo bench rc=$?
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o b -- python3 $R/bench.py --steps 60 --warmup 10 --no-extras --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err; echo trace rc=$?
-rocprofv3 --kernel-trace --output-format csv -d $O/prof_b64 -o b -- python3 $R/bench.py --batch 64 --steps 60 --warmup 10 --no-extras --no-cpu-baseline --no-prof > $O/bench_b64_under_rocprof.json 2> $O/bench_b64.err; echo trace64 rc=$?
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-prof > $O/pmc_fetch.json 2> $O/pmc_fetch.err; echo fetch rc=$?
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-prof > $O/pmc_write.json 2> $O/pmc_write.err; echo write rc=$?
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o b -- python3 $R/bench.py --steps 60 --warmup 10 --no-extras --no-cpu-baseline --launch eager > $O/bench_under_rocprof.json 2> $O/bench_under_rocprof.err; echo trace rc=$?
+rocprofv3 --kernel-trace --output-format csv -d $O/prof_b64 -o b -- python3 $R/bench.py --batch 64 --steps 60 --warmup 10 --no-extras --no-cpu-baseline --no-prof --launch eager > $O/bench_b64_under_rocprof.json 2> $O/bench_b64.err; echo trace64 rc=$?
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o f -- python3 $R/bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-prof --launch eager > $O/pmc_fetch.json 2> $O/pmc_fetch.err; echo fetch rc=$?
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o w -- python3 $R/bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-prof --launch eager > $O/pmc_write.json 2> $O/pmc_write.err; echo write rc=$?
 cd $R
 python tools/trace_anatomy.py $(find $O/prof_bench -name "*kernel_trace.csv") 10 50 > $O/anatomy.txt; echo anatomy rc=$?
 python tools/trace_anatomy.py $(find $O/prof_b64 -name "*kernel_trace.csv") 10 50 > $O/anatomy_b64.txt; echo anatomy64 rc=$?
