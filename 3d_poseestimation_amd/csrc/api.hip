@@ -233,7 +233,7 @@ Ws plan(const PLDesc* d, int64_t B) {
     slab = std::max(slab, (size_t)skinny_chunks((int)B) * std::max(d->in_dim, d->out_dim) * H * 4);
     slab = std::max(slab, skinny_narrow_out_part_floats((int)B, H) * 4);
     if (B <= thin_gemm_max_m() && B % 128) slab = std::max(slab, thin_gemm_scratch_floats((int)B, H, H) * 4);
-    if (B <= kBnSmallRows) slab = std::max(slab, (size_t)(H / 16 + 1) * B * 64 * 4);    // output-layer slabs of small_layer.hip
+    if (B <= thin_gemm_max_m()) slab = std::max(slab, (size_t)(H / 16 + 1) * B * 64 * 4);    // output-layer slabs of small_layer.hip
   }
   w.slab_floats = slab / 4;
   w.slabs = take(slab);
@@ -480,6 +480,26 @@ extern "C" int pl_lifter_fwd_eval(const PLDesc* d, const float* x, float* y, int
   const ParamLayout P = param_layout(d);
   hipStream_t s = (hipStream_t)stream;
   const int H = d->hidden;
+  // Small and ragged batches (everything the thin GEMMs took: M <= 512 rows off the tile grid): one launch per hidden layer
+  // -- Linear, the BatchNorm fold on the running statistics, ReLU, residual -- on the layer kernels of small_layer.hip with
+  // the grid also over 64-row blocks, the first layer on its vector-unit form, the output layer from the slabs the last
+  // launch leaves: 6 launches instead of 16 at B = 64 (97 -> 47 us), every row the same bits whatever the batch.
+  // POSELIFT_SMALL_EVAL=0: the thin-GEMM route (A/B).
+  static const bool small_eval_off = [] { const char* e = getenv("POSELIFT_SMALL_EVAL"); return e && e[0] == '0'; }();
+  if (!small_eval_off && d->bn && d->bn_running && !w.planes && B <= thin_gemm_max_m() && small_layer_ok(2, H, H) &&
+      small_first_ok(d->in_dim) && small_top_ok(d->out_dim)) {
+    const float* a_in = x;
+    for (int l = 0; l < w.L; ++l) {
+      const Layer ly = layer_of(d, P, nullptr, l);
+      const float* resid = (l >= 2 && (l % 2) == 0) ? f32(ws, w.act[l - 2]) : nullptr;
+      const bool last = l == w.L - 1;
+      PL_TRY(launch_small_layer_eval(a_in, ly.W, ly.b, ly.gamma, ly.beta, d->bn_eps, ly.rm, ly.rv, resid, f32(ws, w.act[l]),
+                                     (int)B, H, ly.K, s, l == 0, last ? d->params + P.off[4 * w.L] : nullptr,
+                                     last ? f32(ws, w.slabs) : nullptr, d->out_dim));
+      a_in = f32(ws, w.act[l]);
+    }
+    return launch_small_out(f32(ws, w.slabs), H / 16, (int)B, d->out_dim, d->params + P.off[4 * w.L + 1], y, s);
+  }
   for (int l = 0; l < w.L; ++l) {
     const Layer ly = layer_of(d, P, nullptr, l);
     PL_TRY(launch_bn_fold_eval(ly.b, ly.gamma, ly.beta, ly.rm, ly.rv, d->bn_eps, d->bn, H,

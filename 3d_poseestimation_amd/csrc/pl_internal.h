@@ -216,6 +216,12 @@ int launch_small_layer_fwd(const float* a, const float* W, const float* bias, co
 // ypart != NULL (the last hidden layer of a fused train step): the launch also leaves its share of the output Linear,
 // ypart [H / 16][B][64] (columns < O); launch_small_mse adds the slabs up: y, dpred = grad_scale * 2 (y - t) / (B O) and
 // small_mse_partials(B, O) partial sums of (y - t)^2 -- no launch for the output layer, none for its slab reduce
+// evaluation forward (model.eval()): the same layer kernels with the BatchNorm fold on the running statistics as tail, the
+// grid also over 64-row blocks (any M; every row the same bits whatever the batch), and launch_small_out for the output layer
+int launch_small_layer_eval(const float* a, const float* W, const float* bias, const float* gamma, const float* beta, float eps,
+                            const float* rm, const float* rv, const float* resid, float* act, int M, int H, int K, hipStream_t s,
+                            bool first = false, const float* W2 = nullptr, float* ypart = nullptr, int O = 0);
+int launch_small_out(const float* ypart, int NS, int M, int O, const float* bias, float* y, hipStream_t s);
 int small_mse_partials(int B, int O);     // partial sums launch_small_mse leaves in mpart (<= 64)
 int launch_small_mse(const float* ypart, int NS, int B, int O, const float* bias, const float* tgt, float grad_scale, float* y,
                      float* dpred, float* mpart, hipStream_t s);

@@ -182,20 +182,53 @@ struct FwdArgs {
   const float* W2;
   float* ypart;
   int O;
+  // evaluation (model.eval(), train_1.py:112-126): BatchNorm on the running statistics, Dropout the identity, nothing saved.
+  // No statistic ties the rows together, so the grid also runs over 64-row blocks (blockIdx.y; Mtot rows in all): every row
+  // sees the same contraction order whatever the batch, i.e. the same bits.
+  int eval, Mtot;
 };
+
+// the launch's row block: blockIdx.y * 64 .. + 63 of Mtot rows (evaluation; training launches have one block of B rows)
+__device__ __forceinline__ FwdArgs row_block(FwdArgs p) {
+  if (!p.eval) { p.Mtot = p.B; return p; }
+  const int r0 = blockIdx.y * ROWS;
+  p.B = min(ROWS, p.Mtot - r0);
+  p.a += (size_t)r0 * p.K;
+  if (p.resid) p.resid += (size_t)r0 * p.H;
+  p.act += (size_t)r0 * p.H;
+  if (p.ypart) p.ypart += (size_t)r0 * 64;
+  return p;
+}
 
 // everything behind the Linear: z (bias NOT yet added; thread tid < 256 holds row tid >> 2, columns c .. c + 3 of block blk)
 // what the tail reads from memory besides z: requested BEFORE the contraction, so that its round trip is not the tail's
-struct FwdPre { float4 bias, ga, be, rv; };
+struct FwdPre { float4 bias, ga, be, rv, rmean, rvar; };
 __device__ __forceinline__ FwdPre fwd_prefetch(const FwdArgs& p, int c) {
   const int tid = threadIdx.x, r = tid >> 2;
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-  FwdPre q = {zero, zero, zero, zero};
+  FwdPre q = {zero, zero, zero, zero, zero, zero};
   if (tid < 256) {
     q.bias = ld4(p.bias + c); q.ga = ld4(p.gamma + c); q.be = ld4(p.beta + c);
     if (p.resid && r < p.B) q.rv = ld4(p.resid + (size_t)r * p.H + c);
+    if (p.eval) { q.rmean = ld4(p.rm + c); q.rvar = ld4(p.rv + c); }
   }
   return q;
+}
+// the evaluation tail: y = relu(z s + t) (+ residual) with s = gamma / sqrt(running_var + eps), t = (bias - running_mean) s +
+// beta -- bn_fold_eval_kernel's fold and the GEMM epilogue's order (elementwise.hip, gemm_epilogue.h)
+__device__ __forceinline__ float4 eval_tail(const FwdArgs& p, float4 z, const FwdPre& q, int c) {
+  const int tid = threadIdx.x, r = tid >> 2;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid >= 256 || r >= p.B) return zero;
+  const float sx = q.ga.x * (1.0f / sqrtf(q.rvar.x + p.eps)), sy = q.ga.y * (1.0f / sqrtf(q.rvar.y + p.eps));
+  const float sz = q.ga.z * (1.0f / sqrtf(q.rvar.z + p.eps)), sw = q.ga.w * (1.0f / sqrtf(q.rvar.w + p.eps));
+  float4 y;
+  y.x = fmaxf(fmaf(z.x, sx, fmaf(q.bias.x - q.rmean.x, sx, q.be.x)), 0.f) + q.rv.x;
+  y.y = fmaxf(fmaf(z.y, sy, fmaf(q.bias.y - q.rmean.y, sy, q.be.y)), 0.f) + q.rv.y;
+  y.z = fmaxf(fmaf(z.z, sz, fmaf(q.bias.z - q.rmean.z, sz, q.be.z)), 0.f) + q.rv.z;
+  y.w = fmaxf(fmaf(z.w, sw, fmaf(q.bias.w - q.rmean.w, sw, q.be.w)), 0.f) + q.rv.w;
+  st4(p.act + (size_t)r * p.H + c, y);
+  return y;
 }
 // Returns the thread's four outputs (zeros outside the batch and for threads >= 256).
 __device__ __forceinline__ float4 fwd_tail(const FwdArgs& p, float4 z, const FwdPre& pre, int blk, int c, float4 (*sm)[4]) {
@@ -293,7 +326,7 @@ __device__ __forceinline__ void head_slab(const FwdArgs& p, float4 out, int blk,
   if (tid < 256) st4(hs + tid * 4, out);
   for (int idx = tid; idx < p.O * COLS; idx += NTHR) ws[(idx >> 4) * 17 + (idx & 15)] = p.W2[(size_t)(idx >> 4) * p.H + c0 + (idx & 15)];
   __syncthreads();
-  float* mine = p.ypart + (size_t)blk * p.B * 64;
+  float* mine = p.ypart + (size_t)blk * p.Mtot * 64;
   for (int idx = tid; idx < p.B * 64; idx += NTHR) {
     const int r = idx >> 6, o = idx & 63;
     if (o >= p.O) continue;
@@ -305,10 +338,11 @@ __device__ __forceinline__ void head_slab(const FwdArgs& p, float4 out, int blk,
 }
 
 template <int STEPS, int ABL = 0>
-__global__ __launch_bounds__(NTHR) void small_fwd_kernel(FwdArgs p) {
+__global__ __launch_bounds__(NTHR) void small_fwd_kernel(FwdArgs p_in) {
   __shared__ float part[NWAVE * ROWS * COLS];
   __shared__ float stage[NWAVE * STAGE];
   __shared__ float4 sm[4][4];
+  const FwdArgs p = row_block(p_in);
   const int blk = col_block(blockIdx.x, gridDim.x);
   const int c0 = blk * COLS;
   const int tid = threadIdx.x;
@@ -318,17 +352,21 @@ __global__ __launch_bounds__(NTHR) void small_fwd_kernel(FwdArgs p) {
   __syncthreads();
   float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   if (tid < 256) z = gather_part(part);
-  const float4 out = fwd_tail(p, z, pre, blk, c, sm);
-  if (p.ypart) head_slab(p, out, blk, c0, part, stage);     // (part and stage are free behind the barriers of fwd_tail)
+  const float4 out = p.eval ? eval_tail(p, z, pre, c) : fwd_tail(p, z, pre, blk, c, sm);
+  if (p.ypart) {
+    if (p.eval) __syncthreads();                             // (every thread is done with part)
+    head_slab(p, out, blk, c0, part, stage);                 // (part and stage are free behind the barriers of fwd_tail)
+  }
 }
 
 // The FIRST hidden layer (LinearModel.w1: in_dim = 34 or 51 inputs, baselineModel.py:76,90-94): the contraction is 34 steps,
 // so x (all rows) and the workgroup's 16 rows of W1 sit in LDS and a thread forms its four outputs on the vector unit (an fmaf
 // chain over k in index order); the tail is the other layers'.  K <= kFirstMaxK.
 constexpr int kFirstMaxK = 256;                        // (64 + 16) rows of K floats in the stage array
-__global__ __launch_bounds__(NTHR) void small_first_fwd_kernel(FwdArgs p) {
+__global__ __launch_bounds__(NTHR) void small_first_fwd_kernel(FwdArgs p_in) {
   __shared__ float stage[NWAVE * STAGE];
   __shared__ float4 sm[4][4];
+  const FwdArgs p = row_block(p_in);
   static_assert((ROWS + COLS) * kFirstMaxK <= NWAVE * STAGE, "stage array");
   const int blk = col_block(blockIdx.x, gridDim.x);
   const int c0 = blk * COLS;
@@ -351,8 +389,11 @@ __global__ __launch_bounds__(NTHR) void small_first_fwd_kernel(FwdArgs p) {
     }
     z = make_float4(a0, a1, a2, a3);
   }
-  const float4 out = fwd_tail(p, z, pre, blk, c, sm);
-  if (p.ypart) head_slab(p, out, blk, c0, stage, stage + ROWS * COLS);     // (num_stage = 0: the first layer is the last)
+  const float4 out = p.eval ? eval_tail(p, z, pre, c) : fwd_tail(p, z, pre, blk, c, sm);
+  if (p.ypart) {                                             // (num_stage = 0: the first layer is the last)
+    if (p.eval) __syncthreads();                             // (every thread is done with xs / ws)
+    head_slab(p, out, blk, c0, stage, stage + ROWS * COLS);
+  }
 }
 
 // The weight gradient of the same layer rides in the backward launch as extra workgroups (it needs dz and the layer's input,
@@ -632,10 +673,13 @@ __global__ __launch_bounds__(256) void small_mse_kernel(const float* __restrict_
   if (ok && q == 0) {
     if (bias) a += bias[o];
     y[i] = a;
-    const float d = a - tgt[i];
-    acc = d * d;
-    dpred[i] = d * coef;
+    if (tgt) {
+      const float d = a - tgt[i];
+      acc = d * d;
+      dpred[i] = d * coef;
+    }
   }
+  if (!tgt) return;                                          // (evaluation: y is all there is; kernel-uniform)
 #pragma unroll
   for (int w = 32; w >= 1; w >>= 1) acc += __shfl_xor(acc, w);
   if ((tid & 63) == 0) red[tid >> 6] = acc;
@@ -662,6 +706,47 @@ bool small_first_ok(int K) {
 bool small_top_ok(int O) {
   static const bool off = [] { const char* e = getenv("POSELIFT_SMALL_ENDS"); return e && e[0] == '0'; }();
   return !off && O >= 1 && O <= 64;
+}
+
+// the output Linear of an evaluation forward from the slabs the last hidden layer's launch left: y = bias + sum of slabs
+int launch_small_out(const float* ypart, int NS, int M, int O, const float* bias, float* y, hipStream_t s) {
+  if (!ypart || !y || NS < 1 || M < 1 || !small_top_ok(O)) PL_FAIL(PL_EINVAL, "small_out: bad arguments");
+  hipLaunchKernelGGL(small_mse_kernel, dim3((M * O + kMseElems - 1) / kMseElems), dim3(256), 0, s, ypart, NS, M, O, bias,
+                     (const float*)nullptr, 0.f, y, (float*)nullptr, (float*)nullptr);
+  PL_CHECK_LAUNCH("small_out");
+  return PL_OK;
+}
+
+// hidden layer l of an evaluation forward of M rows (any M: the grid runs over 64-row blocks): act = relu(bn_eval(a W^T + b))
+// (+ resid); first: the K-input first layer; ypart != NULL: + the output Linear's slabs [H / 16][M][64]
+int launch_small_layer_eval(const float* a, const float* W, const float* bias, const float* gamma, const float* beta, float eps,
+                            const float* rm, const float* rv, const float* resid, float* act, int M, int H, int K, hipStream_t s,
+                            bool first, const float* W2, float* ypart, int O) {
+  if (first ? !(small_layer_ok(2, H, H) && small_first_ok(K)) : !small_layer_ok(2, H, K))
+    PL_FAIL(PL_ESHAPE, "small_layer_eval: H=%d K=%d first=%d", H, K, (int)first);
+  if (!a || !W || !bias || !gamma || !beta || !rm || !rv || !act || M < 1) PL_FAIL(PL_EINVAL, "small_layer_eval: bad arguments");
+  if ((!first && (!al16(a) || !al16(W))) || !al16(bias) || !al16(gamma) || !al16(beta) || !al16(rm) || !al16(rv) || !al16(act) ||
+      !al16(resid))
+    PL_FAIL(PL_EINVAL, "small_layer_eval: 16-byte alignment");
+  FwdArgs p = {};
+  p.a = a; p.W = W; p.bias = bias; p.gamma = gamma; p.beta = beta; p.resid = resid;
+  p.rm = const_cast<float*>(rm); p.rv = const_cast<float*>(rv); p.act = act; p.eps = eps;
+  p.B = ROWS; p.H = H; p.K = K; p.eval = 1; p.Mtot = M;
+  if (ypart) {
+    if (!W2 || !small_top_ok(O)) PL_FAIL(PL_EINVAL, "small_layer_eval: output-layer slabs (O=%d)", O);
+    p.W2 = W2; p.ypart = ypart; p.O = O;
+  }
+  const dim3 grid(H / COLS, (M + ROWS - 1) / ROWS), block(NTHR);
+  void* prof = prof_begin_flops(2.0 * M * H * K, s);
+  if (first) hipLaunchKernelGGL(small_first_fwd_kernel, grid, block, 0, s, p);
+  else switch (K / (NWAVE * 32)) {
+    case 1: hipLaunchKernelGGL(small_fwd_kernel<1>, grid, block, 0, s, p); break;
+    case 2: hipLaunchKernelGGL(small_fwd_kernel<2>, grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL((small_fwd_kernel<4, 0>), grid, block, 0, s, p); break;
+  }
+  prof_end(prof, s);
+  PL_CHECK_LAUNCH("small_layer_eval");
+  return PL_OK;
 }
 
 int launch_small_layer_fwd(const float* a, const float* W, const float* bias, const float* gamma, const float* beta, float eps,

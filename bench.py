@@ -366,7 +366,19 @@ def batch64_latency(pkg, a, dev, warm=20, steps=50):
         res[how] = _median(ts)
     best = min(res, key=res.get)
     t = res[best]
+    # serving at the same batch: model.eval(); model(x) (train_1.py:112-126), 200 pipelined calls
+    m.eval()
+    with torch.no_grad():
+        for _ in range(20):
+            m(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            m(x)
+        torch.cuda.synchronize()
+        t_eval = (time.perf_counter() - t0) / 200
     return {"ms_per_step": round(1e3 * t, 4), "poses_per_s": round(64 / t, 1), "launch": best,
+            "eval_forward_us": round(1e6 * t_eval, 1),
             "ms_per_step_eager": round(1e3 * res["eager"], 4), "ms_per_step_hipgraph": round(1e3 * res["hipgraph"], 4),
             "how": f"median of {steps} synchronised steps after {warm} warm-ups (host launch latency included), issued as one "
                    "hipGraph replay (GraphedTrainStep) and as an eager train_step: the lower of the two"}
