@@ -188,6 +188,12 @@ SIGNATURES = {
     "pl_conv2d_planes_wgrad": (_c.c_int, [_c.c_int, _P, _c.c_int64, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64,
                                           _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _P, _c.c_float,
                                           _P, _P, _P]),
+    "pl_conv2d_planes_fwd_hw": (_c.c_int, [_c.c_int, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P,
+                                           _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                           _c.c_int, _P, _c.c_float, _P, _P, _P]),
+    "pl_conv2d_planes_wgrad_hw": (_c.c_int, [_c.c_int, _P, _c.c_int64, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64,
+                                             _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                             _c.c_int, _P, _c.c_float, _P, _P, _P]),
     "pl_prof_enable": (_c.c_int, [_c.c_int]),
     "pl_prof_read": (_c.c_int, [_c.c_double, _c.c_double, _c.POINTER(_c.c_double), _c.POINTER(_c.c_int64),
                                 _c.POINTER(_c.c_double)]),

@@ -23,6 +23,12 @@ from . import conv
 from .heads import soft_argmax_2d, soft_argmax_3d, soft_argmax_3d_nhwc
 
 
+def _stem_on_planes():
+    """POSELIFT_STEM_PLANES=0: the direct fp32 stem kernel of rounds 1-2 (same-box A/B)."""
+    import os
+    return os.environ.get("POSELIFT_STEM_PLANES", "1") != "0"
+
+
 class Bottleneck(nn.Module):
     expansion = 4
 
@@ -132,9 +138,18 @@ class ResNet(nn.Module):
 
         def cv(inp, m, stride, padding):
             return conv.conv2d_nhwc_autograd(inp, w(m), stride, padding, ar)
-        x = bnr(cv(x.float(), self.conv1, 2, 3), self.bn1, True)
+        planes = self.compute_dtype in ("f16x3", "bf16p")
+        Bf, Hf, Wf, _ = x.shape
+        if planes and _stem_on_planes() and conv.stem_planes_supported(Bf, Hf, Wf, 3, self.conv1.out_channels, 7, 7, 2, 3):
+            # the stem as a planes GEMM on the frame's pixel-pair view (conv.stem_planes), BatchNorm from its epilogue statistics
+            mode = conv._lib.PL_F16X3 if self.compute_dtype == "f16x3" else conv._lib.PL_BF16
+            link = conv.PlaneLink(mode)
+            z = conv.stem_planes(conv.stem_input_planes(x, mode), self.conv1.weight, link)
+            x = conv.batchnorm_relu_train_planes(z, self.bn1, True, False, link)
+        else:
+            x = bnr(cv(x.float(), self.conv1, 2, 3), self.bn1, True)
         x = conv.maxpool3x3s2_nhwc_autograd(x)
-        if self.compute_dtype in ("f16x3", "bf16p"):
+        if planes:
             x, xp = self._blocks_train_planes(x, cv, bnr)
             return (x, xp) if want_planes else x
         for li in (1, 2, 3, 4):

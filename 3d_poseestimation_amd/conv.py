@@ -754,13 +754,15 @@ def _conv_planes_fwd(xp, x_shape, wp, w_shape, stride, pad, out_scale, dyn_inv=N
     """pl_conv2d_planes_fwd on carriers: xp planes of x [B][H][W][Cin], wp planes of the OHWI kernel w_shape."""
     B, H, W, cin = x_shape
     cout, kh, kw, _ = w_shape
-    ho, wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+    sh, sw = stride if isinstance(stride, tuple) else (stride, stride)
+    ph, pw, pwr = pad if isinstance(pad, tuple) else (pad, pad, pad)          # (above = below, left, right)
+    ho, wo = (H + 2 * ph - kh) // sh + 1, (W + pw + pwr - kw) // sw + 1
     y = torch.empty(B, ho, wo, cout, device=xp.device)
     with _lib.on_device(xp.device):
-        rc = _lib.lib().pl_conv2d_planes_fwd(mode, xp.data_ptr(), B * H * W * cin, B, H, W, cin, wp.data_ptr(),
-                                             cout * kh * kw * cin, cout, kh, kw, stride, pad, y.data_ptr(), float(out_scale),
-                                             dyn_inv.data_ptr() if dyn_inv is not None else None,
-                                             stat.data_ptr() if stat is not None else None, _lib.current_stream_ptr())
+        rc = _lib.lib().pl_conv2d_planes_fwd_hw(mode, xp.data_ptr(), B * H * W * cin, B, H, W, cin, wp.data_ptr(),
+                                                cout * kh * kw * cin, cout, kh, kw, sh, sw, ph, pw, pwr, y.data_ptr(), float(out_scale),
+                                                dyn_inv.data_ptr() if dyn_inv is not None else None,
+                                                stat.data_ptr() if stat is not None else None, _lib.current_stream_ptr())
     _lib.check(rc, "pl_conv2d_planes_fwd")
     return y
 
@@ -874,6 +876,90 @@ class _ConvKxKPlanesFn(torch.autograd.Function):
             dw_ohwi = dw
             dw = _pgrad(wparam, lambda out: _oihw_from_ohwi(dw_ohwi, out))
         return dx, dw, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The stem (phase4_joined/Resnet.py:112-113,137: Conv2d(3, 64, 7, stride 2, padding 3, bias=False)) on the planes GEMM.
+# K = 7*7*3 = 147 fits nothing the matrix pipeline stages, so the frame is padded to 4 channels and read as pixel PAIRS
+# [B][H][W/2][8]; the window of output (oh, ow) in kernel row kh is then the four pairs ow - 2 .. ow + 1 of input row
+# 2 oh - 3 + kh: 32 contiguous values = one k-tile, of which the first pixel (kw = -1) and every fourth channel meet zero
+# weights.  A convolution with 7 x 4 taps of 8 channels, stride (2, 1), padding 3 / 3 / 2 left / 1 right: K = 224 (pl_conv2d_planes_fwd_hw;
+# the weight gradient is the gathered TN GEMM with the same geometry, its 224 columns folded back to the 147 real ones).
+# Round 3; before: a direct fp32 kernel on the vector unit (1.45 ms forward, 1.28 ms weight gradient at B = 256).
+# ---------------------------------------------------------------------------------------------------------------------
+def stem_planes_supported(B, H, W, cin, cout, kh, kw, stride, pad):
+    return (cin == 3 and cout == 64 and kh == 7 and kw == 7 and stride == 2 and pad == 3 and H % 2 == 0 and W % 4 == 0 and
+            (B * (H // 2) * (W // 2)) % 256 == 0 and B * H * W * 4 * 2 < (1 << 31))
+
+
+def stem_input_planes(frames_nhwc, mode=_lib.PL_F16X3):
+    """[B, H, W, 3] fp32 frames -> carrier of the planes of the 4-channel pixel-pair view [B, H, W/2, 8]."""
+    B, H, W, _ = frames_nhwc.shape
+    x4 = torch.nn.functional.pad(frames_nhwc.float(), (0, 1))
+    return _planes_of(x4.reshape(B, H, W // 2, 8), ACT_PLANE_SCALE, mode)
+
+
+def _stem_weight_pairs(w_oihw):
+    """[64][3][7][7] -> the 7 x 4-tap kernel on pixel pairs [64][7][4][8]: pixel p of the 8-pixel window is kw = p - 1."""
+    cout = w_oihw.shape[0]
+    wv = torch.zeros(cout, 7, 8, 4, device=w_oihw.device, dtype=torch.float32)
+    wv[:, :, 1:, :3] = w_oihw.float().permute(0, 2, 3, 1)
+    return wv.reshape(cout, 7, 4, 8)
+
+
+class _StemPlanesFn(torch.autograd.Function):
+    """z [B][H/2][W/2][64] fp32 (+ the epilogue's BatchNorm statistics) from the frame's pair-view planes and the conv1
+    parameter; backward: the weight gradient only (frames need none)."""
+
+    @staticmethod
+    def forward(ctx, xp, wparam, link):
+        B, H, W2, _ = xp.shape
+        wp = _planes_of(_stem_weight_pairs(wparam.detach()), WEIGHT_PLANE_SCALE, link.mode)
+        rows = B * (H // 2) * W2
+        stat = _stat_buffer(rows, 64, xp.device)
+        z = _conv_planes_fwd(xp, xp.shape, wp, (64, 7, 4, 8), (2, 1), (3, 2, 1), 1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), None,
+                             link.mode, stat)
+        ctx.save_for_backward(xp)
+        ctx.link, ctx.wparam = link, wparam
+        ctx.mark_non_differentiable(stat)
+        ctx.set_materialize_grads(False)
+        return z, stat
+
+    @staticmethod
+    def backward(ctx, dzp, _gstat):
+        if dzp is None or not ctx.needs_input_grad[1]:
+            return None, None, None
+        (xp,) = ctx.saved_tensors
+        wparam = ctx.wparam
+        B, H, W2, _ = xp.shape
+        _, ho, wo, cout = dzp.shape
+        dzp = dzp.contiguous()
+        inv, mode = ctx.link.dz_scale[1:], ctx.link.mode
+        L = _lib.lib()
+        n = cout * 7 * 4 * 8
+        splits = L.pl_gemm_planes_splits(cout, 7 * 4 * 8, B * ho * wo)
+        slabs = torch.empty(splits * n, device=dzp.device) if splits > 1 else None
+        dwp = torch.empty(cout, 7, 8, 4, device=dzp.device)
+        with _lib.on_device(dzp.device):
+            rc = L.pl_conv2d_planes_wgrad_hw(mode, dzp.data_ptr(), B * ho * wo * cout, xp.data_ptr(), B * H * W2 * 8, B, H, W2, 8,
+                                             cout, 7, 4, 2, 1, 3, 2, 1, dwp.data_ptr(), 1.0 / ACT_PLANE_SCALE, inv.data_ptr(),
+                                             slabs.data_ptr() if slabs is not None else None, _lib.current_stream_ptr())
+        _lib.check(rc, "pl_conv2d_planes_wgrad_hw")
+
+        def make(out):
+            g = dwp[:, :, 1:, :3].permute(0, 3, 1, 2)              # the 147 real taps, as OIHW
+            if out is None:
+                return g.contiguous()
+            out.copy_(g)
+            return out
+        return None, _pgrad(wparam, make), None
+
+
+def stem_planes(xp, weight_oihw, link):
+    """xp: stem_input_planes(frames); weight: the conv1 parameter [64][3][7][7]; z fp32 [B][H/2][W/2][64]."""
+    z, stat = _StemPlanesFn.apply(xp, weight_oihw, link)
+    link.stat = stat
+    return z
 
 
 def conv_planes(xp, weight_oihw, stride, pad, link):

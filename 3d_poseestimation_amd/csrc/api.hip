@@ -1009,12 +1009,14 @@ extern "C" int pl_gemm_planes(int layout, int mode, const float* A, const float*
 }
 
 // K slices of a planes GEMM with few output tiles (the conv weight gradients: K = pixels): enough workgroups for every
-// CU twice, slices of whole 32-k tiles, at most 64 slabs
+// CU twice, slices of whole 32-k tiles, at most 64 slabs -- 128 where the output is small enough for the slab reduce not to
+// matter (the stem's weight gradient: 64 x 224 outputs, 2 tiles, 4.2 M pixels: 128 workgroups took 1.49 ms, 256 take half)
 extern "C" int pl_gemm_planes_splits(int64_t M, int64_t N, int64_t K) {
   if (M <= 0 || N <= 0 || K <= 0) return 1;
   const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+  const int cap = M * N <= 32768 ? 128 : 64;
   int s = 1;
-  while (s < 64 && tiles * s < 512 && K % (32 * 2 * s) == 0 && K / (2 * s) >= 256) s *= 2;
+  while (s < cap && tiles * s < 512 && K % (32 * 2 * s) == 0 && K / (2 * s) >= 256) s *= 2;
   return s;
 }
 
@@ -1051,25 +1053,36 @@ extern "C" int pl_gemm_stat_groups(int64_t M) { return M > 0 && M <= INT32_MAX ?
 
 // KxK convolutions on the planes GEMM with the input gathered by the loader waves (implicit GEMM, gemm_planes16.h)
 static int conv_planes_geom(GemmArgs& e, int64_t B, int64_t H, int64_t W, int64_t Cin, int KH, int KW, int stride, int pad,
-                            int64_t* Ho, int64_t* Wo, const char* who) {
+                            int64_t* Ho, int64_t* Wo, const char* who, int stride_w = 0, int pad_w = -1, int pad_w_right = -1) {
+  if (stride_w <= 0) stride_w = stride;
+  if (pad_w < 0) pad_w = pad;
+  if (pad_w_right < 0) pad_w_right = pad_w;          // (the gather pads by its bounds test: only Wo knows the right padding)
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0)
     PL_FAIL(PL_ESHAPE, "%s: bad geometry", who);
   *Ho = (H + 2 * pad - KH) / stride + 1;
-  *Wo = (W + 2 * pad - KW) / stride + 1;
+  *Wo = (W + pad_w + pad_w_right - KW) / stride_w + 1;
   if (*Ho <= 0 || *Wo <= 0 || B * *Ho * *Wo > INT32_MAX) PL_FAIL(PL_ESHAPE, "%s: bad geometry", who);
   e.conv_cin = (int)Cin; e.conv_h = (int)H; e.conv_w = (int)W; e.conv_ho = (int)*Ho; e.conv_wo = (int)*Wo;
-  e.conv_kw = KW; e.conv_stride = stride; e.conv_pad_h = pad; e.conv_pad_w = pad;
+  e.conv_kw = KW; e.conv_stride = stride; e.conv_stride_w = stride_w; e.conv_pad_h = pad; e.conv_pad_w = pad_w;
   return PL_OK;
 }
 
 extern "C" int pl_conv2d_planes_fwd(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W, int64_t Cin,
                                     const void* w_planes, int64_t w_plane, int64_t Cout, int KH, int KW, int stride, int pad,
                                     float* y, float out_scale, const float* dyn_inv, float* stat, void* stream) {
+  return pl_conv2d_planes_fwd_hw(mode, x_planes, x_plane, B, H, W, Cin, w_planes, w_plane, Cout, KH, KW, stride, stride, pad, pad,
+                                 pad, y, out_scale, dyn_inv, stat, stream);
+}
+
+extern "C" int pl_conv2d_planes_fwd_hw(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W,
+                                       int64_t Cin, const void* w_planes, int64_t w_plane, int64_t Cout, int KH, int KW,
+                                       int stride_h, int stride_w, int pad_h, int pad_w, int pad_w_right, float* y,
+                                       float out_scale, const float* dyn_inv, float* stat, void* stream) {
   if (mode != PL_F16X3 && mode != PL_BF16) PL_FAIL(PL_EDTYPE, "pl_conv2d_planes_fwd: mode %d", mode);
   if (!x_planes || !w_planes || !y || Cout <= 0) PL_FAIL(PL_EINVAL, "pl_conv2d_planes_fwd: null pointer");
   PlanesGemmArgs g = {};
   int64_t Ho, Wo;
-  PL_TRY(conv_planes_geom(g.e, B, H, W, Cin, KH, KW, stride, pad, &Ho, &Wo, "pl_conv2d_planes_fwd"));
+  PL_TRY(conv_planes_geom(g.e, B, H, W, Cin, KH, KW, stride_h, pad_h, &Ho, &Wo, "pl_conv2d_planes_fwd", stride_w, pad_w, pad_w_right));
   const int64_t K = (int64_t)KH * KW * Cin;
   g.A = static_cast<const unsigned short*>(x_planes); g.B = static_cast<const unsigned short*>(w_planes);
   g.a_plane = x_plane; g.b_plane = w_plane; g.lda = 0; g.ldb = (int)K;
@@ -1174,11 +1187,19 @@ extern "C" int pl_deconv4x4s2_planes_fwd(int mode, const void* x_planes, int64_t
 extern "C" int pl_conv2d_planes_wgrad(int mode, const void* dz_planes, int64_t dz_plane, const void* x_planes, int64_t x_plane,
                                       int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH, int KW, int stride,
                                       int pad, float* dw, float out_scale, const float* dyn_inv, float* slabs, void* stream) {
+  return pl_conv2d_planes_wgrad_hw(mode, dz_planes, dz_plane, x_planes, x_plane, B, H, W, Cin, Cout, KH, KW, stride, stride, pad,
+                                   pad, pad, dw, out_scale, dyn_inv, slabs, stream);
+}
+
+extern "C" int pl_conv2d_planes_wgrad_hw(int mode, const void* dz_planes, int64_t dz_plane, const void* x_planes,
+                                         int64_t x_plane, int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH,
+                                         int KW, int stride_h, int stride_w, int pad_h, int pad_w, int pad_w_right, float* dw,
+                                         float out_scale, const float* dyn_inv, float* slabs, void* stream) {
   if (mode != PL_F16X3 && mode != PL_BF16) PL_FAIL(PL_EDTYPE, "pl_conv2d_planes_wgrad: mode %d", mode);
   if (!dz_planes || !x_planes || !dw || Cout <= 0) PL_FAIL(PL_EINVAL, "pl_conv2d_planes_wgrad: null pointer");
   PlanesGemmArgs g = {};
   int64_t Ho, Wo;
-  PL_TRY(conv_planes_geom(g.e, B, H, W, Cin, KH, KW, stride, pad, &Ho, &Wo, "pl_conv2d_planes_wgrad"));
+  PL_TRY(conv_planes_geom(g.e, B, H, W, Cin, KH, KW, stride_h, pad_h, &Ho, &Wo, "pl_conv2d_planes_wgrad", stride_w, pad_w, pad_w_right));
   const int64_t N = (int64_t)KH * KW * Cin, K = B * Ho * Wo;
   g.A = static_cast<const unsigned short*>(dz_planes); g.B = static_cast<const unsigned short*>(x_planes);
   g.a_plane = dz_plane; g.b_plane = x_plane; g.lda = (int)Cout; g.ldb = 0;

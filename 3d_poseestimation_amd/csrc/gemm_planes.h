@@ -64,7 +64,9 @@ struct PlanesArgs {
   // zeros (an out-of-range LDS-DMA lane writes zeros: tools/ubench/dma_oob_probe.hip):
   //   forward / data gradient (NT, gathered A): A = x, row m = output pixel (b, oh, ow), k = (kh*cv_kw + kw)*cv_cin + ci;
   //   weight gradient (TN, gathered B):          B = x, k = output pixel, column n = (kh*cv_kw + kw)*cv_cin + ci.
-  int cv_cin, cv_h, cv_w, cv_ho, cv_wo, cv_kw, cv_stride, cv_pad_h, cv_pad_w;
+  // cv_stride: the stride along h, cv_stride_w along w (the stem's pixel-pair view has 2 and 1).  cv_cin == 8 (forward only:
+  // cv_kw % 4 == 0): a 32-k tile is four neighbouring taps of one kernel row, 8 channels each.
+  int cv_cin, cv_h, cv_w, cv_ho, cv_wo, cv_kw, cv_stride, cv_stride_w, cv_pad_h, cv_pad_w;
   int abl;           // timing-only ablations (POSELIFT_ABL, wrong results by construction): 2 = no operand DMA, 4 = no MFMAs
 };
 

@@ -443,6 +443,7 @@ PlanesKern kern_of(GemmLayout layout, const PlanesGemmArgs& a) {
   k.e = a.e;
   k.p.cv_cin = a.e.conv_cin; k.p.cv_h = a.e.conv_h; k.p.cv_w = a.e.conv_w; k.p.cv_ho = a.e.conv_ho; k.p.cv_wo = a.e.conv_wo;
   k.p.cv_kw = a.e.conv_kw; k.p.cv_stride = a.e.conv_stride; k.p.cv_pad_h = a.e.conv_pad_h; k.p.cv_pad_w = a.e.conv_pad_w;
+  k.p.cv_stride_w = a.e.conv_stride_w > 0 ? a.e.conv_stride_w : a.e.conv_stride;
   k.out_scale = a.out_scale;
   k.dyn_inv = a.dyn_inv;
   static const int vec = [] { const char* e = getenv("POSELIFT_ADDEND_SCALAR"); return (e && e[0] == '1') ? 0 : 1; }();
@@ -500,7 +501,9 @@ bool planes_gemm_ok(GemmLayout layout, const PlanesGemmArgs& a) {
     const int npl_ = a.mode == plp::kF16x3 ? 2 : 1;
     if (xb >= 0x7fffffe0ll) return false;
     (void)npl_;
-    if (layout == kNT && ((e.conv_cin & 31) || e.K % e.conv_cin)) return false;
+    // (8 channels: four taps of a kernel row per 32-k tile -- the stem on pixel pairs; one K slice, no pair staging)
+    const bool cin8 = e.conv_cin == 8 && e.conv_kw % 4 == 0 && e.split_k <= 1;
+    if (layout == kNT && !cin8 && ((e.conv_cin & 31) || e.K % e.conv_cin)) return false;
     if (e.scat_on && (layout != kNT || e.split_k > 1 || e.addend || e.resid || e.relu == 2 || e.stat_sum)) return false;
     if (layout == kTN && ((e.conv_cin & 7) || e.N % e.conv_cin)) return false;
   }

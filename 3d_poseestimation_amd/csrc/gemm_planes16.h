@@ -214,11 +214,24 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
           const int ow = m % p.cv_wo, t2 = m / p.cv_wo;
           const int oh = t2 % p.cv_ho, b = t2 / p.cv_ho;
           cih0[j] = oh * p.cv_stride - p.cv_pad_h;
-          ciw0[j] = ow * p.cv_stride - p.cv_pad_w;
-          cbase[j] = ((b * p.cv_h + cih0[j]) * p.cv_w + ciw0[j]) * p.cv_cin * 2 + (((lane & 3) ^ kc16_swz(row)) << 4);
+          ciw0[j] = ow * p.cv_stride_w - p.cv_pad_w;
+          const int q = (lane & 3) ^ kc16_swz(row);          // the 16-byte chunk of the 64-byte tile row this lane fetches
+          if (p.cv_cin == 8) {
+            // 8-channel input (the stem's pixel pairs): the row's four chunks are four neighbouring taps (kw .. kw + 3) of
+            // one kernel row, so the lane's own tap decides its source pixel and its padding test
+            ciw0[j] += q;
+            cbase[j] = ((b * p.cv_h + cih0[j]) * p.cv_w + ciw0[j]) * 16;
+          } else {
+            cbase[j] = ((b * p.cv_h + cih0[j]) * p.cv_w + ciw0[j]) * p.cv_cin * 2 + (q << 4);
+          }
         }
-        ctap = kbeg / p.cv_cin; cc0 = kbeg - ctap * p.cv_cin;
-        ckh = ctap / p.cv_kw; ckw = ctap - ckh * p.cv_kw;
+        if (p.cv_cin == 8) {
+          ctap = kbeg / 8; cc0 = 0;
+          ckh = ctap / p.cv_kw; ckw = ctap - ckh * p.cv_kw;
+        } else {
+          ctap = kbeg / p.cv_cin; cc0 = kbeg - ctap * p.cv_cin;
+          ckh = ctap / p.cv_kw; ckw = ctap - ckh * p.cv_kw;
+        }
       }
       if (CONV == 2) {
         // the lane's 16-byte chunk = 8 consecutive columns n = (tap, ci .. ci+7) of the [k][N] image (cv_cin % 8 == 0)
@@ -245,8 +258,13 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
           const bool ok = (unsigned)(cih0[j] + ckh) < (unsigned)p.cv_h && (unsigned)(ciw0[j] + ckw) < (unsigned)p.cv_w;
           va[j] = ok ? cbase[j] + toff : kDmaOutOfRange;
         }
-        cc0 += 32;
-        if (cc0 >= p.cv_cin) { cc0 = 0; if (++ckw == p.cv_kw) { ckw = 0; ++ckh; } }
+        if (p.cv_cin == 8) {
+          ckw += 4;                                        // (four taps per tile; cv_kw % 4 == 0)
+          if (ckw >= p.cv_kw) { ckw = 0; ++ckh; }
+        } else {
+          cc0 += 32;
+          if (cc0 >= p.cv_cin) { cc0 = 0; if (++ckw == p.cv_kw) { ckw = 0; ++ckh; } }
+        }
       }
       if (CONV == 2) {
         // k rows = output pixels kbeg + 32 kt + 4 (lw + 4 j) + (lane >> 4): pixel -> (b, oh, ow) -> the tap's input pixel
@@ -255,7 +273,7 @@ __device__ __forceinline__ void planes_run16(const PlanesArgs& p, const int bloc
           const int pix = kbeg + kt * 32 + (lw + 4 * j) * 4 + (lane >> 4);
           const int ow = pix % p.cv_wo, t2 = pix / p.cv_wo;
           const int oh = t2 % p.cv_ho, b = t2 / p.cv_ho;
-          const int ih = oh * p.cv_stride - p.cv_pad_h + wkh, iw = ow * p.cv_stride - p.cv_pad_w + wkw;
+          const int ih = oh * p.cv_stride - p.cv_pad_h + wkh, iw = ow * p.cv_stride_w - p.cv_pad_w + wkw;
           const bool ok = (unsigned)ih < (unsigned)p.cv_h && (unsigned)iw < (unsigned)p.cv_w;
           vb[j] = ok ? (((b * p.cv_h + ih) * p.cv_w + iw) * p.cv_cin + wcol) * 2 : kDmaOutOfRange;
         }
@@ -788,7 +806,7 @@ __device__ __forceinline__ void planes_run16w(const PlanesArgs& p, const int blo
           const int ow = m % p.cv_wo, t2 = m / p.cv_wo;
           const int oh = t2 % p.cv_ho, b = t2 / p.cv_ho;
           cih0[j] = oh * p.cv_stride - p.cv_pad_h;
-          ciw0[j] = ow * p.cv_stride - p.cv_pad_w;
+          ciw0[j] = ow * p.cv_stride_w - p.cv_pad_w;
           cbase[j] = ((b * p.cv_h + cih0[j]) * p.cv_w + ciw0[j]) * p.cv_cin * 2 + (((lane & 7) ^ kc16w_swz(row)) << 4);
         }
         const int ctap = kbeg / p.cv_cin;

@@ -60,6 +60,7 @@ struct GemmArgs {
   // NHWC input x [B][H][W][Cin]; row m = (b, oh, ow), k = (kh*KW + kw)*Cin + ci, element
   // x[b][oh*stride - pad + kh][ow*stride - pad + kw][ci] or 0 outside the image.  B = weights [N][K] (OHWI).
   int conv_cin, conv_h, conv_w, conv_ho, conv_wo, conv_kw, conv_stride, conv_pad_h, conv_pad_w;
+  int conv_stride_w;        // planes convolutions: stride along w when it differs from conv_stride (along h); 0 = the same
   // BatchNorm-backward pass 1 of the layer BELOW, folded into the epilogue of the dX GEMM that produces its incoming
   // gradient (planes GEMM only; bnr_z == NULL otherwise): C is g = d(act of that layer); with its saved z, ReLU/dropout
   // bitmap, batch mean and rstd the epilogue also emits, per 64-row block and column, sum dy and sum dy*zhat

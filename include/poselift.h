@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define PL_VERSION 108 /* 0.1.8: + pl_lifter_train_step, pl_lifter_step_carries_adamw; 0.1.7: + pl_workspace_bitmap_format (small-batch layer kernels); 0.1.6: + pl_counter_add; 0.1.5: + pl_flip_pose_ex, pl_flip_w_nhwc (phase5 Flip branch); 0.1.4: + pl_planes_split_strided; 0.1.3: + pl_bn_join_bwd (0.1.2: operand-plane outputs of the BatchNorm / join kernels, pl_gemm_planes_raw) */
+#define PL_VERSION 109 /* 0.1.9: + pl_conv2d_planes_fwd_hw, pl_conv2d_planes_wgrad_hw (the stem on the planes GEMM); 0.1.8: + pl_lifter_train_step, pl_lifter_step_carries_adamw; 0.1.7: + pl_workspace_bitmap_format (small-batch layer kernels); 0.1.6: + pl_counter_add; 0.1.5: + pl_flip_pose_ex, pl_flip_w_nhwc (phase5 Flip branch); 0.1.4: + pl_planes_split_strided; 0.1.3: + pl_bn_join_bwd (0.1.2: operand-plane outputs of the BatchNorm / join kernels, pl_gemm_planes_raw) */
 
 typedef enum PLStatus {
   PL_OK = 0,
@@ -548,6 +548,19 @@ int pl_deconv4x4s2_planes_fwd_ep(int mode, const void* x_planes, int64_t x_plane
 int pl_conv2d_planes_wgrad(int mode, const void* dz_planes, int64_t dz_plane, const void* x_planes, int64_t x_plane,
                            int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH, int KW, int stride,
                            int pad, float* dw, float out_scale, const float* dyn_inv, float* slabs, void* stream);
+/* The same two with separate strides and paddings along h and w, and -- forward -- an 8-channel input when KW % 4 == 0 (a 32-k
+ * tile is then four neighbouring taps of one kernel row).  What this is for: the 7x7 / stride 2 / pad 3 stem on 3 input
+ * channels (phase4_joined/Resnet.py:112-113,137) as a planes GEMM -- the frame padded to 4 channels and viewed as pixel PAIRS
+ * [B][H][W/2][8], the kernel as 7 x 4 taps of 8 (zero where the pair window overhangs the 7 real taps), stride (2, 1),
+ * padding 3 above and below, 2 pairs left and 1 right (pad_w / pad_w_right: W/2 outputs per row): conv.stem_planes. */
+int pl_conv2d_planes_fwd_hw(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W, int64_t Cin,
+                            const void* w_planes, int64_t w_plane, int64_t Cout, int KH, int KW, int stride_h, int stride_w,
+                            int pad_h, int pad_w, int pad_w_right, float* y, float out_scale, const float* dyn_inv, float* stat,
+                            void* stream);
+int pl_conv2d_planes_wgrad_hw(int mode, const void* dz_planes, int64_t dz_plane, const void* x_planes, int64_t x_plane,
+                              int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH, int KW, int stride_h,
+                              int stride_w, int pad_h, int pad_w, int pad_w_right, float* dw, float out_scale,
+                              const float* dyn_inv, float* slabs, void* stream);
 int pl_gemm_planes_raw(int layout, int mode, const void* A, int64_t a_plane, int64_t lda, const void* B, int64_t b_plane,
                        int64_t ldb, float* C, int64_t M, int64_t N, int64_t K, const float* bias, float out_scale,
                        const float* dyn_inv, float* slabs, float* stat, void* stream);

@@ -766,6 +766,43 @@ def test_conv_planes_stride2_autograd_vs_torch_fp64(pkg, mode, B, H, W, Cin, Cou
     assert float((wd.grad.cpu().double() - wantw).abs().max()) <= tol * float(wantw.abs().max()) * (B * Ho * Wo) ** 0.5, route
 
 
+@pytest.mark.parametrize("mode", ["f16x3", "bf16p"])
+@pytest.mark.parametrize("B,H,W", [(4, 64, 64), (1, 32, 64), (2, 128, 64)])
+def test_stem_on_the_planes_gemm_vs_torch_fp64(pkg, mode, B, H, W):
+    """The 7x7 / stride 2 / pad 3 stem on 3 input channels (Resnet.py:112-113) as a planes GEMM on the frame's pixel-pair view
+    (conv.stem_planes: 7 x 4 taps of 8 channels, stride (2, 1), padding (3, 2), zero weights where the pair window overhangs the
+    seven real taps): output -- every border pixel included --, the epilogue's BatchNorm statistics and the weight gradient
+    (gathered TN GEMM, its 224 columns folded back to the 147 real ones) against torch's conv2d in fp64."""
+    from importlib import import_module
+    cv = import_module("3d_poseestimation_amd.conv")
+    lib_mode = {"f16x3": pkg._lib.PL_F16X3, "bf16p": pkg._lib.PL_BF16}[mode]
+    assert cv.stem_planes_supported(B, H, W, 3, 64, 7, 7, 2, 3)
+    g = torch.Generator().manual_seed(B * 7 + H + W)
+    x = torch.rand(B, H, W, 3, generator=g)                                       # frames in [0, 1)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    dz = torch.randn(B, H // 2, W // 2, 64, generator=g)
+    link = cv.PlaneLink(lib_mode)
+    link.dz_scale = torch.tensor([1.0, 1.0, 1.0], device=DEV)
+    wd = w.to(DEV).requires_grad_(True)
+    z = cv.stem_planes(cv.stem_input_planes(x.to(DEV), lib_mode), wd, link)
+    stat = link.stat
+    z.backward(cv._planes_of(dz.to(DEV), 1.0, lib_mode))
+    x64 = x.double().permute(0, 3, 1, 2)
+    w64 = w.double().requires_grad_(True)
+    ref = F.conv2d(x64, w64, stride=2, padding=3)
+    ref.backward(dz.double().permute(0, 3, 1, 2))
+    refn = ref.detach().permute(0, 2, 3, 1)
+    tol = 2e-2 if mode == "bf16p" else 3e-6
+    assert z.shape == refn.shape
+    assert float((z.detach().cpu().double() - refn).abs().max()) <= tol * float(refn.abs().max()) * 4
+    # the epilogue statistics: sums over 64-row groups of the output
+    rows = refn.reshape(-1, 64)
+    sums = stat[0].cpu().double().sum(0)
+    assert float((sums - rows.sum(0)).abs().max()) <= (tol * 40) * float(rows.abs().sum(0).max())
+    wantw = w64.grad
+    assert float((wd.grad.cpu().double() - wantw).abs().max()) <= tol * float(wantw.abs().max()) * (B * H * W / 4) ** 0.5
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,K,stride,pad", [
     (2, 16, 16, 64, 64, 3, 1, 1),        # layer1's conv2 in small: a 64-wide tile hanging over N
     (2, 16, 24, 32, 128, 3, 2, 1),       # stride 2, one 32-k tile per tap
