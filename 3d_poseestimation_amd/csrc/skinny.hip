@@ -20,6 +20,11 @@
 // batches: past ~48 requests per wave the queue, not the round trip, is what a wave waits for; and the saved z of the BNR
 // epilogue requested before the staging -- 14.8 against 14.6 us; and, again after the staging fix, the workgroup's 64 x 128
 // output block through LDS into 16-byte stores on 512-byte row segments -- 10.3 / 14.9 us against 10.0 / 14.5 us.  Not kept.)
+// (Round 3, after csrc/small_layer.hip found per-lane row fetches at a quarter of the coalesced rate: narrow_out with a
+// workgroup's 64 rows x 128 k of h and of W arriving as 512-byte row pieces and passing through LDS into 16x16x4 MFMA
+// fragments -- 15.2 us against 11.6 us for the form below; wide_out's 128 weight columns ([H][K] case) staged through LDS
+// instead of 17 per-lane 4-byte fetches -- 9.35 against 9.2 us.  These kernels sit on their fp32 MFMA issue (0.54 GFLOP at
+// 157 TF = 3.4 us chip-wide) plus one exposed round trip, not on the request pattern.  Not kept.)
 #include "pl_internal.h"
 
 namespace pl {
