@@ -706,6 +706,35 @@ def test_small_batch_adamw_inside_the_backward_launches_is_bitwise_the_separate_
     assert not torch.equal(out[0][1], pkg.LinearModel(34, 51, linear_size=H, num_stage=S).to(DEV).flat_params)
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "f16x3"])
+def test_train_step_entry_point_at_a_large_batch_is_fwd_bwd_plus_one_adamw_launch(pkg, dtype):
+    """pl_lifter_train_step where no backward launch has room for the optimizer (B = 256: tile GEMMs on every CU): forward,
+    loss, backward, then ONE pl_adamw_flat launch -- bitwise fused_train_fwd_bwd + optimizer.step(), and an evaluation on the
+    planes path afterwards sees the new weights (the call leaves the persistent weight planes stale and says so)."""
+    out = []
+    for in_call in (True, False):
+        torch.manual_seed(0)
+        m = pkg.LinearModel(34, 51, linear_size=256, p_dropout=0.5, compute_dtype=dtype).to(DEV).train()
+        m.manual_seed(3)
+        opt = pkg.FlatAdamW(m, lr=1e-3)
+        assert not m.step_carries_adamw(256)
+        x, y = pkg.synth.synthetic_batch(256, 41, DEV)
+        x2, y2 = x.reshape(256, -1).contiguous(), y.reshape(256, -1).contiguous()
+        for i in range(2):
+            if in_call:
+                loss, _ = m.fused_train_fwd_bwd(x2, y2, adamw=opt._step_struct(1e-3, None, opt._t + 1, None))
+                opt._advance_host(1)
+            else:
+                loss, _ = m.fused_train_fwd_bwd(x2, y2)
+                opt.step()
+        m.eval()
+        with torch.no_grad():
+            ye = m(x).clone()
+        out.append((loss.clone(), m.flat_params.clone(), opt._m.clone(), opt._v.clone(), ye))
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+
+
 def test_fused_train_step_is_bitwise_the_autograd_route(pkg, monkeypatch):
     """train_step's fast path (pl_lifter_train_fwd_bwd + pl_adamw_flat) and the autograd route
     (LinearModel.forward -> mse_loss -> backward -> optimizer.step) run the same kernels."""
