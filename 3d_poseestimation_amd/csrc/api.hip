@@ -724,6 +724,9 @@ static int bwd_impl(const PLDesc* d, const float* x, const float* dy, int64_t B,
   const float* h_last = f32(ws, w.act[w.L - 1]);
   if (skinny_supported(O, H)) {
     // dW5 partials, and -- the kernel holds every row of dy in its A fragments -- the bias gradient's partial column sums
+    // (Round 3 tried this launch on a side stream -- nothing reads its output before the closing reduce, and it and the head of
+    //  the chain below are both latency-bound -- forked and joined with events: 0.627 -> 0.660 ms per step eager, 0.644 -> 0.663
+    //  replayed from a graph, same box: the two cross-stream dependencies cost more than the 13 us launch they hide.)
     PL_TRY(launch_skinny_wide_in(dy, h_last, grads + P.off[4 * w.L], Bi, O, H, false, f32(ws, w.skp_out), s, false,
                                  f32(ws, w.outpart)));
     job(f32(ws, w.skp_out), grads + P.off[4 * w.L], skinny_in_chunks(Bi), O * H, 0, 0);
