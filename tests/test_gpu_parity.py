@@ -269,6 +269,50 @@ def test_g3_train_with_reference_dropout_masks(pkg):
     _check_grads(_grads(m), golden_state(g, "grad:"), True)
 
 
+@pytest.mark.parametrize("how", ["injected masks", "p = 0", "p = 1"])
+def test_small_batch_layer_kernels_dropout_modes_vs_oracle(pkg, how):
+    """The column-owning layer kernels (csrc/small_layer.hip: B <= 64, H % 256 == 0) under the dropout modes the Philox tests
+    do not reach: keep decisions injected as bitmaps (the reference-mask parity mode), Dropout(0) and Dropout(1) -- forward,
+    every gradient and dx against the numpy oracle with the same masks."""
+    B, H, S = 24, 256, 2
+    p = {"injected masks": 0.5, "p = 0": 0.0, "p = 1": 1.0}[how]
+    torch.manual_seed(3)
+    m = pkg.LinearModel(34, 51, linear_size=H, num_stage=S, p_dropout=p).to(DEV).train()
+    st = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(B)
+    x = torch.rand(B, 34, generator=g).to(DEV).requires_grad_(True)
+    t = (torch.rand(B, 51, generator=g) - 0.5).to(DEV)
+    L = 1 + 2 * S
+    rng = np.random.default_rng(5)
+    if how == "injected masks":
+        masks = [rng.random((B, H)) < 0.5 for _ in range(L)]
+        words = np.stack([pkg.layout.pack_keep_bitmap(k) for k in masks])
+        m.debug_inject_keep(_t(words.view(np.int64)))
+    else:
+        masks = [np.full((B, H), p == 0.0) for _ in range(L)]
+    pred = m(x)
+    loss = pkg.mse_loss(pred, t)
+    loss.backward()
+    opred, cache = orc.forward(st, x.detach().cpu().numpy(), num_stage=S, train=True, use_bn=True, p_dropout=p if p < 1 else 0.5,
+                               keep_masks=masks, on_masks=_gpu_decisions(pkg, m, L, H))
+    _assert_decisions_consistent(cache, 1e-3)
+    oloss, dpred = orc.mse_loss(opred, t.cpu().numpy())
+    ograds, odx = orc.backward(st, cache, dpred)
+    scale = max(np.abs(opred).max(), 1e-6)
+    _close(pred.detach().cpu().numpy() / scale, opred / scale, 0, 2e-5)
+    _close(loss.item(), oloss, 2e-5, 0)
+    got = _grads(m)
+    for k, v in ograds.items():
+        if (k.endswith(".bias") and "batch_norm" not in k and k != "w2.bias") or np.linalg.norm(v) == 0:
+            assert np.linalg.norm(got[k]) <= 1e-4 * (1 + np.linalg.norm(v)) or not np.linalg.norm(v) == 0
+            continue
+        rel = np.linalg.norm((got[k] - v).astype(np.float64)) / (np.linalg.norm(v.astype(np.float64)) + 1e-30)
+        assert rel < 2e-4, (k, rel)
+    if np.linalg.norm(odx) > 0:
+        rel = np.linalg.norm((x.grad.cpu().numpy() - odx).astype(np.float64)) / np.linalg.norm(odx.astype(np.float64))
+        assert rel < 2e-4, ("dx", rel)
+
+
 def test_g4_three_adamw_steps_vs_reference(pkg):
     g = load_golden("g4_adamw_small.npz")
     m = _model_from_state(pkg, golden_state(g), 64, 2, 0.0, True).train()
