@@ -171,6 +171,8 @@ struct Ws {
   bool planes;
   int pkind;                          // PlaneOut::kind: 2 fp16 pair (PL_F16X3), 1 bf16 (PL_BF16)
   std::vector<size_t> actp, wp;       // activation planes of layers 0..L-2, weight planes of layers 1..L-1
+  std::vector<size_t> sactp;          // small / ragged batches off the planes path, PL_F16X3: activation planes of layers 0..L-2
+                                      // written by the layer kernels' tails (small_layer.hip: the fp16-planes contraction)
   std::vector<char> act_f32;          // is the fp32 activation of layer l materialised?
   size_t dzp, amax, dzscale;
   // partial sums whose combine is deferred to the ONE reduce launch at the end of a backward range
@@ -253,6 +255,8 @@ Ws plan(const PLDesc* d, int64_t B) {
     w.amax = take(std::max((size_t)((H + 255) / 256) * w.RC, (size_t)(B / 64) * (H / 32)) * 2 * 4);
     w.dzscale = take((size_t)w.L * 2 * 4);
   }
+  if (!w.planes && d->dtype == PL_F16X3 && B <= thin_gemm_max_m())
+    for (int l = 0; l + 1 < w.L; ++l) w.sactp.push_back(take(w.act_bytes));           // two fp16 planes = 4 B per element
   w.total = o;
   return w;
 }
@@ -284,6 +288,14 @@ BnrSlab bnr_slab(const PLDesc* d, const Ws& w, void* ws, int rc, int n_amax, boo
 }
 
 inline bool bn_small(const PLDesc* d, const Ws& w, int64_t B) { return bn_small_ok(d, w.planes, B); }
+
+// PL_F16X3 descriptors: the small-batch layer kernels contract on fp16 planes (three MFMAs per product) instead of exact fp32
+// MFMAs -- forward and evaluation; the first layer's launch (which must then be one of them) writes the first planes.
+// POSELIFT_SMALL_F16=0: exact fp32 there, as for every other dtype (same-box A/B).
+inline bool small_f16_on(const PLDesc* d, const Ws& w) {
+  static const bool off = [] { const char* e = getenv("POSELIFT_SMALL_F16"); return e && e[0] == '0'; }();
+  return !off && d->dtype == PL_F16X3 && !w.sactp.empty() && small_first_ok(d->in_dim);
+}
 
 struct Layer {
   const float *W, *b, *gamma, *beta;
@@ -493,9 +505,11 @@ extern "C" int pl_lifter_fwd_eval(const PLDesc* d, const float* x, float* y, int
       const Layer ly = layer_of(d, P, nullptr, l);
       const float* resid = (l >= 2 && (l % 2) == 0) ? f32(ws, w.act[l - 2]) : nullptr;
       const bool last = l == w.L - 1;
+      const bool f16 = small_f16_on(d, w);
       PL_TRY(launch_small_layer_eval(a_in, ly.W, ly.b, ly.gamma, ly.beta, d->bn_eps, ly.rm, ly.rv, resid, f32(ws, w.act[l]),
                                      (int)B, H, ly.K, s, l == 0, last ? d->params + P.off[4 * w.L] : nullptr,
-                                     last ? f32(ws, w.slabs) : nullptr, d->out_dim));
+                                     last ? f32(ws, w.slabs) : nullptr, d->out_dim,
+                                     (f16 && l > 0) ? u16(ws, w.sactp[l - 1]) : nullptr, (f16 && !last) ? u16(ws, w.sactp[l]) : nullptr));
       a_in = f32(ws, w.act[l]);
     }
     return launch_small_out(f32(ws, w.slabs), H / 16, (int)B, d->out_dim, d->params + P.off[4 * w.L + 1], y, s);
@@ -600,7 +614,8 @@ static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, 
                                     (int)B, H, ly.K, d->p_dropout, seed, step, l,
                                     inject_keep ? inject_keep + (size_t)l * inj_stride : nullptr, s, d->step_dev, l == 0,
                                     slabs_here ? d->params + P.off[4 * w.L] : nullptr, slabs_here ? f32(ws, w.slabs) : nullptr,
-                                    d->out_dim));
+                                    d->out_dim, (small_f16_on(d, w) && l > 0) ? u16(ws, w.sactp[l - 1]) : nullptr,
+                                    (small_f16_on(d, w) && l + 1 < w.L) ? u16(ws, w.sactp[l]) : nullptr));
       a_in = f32(ws, w.act[l]);
       continue;
     }

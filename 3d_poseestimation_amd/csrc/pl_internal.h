@@ -213,7 +213,11 @@ int launch_small_layer_fwd(const float* a, const float* W, const float* bias, co
                            float momentum, float* rm, float* rv, int64_t* nbt, float* mean, float* rstd, const float* resid,
                            float* z, float* act, uint64_t* bits, int B, int H, int K, float pdrop, uint64_t seed, uint64_t step,
                            int layer, const uint64_t* inject_keep, hipStream_t s, const uint64_t* step_dev, bool first = false,
-                           const float* W2 = nullptr, float* ypart = nullptr, int O = 0);
+                           const float* W2 = nullptr, float* ypart = nullptr, int O = 0,
+                           const unsigned short* a_planes = nullptr, unsigned short* out_planes = nullptr);
+// a_planes (PL_F16X3 descriptors, not the first layer): the input as two fp16 planes [B][K] (h, l) -- the contraction then
+// runs as three fp16 MFMAs per product (fp32-grade, a fifth of the MFMA time of the exact fp32 form); out_planes: the output
+// also as planes [B][H], for the next layer's launch
 // ypart != NULL (the last hidden layer of a fused train step): the launch also leaves its share of the output Linear,
 // ypart [H / 16][B][64] (columns < O); launch_small_mse adds the slabs up: y, dpred = grad_scale * 2 (y - t) / (B O) and
 // small_mse_partials(B, O) partial sums of (y - t)^2 -- no launch for the output layer, none for its slab reduce
@@ -221,7 +225,8 @@ int launch_small_layer_fwd(const float* a, const float* W, const float* bias, co
 // grid also over 64-row blocks (any M; every row the same bits whatever the batch), and launch_small_out for the output layer
 int launch_small_layer_eval(const float* a, const float* W, const float* bias, const float* gamma, const float* beta, float eps,
                             const float* rm, const float* rv, const float* resid, float* act, int M, int H, int K, hipStream_t s,
-                            bool first = false, const float* W2 = nullptr, float* ypart = nullptr, int O = 0);
+                            bool first = false, const float* W2 = nullptr, float* ypart = nullptr, int O = 0,
+                            const unsigned short* a_planes = nullptr, unsigned short* out_planes = nullptr);
 int launch_small_out(const float* ypart, int NS, int M, int O, const float* bias, float* y, hipStream_t s);
 int small_mse_partials(int B, int O);     // partial sums launch_small_mse leaves in mpart (<= 64)
 int launch_small_mse(const float* ypart, int NS, int B, int O, const float* bias, const float* tgt, float grad_scale, float* y,

@@ -24,6 +24,7 @@
 #include "bn_pieces.h"
 #include "philox.h"
 #include "pl_internal.h"
+#include "plane_store.h"
 
 namespace pl {
 namespace {
@@ -51,7 +52,9 @@ __device__ __forceinline__ int col_block(int b, int nb) {
 // makes both the b128 writes and the fragment reads conflict-free); no barrier: one wave's DS operations execute in order.
 // Rows >= M read row M - 1 (valid memory); their results are never used.
 constexpr int LDR = 36;                                   // floats per row of the step image
-constexpr int STAGE = (ROWS + COLS) * LDR;                // per wave: 64 rows of A, 16 of B
+constexpr int LDH = 40;                                   // halves per row of one PLANE's step image (f16x3 form below)
+// per wave: 64 rows of A, 16 of B -- fp32 rows of LDR floats, or two fp16 planes of LDH halves each (the larger of the two)
+constexpr int STAGE = (ROWS + COLS) * (LDR > LDH ? LDR : LDH);
 template <int STEPS, bool B_KS, int ABL = 0>
 __device__ __forceinline__ void contract(const float* __restrict__ A, int lda, int M, const float* __restrict__ Bm, int ldb,
                                          int c0, float* __restrict__ part, float* __restrict__ stage) {
@@ -129,6 +132,93 @@ __device__ __forceinline__ void contract(const float* __restrict__ A, int lda, i
     for (int v = 0; v < 4; ++v) mine[(16 * t + 4 * kq + v) * COLS + i] = acc[t][v];
 }
 
+// The same contraction on fp16 operand planes (PL_F16X3 descriptors, forward): A arrives as the two planes the producing
+// launch's tail wrote (h = fp16(x), l = fp16((x - h) 2048): plane_store.h), B = W is split on the fly (16 rows per workgroup:
+// 32 elements per thread), and a 32-k step is three v_mfma_f32_16x16x32_f16 per row tile on two accumulators -- main = Ah Bh,
+// low = Ah Bl + Al Bh, result (main + low / 2048) / (S_a S_w) -- 192 MFMA cycles per step instead of the 1,024 of the exact
+// fp32 form: the 3.8 us of MFMA issue that a forward launch was waiting for becomes 0.7.  The fp32-grade arithmetic of the
+// bench's large batches (gemm_planes.h), not exact fp32: only descriptors that ask for it take it.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4h __attribute__((ext_vector_type(4)));
+template <int STEPS>
+__device__ __forceinline__ void contract_f16(const unsigned short* __restrict__ Ah, size_t a_plane, int lda, int M,
+                                             const float* __restrict__ Bm, int ldb, int c0, float w_scale, float out_scale,
+                                             float* __restrict__ part, float* __restrict__ stage) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, kq = lane >> 4;
+  const int kb = wave * STEPS * 32;
+  _Float16* img = reinterpret_cast<_Float16*>(stage + wave * STAGE);
+  _Float16* iAh = img;
+  _Float16* iAl = img + ROWS * LDH;
+  _Float16* iBh = img + 2 * ROWS * LDH;
+  _Float16* iBl = iBh + COLS * LDH;
+  uint4 gah[STEPS][4], gal[STEPS][4];
+  float4 gb[STEPS][2];
+  {
+    const int rr = lane >> 2, q8 = 8 * (lane & 3);          // A planes: four lanes per 64-byte row piece, 16 rows per instruction
+    const int br = lane >> 3, bq = 4 * (lane & 7);          // B fp32: eight lanes per 128-byte row piece
+#pragma unroll
+    for (int s = 0; s < STEPS; ++s) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned short* q = Ah + (size_t)min(16 * j + rr, M - 1) * lda + kb + 32 * s + q8;
+        gah[s][j] = *reinterpret_cast<const uint4*>(q);
+        gal[s][j] = *reinterpret_cast<const uint4*>(q + a_plane);
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) gb[s][j] = ld4(Bm + (size_t)(c0 + 8 * j + br) * ldb + kb + 32 * s + bq);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  f32x4 acc0[4], acc1[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { acc0[t] = f32x4{0.f, 0.f, 0.f, 0.f}; acc1[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+  for (int s = 0; s < STEPS; ++s) {
+    {
+      const int rr = lane >> 2, q8 = 8 * (lane & 3);
+      const int br = lane >> 3, bq = 4 * (lane & 7);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<uint4*>(iAh + (16 * j + rr) * LDH + q8) = gah[s][j];
+        *reinterpret_cast<uint4*>(iAl + (16 * j + rr) * LDH + q8) = gal[s][j];
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const float a[4] = {gb[s][j].x * w_scale, gb[s][j].y * w_scale, gb[s][j].z * w_scale, gb[s][j].w * w_scale};
+        f16x4h hh, ll;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hh[e] = (_Float16)a[e];
+          ll[e] = (_Float16)((a[e] - (float)hh[e]) * 2048.0f);
+        }
+        *reinterpret_cast<f16x4h*>(iBh + (8 * j + br) * LDH + bq) = hh;
+        *reinterpret_cast<f16x4h*>(iBl + (8 * j + br) * LDH + bq) = ll;
+      }
+    }
+    f16x8 ah[4], al[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      ah[t] = *reinterpret_cast<const f16x8*>(iAh + (16 * t + i) * LDH + 8 * kq);
+      al[t] = *reinterpret_cast<const f16x8*>(iAl + (16 * t + i) * LDH + 8 * kq);
+    }
+    const f16x8 bh = *reinterpret_cast<const f16x8*>(iBh + i * LDH + 8 * kq);
+    const f16x8 bl = *reinterpret_cast<const f16x8*>(iBl + i * LDH + 8 * kq);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      acc0[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bh, acc0[t], 0, 0, 0);
+      acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[t], bl, acc1[t], 0, 0, 0);
+      acc1[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[t], bh, acc1[t], 0, 0, 0);
+    }
+  }
+  float* mine = part + wave * (ROWS * COLS);
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+      mine[(16 * t + 4 * kq + v) * COLS + i] = fmaf(acc1[t][v], 1.0f / 2048.0f, acc0[t][v]) * out_scale;
+}
+
 // the epilogue's element of thread tid < 256: row tid >> 2 (= 16 wave + (lane >> 2)), columns c0 + 4 (tid & 3) .. + 3
 __device__ __forceinline__ float4 gather_part(const float* __restrict__ part) {
   const int tid = threadIdx.x;
@@ -186,6 +276,11 @@ struct FwdArgs {
   // No statistic ties the rows together, so the grid also runs over 64-row blocks (blockIdx.y; Mtot rows in all): every row
   // sees the same contraction order whatever the batch, i.e. the same bits.
   int eval, Mtot;
+  // PL_F16X3 descriptors: the input as fp16 planes [rows][K] (h, then l a_plane elements behind: what the launch before left in
+  // outp), this layer's output also as planes for the next launch (outp; NULL: nobody reads them)
+  const unsigned short* ap;
+  unsigned short* outp;
+  size_t a_plane, o_plane;
 };
 
 // the launch's row block: blockIdx.y * 64 .. + 63 of Mtot rows (evaluation; training launches have one block of B rows)
@@ -194,6 +289,8 @@ __device__ __forceinline__ FwdArgs row_block(FwdArgs p) {
   const int r0 = blockIdx.y * ROWS;
   p.B = min(ROWS, p.Mtot - r0);
   p.a += (size_t)r0 * p.K;
+  if (p.ap) p.ap += (size_t)r0 * p.K;
+  if (p.outp) p.outp += (size_t)r0 * p.H;
   if (p.resid) p.resid += (size_t)r0 * p.H;
   p.act += (size_t)r0 * p.H;
   if (p.ypart) p.ypart += (size_t)r0 * 64;
@@ -228,6 +325,7 @@ __device__ __forceinline__ float4 eval_tail(const FwdArgs& p, float4 z, const Fw
   y.z = fmaxf(fmaf(z.z, sz, fmaf(q.bias.z - q.rmean.z, sz, q.be.z)), 0.f) + q.rv.z;
   y.w = fmaxf(fmaf(z.w, sw, fmaf(q.bias.w - q.rmean.w, sw, q.be.w)), 0.f) + q.rv.w;
   st4(p.act + (size_t)r * p.H + c, y);
+  if (p.outp) store_planes4(PlaneDst{p.outp, p.outp + p.o_plane, kActPlaneScale, 2, 0}, (size_t)r * p.H + c, y);
   return y;
 }
 // Returns the thread's four outputs (zeros outside the batch and for threads >= 256).
@@ -314,7 +412,10 @@ __device__ __forceinline__ float4 fwd_tail(const FwdArgs& p, float4 z, const Fwd
   }
   if (lane < 4) p.bits[(size_t)blk * 16 + wave * 4 + lane] = word;
   const float4 out = make_float4(o[0] + rv.x, o[1] + rv.y, o[2] + rv.z, o[3] + rv.w);
-  if (live) st4(p.act + (size_t)r * p.H + c, out);
+  if (live) {
+    st4(p.act + (size_t)r * p.H + c, out);
+    if (p.outp) store_planes4(PlaneDst{p.outp, p.outp + p.o_plane, kActPlaneScale, 2, 0}, (size_t)r * p.H + c, out);
+  }
   return live ? out : zero;
 }
 
@@ -348,7 +449,10 @@ __global__ __launch_bounds__(NTHR) void small_fwd_kernel(FwdArgs p_in) {
   const int tid = threadIdx.x;
   const int c = c0 + 4 * (tid & 3);
   const FwdPre pre = fwd_prefetch(p, c);
-  if (ABL != 1) contract<STEPS, false, ABL>(p.a, p.K, p.B, p.W, p.K, c0, part, stage);
+  if (ABL == 0 && p.ap)
+    contract_f16<STEPS>(p.ap, p.a_plane, p.K, p.B, p.W, p.K, c0, kWeightPlaneScale, 1.0f / (kActPlaneScale * kWeightPlaneScale), part,
+                        stage);
+  else if (ABL != 1) contract<STEPS, false, ABL>(p.a, p.K, p.B, p.W, p.K, c0, part, stage);
   __syncthreads();
   float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   if (tid < 256) z = gather_part(part);
@@ -721,7 +825,8 @@ int launch_small_out(const float* ypart, int NS, int M, int O, const float* bias
 // (+ resid); first: the K-input first layer; ypart != NULL: + the output Linear's slabs [H / 16][M][64]
 int launch_small_layer_eval(const float* a, const float* W, const float* bias, const float* gamma, const float* beta, float eps,
                             const float* rm, const float* rv, const float* resid, float* act, int M, int H, int K, hipStream_t s,
-                            bool first, const float* W2, float* ypart, int O) {
+                            bool first, const float* W2, float* ypart, int O, const unsigned short* a_planes,
+                            unsigned short* out_planes) {
   if (first ? !(small_layer_ok(2, H, H) && small_first_ok(K)) : !small_layer_ok(2, H, K))
     PL_FAIL(PL_ESHAPE, "small_layer_eval: H=%d K=%d first=%d", H, K, (int)first);
   if (!a || !W || !bias || !gamma || !beta || !rm || !rv || !act || M < 1) PL_FAIL(PL_EINVAL, "small_layer_eval: bad arguments");
@@ -736,6 +841,8 @@ int launch_small_layer_eval(const float* a, const float* W, const float* bias, c
     if (!W2 || !small_top_ok(O)) PL_FAIL(PL_EINVAL, "small_layer_eval: output-layer slabs (O=%d)", O);
     p.W2 = W2; p.ypart = ypart; p.O = O;
   }
+  if ((a_planes && (first || !al16(a_planes))) || !al16(out_planes)) PL_FAIL(PL_EINVAL, "small_layer_eval: operand planes");
+  p.ap = a_planes; p.a_plane = (size_t)M * K; p.outp = out_planes; p.o_plane = (size_t)M * H;
   const dim3 grid(H / COLS, (M + ROWS - 1) / ROWS), block(NTHR);
   void* prof = prof_begin_flops(2.0 * M * H * K, s);
   if (first) hipLaunchKernelGGL(small_first_fwd_kernel, grid, block, 0, s, p);
@@ -753,7 +860,7 @@ int launch_small_layer_fwd(const float* a, const float* W, const float* bias, co
                            float momentum, float* rm, float* rv, int64_t* nbt, float* mean, float* rstd, const float* resid,
                            float* z, float* act, uint64_t* bits, int B, int H, int K, float pdrop, uint64_t seed, uint64_t step,
                            int layer, const uint64_t* inject_keep, hipStream_t s, const uint64_t* step_dev, bool first,
-                           const float* W2, float* ypart, int O) {
+                           const float* W2, float* ypart, int O, const unsigned short* a_planes, unsigned short* out_planes) {
   if (first ? !(small_layer_ok(B, H, H) && small_first_ok(K)) : !small_layer_ok(B, H, K))
     PL_FAIL(PL_ESHAPE, "small_layer_fwd: B=%d H=%d K=%d first=%d", B, H, K, (int)first);
   if (!a || !W || !bias || !gamma || !beta || !mean || !rstd || !z || !act || !bits || (rm != nullptr) != (rv != nullptr))
@@ -777,6 +884,8 @@ int launch_small_layer_fwd(const float* a, const float* W, const float* bias, co
     if (!W2 || !small_top_ok(O)) PL_FAIL(PL_EINVAL, "small_layer_fwd: output-layer slabs (O=%d)", O);
     p.W2 = W2; p.ypart = ypart; p.O = O;
   }
+  if ((a_planes && (first || !al16(a_planes))) || !al16(out_planes)) PL_FAIL(PL_EINVAL, "small_layer_fwd: operand planes");
+  p.ap = a_planes; p.a_plane = (size_t)B * K; p.outp = out_planes; p.o_plane = (size_t)B * H;
   const dim3 grid(H / COLS), block(NTHR);
   void* prof = prof_begin_flops(2.0 * B * H * K, s);
   if (first) {

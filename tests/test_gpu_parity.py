@@ -546,7 +546,8 @@ def test_full_size_properties(pkg, full):
     (37, 256, 2, 34, 51, True, "fp32"),      #   direction (small_layer.hip), ragged rows,
     (2, 256, 1, 34, 51, True, "fp32"),       #   two rows,
     (5, 256, 1, 34, 51, True, "fp32"),
-    (16, 512, 3, 51, 34, True, "f16x3"),     #   three stages, the other K split
+    (16, 512, 3, 51, 34, True, "f16x3"),     #   three stages, the other K split; f16x3: the forward launches contract on
+    (64, 1024, 2, 34, 51, True, "f16x3"),    #   fp16 planes (three MFMAs per product) written by the launch before
     (65, 256, 2, 34, 51, True, "fp32"),      # 64 + 1 rows
     (100, 64, 2, 51, 34, True, "fp32"),      # the phase5 projector LinearModel(51, 34, linear_size=64)
     (129, 1024, 2, 34, 51, True, "fp32"),    # full width, ragged rows: whole-tile GEMMs fall back to edge path
@@ -721,8 +722,8 @@ def test_small_batch_fused_step_vs_autograd_route(pkg, monkeypatch, B, H, S):
     np.testing.assert_allclose(losses[0], losses[1], rtol=1e-5)
 
 
-@pytest.mark.parametrize("B,H,S", [(64, 1024, 2), (20, 256, 1), (9, 512, 0)])
-def test_small_batch_adamw_inside_the_backward_launches_is_bitwise_the_separate_launch(pkg, B, H, S):
+@pytest.mark.parametrize("B,H,S,dtype", [(64, 1024, 2, "fp32"), (20, 256, 1, "fp32"), (9, 512, 0, "fp32"), (64, 1024, 2, "f16x3")])
+def test_small_batch_adamw_inside_the_backward_launches_is_bitwise_the_separate_launch(pkg, B, H, S, dtype):
     """pl_lifter_train_step at B <= 64: each backward launch carries a slice of the AdamW step on spare workgroups and one
     small launch updates the bottom of the arena.  Against fused_train_fwd_bwd + optimizer.step() (one AdamW launch over the
     whole arena): the same kernels produce the gradients, the element arithmetic is the same -- parameters, both moment
@@ -730,7 +731,7 @@ def test_small_batch_adamw_inside_the_backward_launches_is_bitwise_the_separate_
     out = []
     for in_call in (True, False):
         torch.manual_seed(0)
-        m = pkg.LinearModel(34, 51, linear_size=H, num_stage=S, p_dropout=0.5).to(DEV).train()
+        m = pkg.LinearModel(34, 51, linear_size=H, num_stage=S, p_dropout=0.5, compute_dtype=dtype).to(DEV).train()
         m.manual_seed(3)
         opt = pkg.FlatAdamW(m, lr=1e-3, weight_decay=0.02)
         assert m.step_carries_adamw(B) and not m.step_carries_adamw(128)
@@ -747,7 +748,7 @@ def test_small_batch_adamw_inside_the_backward_launches_is_bitwise_the_separate_
         out.append((torch.stack(losses), m.flat_params.clone(), opt._m.clone(), opt._v.clone(), m.flat_grads.clone()))
     for a, b in zip(*out):
         assert torch.equal(a, b)
-    assert not torch.equal(out[0][1], pkg.LinearModel(34, 51, linear_size=H, num_stage=S).to(DEV).flat_params)
+    assert not torch.equal(out[0][1], pkg.LinearModel(34, 51, linear_size=H, num_stage=S, compute_dtype=dtype).to(DEV).flat_params)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "f16x3"])
