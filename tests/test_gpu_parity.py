@@ -546,6 +546,8 @@ def test_full_size_properties(pkg, full):
     (37, 256, 2, 34, 51, True, "fp32"),      #   direction (small_layer.hip), ragged rows,
     (2, 256, 1, 34, 51, True, "fp32"),       #   two rows,
     (5, 256, 1, 34, 51, True, "fp32"),
+    (32, 256, 1, 300, 70, True, "fp32"),     #   300 inputs, 70 outputs: first / output layer NOT on the layer kernels (row-format
+                                             #   bitmap for layer 0, tile format above it; generic GEMMs at both ends)
     (16, 512, 3, 51, 34, True, "f16x3"),     #   three stages, the other K split; f16x3: the forward launches contract on
     (64, 1024, 2, 34, 51, True, "f16x3"),    #   fp16 planes (three MFMAs per product) written by the launch before
     (65, 256, 2, 34, 51, True, "fp32"),      # 64 + 1 rows
