@@ -231,6 +231,26 @@ __device__ __forceinline__ float4 gather_part(const float* __restrict__ part) {
   return v;
 }
 
+// dst[idx] = src(idx) for idx < n, by the whole workgroup: BATCH loads per thread requested before the first is stored (an
+// element loop keeps ONE 4-byte load in flight per thread: 5-7 dependent round trips for the 2-3 K floats staged here)
+template <int BATCH, class F>
+__device__ __forceinline__ void fill_lds(float* dst, int n, F src) {
+  for (int base = threadIdx.x; base < n; base += BATCH * NTHR) {
+    float v[BATCH];
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int idx = base + u * NTHR;
+      v[u] = src(min(idx, n - 1));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < BATCH; ++u) {
+      const int idx = base + u * NTHR;
+      if (idx < n) dst[idx] = v[u];
+    }
+  }
+}
+
 // column sums over the 64 rows of NV float4 values per thread (threads >= 256 pass zeros and get garbage): the wave's 16 rows
 // by butterfly over lanes l ^ 4, 8, 16, 32, the four epilogue waves through LDS in wave order
 template <int NV>
@@ -425,7 +445,19 @@ __device__ __forceinline__ float4 fwd_tail(const FwdArgs& p, float4 z, const Fwd
 __device__ __forceinline__ void head_slab(const FwdArgs& p, float4 out, int blk, int c0, float* hs, float* ws) {
   const int tid = threadIdx.x;
   if (tid < 256) st4(hs + tid * 4, out);
-  for (int idx = tid; idx < p.O * COLS; idx += NTHR) ws[(idx >> 4) * 17 + (idx & 15)] = p.W2[(size_t)(idx >> 4) * p.H + c0 + (idx & 15)];
+  {
+    float v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = min(tid + u * NTHR, p.O * COLS - 1);
+      v[u] = p.W2[(size_t)(idx >> 4) * p.H + c0 + (idx & 15)];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + u * NTHR;
+      if (idx < p.O * COLS) ws[(idx >> 4) * 17 + (idx & 15)] = v[u];
+    }
+  }
   __syncthreads();
   float* mine = p.ypart + (size_t)blk * p.Mtot * 64;
   for (int idx = tid; idx < p.B * 64; idx += NTHR) {
@@ -478,8 +510,13 @@ __global__ __launch_bounds__(NTHR) void small_first_fwd_kernel(FwdArgs p_in) {
   const FwdPre pre = fwd_prefetch(p, c0 + 4 * (tid & 3));
   float* xs = stage;
   float* ws = stage + ROWS * K;
-  for (int idx = tid; idx < ROWS * K; idx += NTHR) xs[idx] = idx < p.B * K ? p.a[idx] : 0.f;
-  for (int idx = tid; idx < COLS * K; idx += NTHR) ws[idx] = p.W[(size_t)c0 * K + idx];
+  {
+    const float* __restrict__ xa = p.a;
+    const float* __restrict__ wa = p.W + (size_t)c0 * K;
+    const int nx = p.B * K;
+    fill_lds<8>(xs, ROWS * K, [&](int idx) { return idx < nx ? xa[idx] : 0.f; });
+    fill_lds<2>(ws, COLS * K, [&](int idx) { return wa[idx]; });
+  }
   __syncthreads();
   const int c = c0 + 4 * (tid & 3);
   float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -638,7 +675,7 @@ __device__ __forceinline__ void first_wgrad(float4 d, const float* __restrict__ 
                                             float* ds, float* xs) {
   const int tid = threadIdx.x;
   if (tid < 256) st4(ds + tid * 4, d);                   // [row][16]
-  for (int idx = tid; idx < B * K1; idx += NTHR) xs[idx] = x[idx];
+  fill_lds<8>(xs, B * K1, [&](int idx) { return x[idx]; });
   __syncthreads();
   for (int o = tid; o < COLS * K1; o += NTHR) {
     const int cc = o / K1, k = o - cc * K1;
@@ -711,9 +748,34 @@ __global__ __launch_bounds__(NTHR) void small_top_bwd_kernel(TopArgs p) {
   float* dys = stage;                    // [64][O]
   float* ws = stage + ROWS * 64;         // [O][16]
   float* hs = ws + 64 * COLS;            // [64][16]
-  for (int idx = tid; idx < ROWS * O; idx += NTHR) dys[idx] = idx < p.B * O ? p.dy[idx] : 0.f;
-  for (int idx = tid; idx < O * COLS; idx += NTHR) ws[idx] = p.W2[(size_t)(idx >> 4) * p.H + c0 + (idx & 15)];
-  for (int idx = tid; idx < ROWS * COLS; idx += NTHR) hs[idx] = (idx >> 4) < p.B ? p.h[(size_t)(idx >> 4) * p.H + c0 + (idx & 15)] : 0.f;
+  {
+    // (everything the workgroup stages is requested before the first LDS store: 8 + 2 + 2 loads per thread, one round trip)
+    const int nd = p.B * O;
+    float vd[8], vw[2], vh[2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + u * NTHR;
+      vd[u] = idx < nd ? p.dy[idx] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int iw = min(tid + u * NTHR, O * COLS - 1), ih = tid + u * NTHR;
+      vw[u] = p.W2[(size_t)(iw >> 4) * p.H + c0 + (iw & 15)];
+      vh[u] = (ih >> 4) < p.B ? p.h[(size_t)(ih >> 4) * p.H + c0 + (ih & 15)] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = tid + u * NTHR;
+      if (idx < ROWS * O) dys[idx] = vd[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int idx = tid + u * NTHR;
+      if (idx < O * COLS) ws[idx] = vw[u];
+      hs[idx] = vh[u];
+    }
+  }
   __syncthreads();
   const int r = tid >> 2, c = c0 + 4 * (tid & 3);
   float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
