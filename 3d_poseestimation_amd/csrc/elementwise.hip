@@ -1708,7 +1708,8 @@ static int adamw_launch(float* p, const float* g, float* m, float* v, int64_t n,
   const int vec = aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v);
   int64_t work = vec ? (n >> 2) : n;
   int blocks = (int)((work + NTHR - 1) / NTHR);
-  if (blocks > 2048) blocks = 2048;
+  static const int cap = [] { const char* e = getenv("POSELIFT_ADAM_BLOCKS"); return e ? atoi(e) : 512; }();   // (same-box sweep, B = 64 step: 256 / 512 / 1024 / 2048 -> 0.1297 / 0.1289 / 0.1295 / 0.1304 ms; B = 4096: no difference)
+  if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(NTHR), 0, (hipStream_t)stream, p, g, m, v, n, in, vec);
   PL_CHECK_LAUNCH("adamw");

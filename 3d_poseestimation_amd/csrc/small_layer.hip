@@ -788,14 +788,16 @@ __global__ __launch_bounds__(NTHR) void small_top_bwd_kernel(TopArgs p) {
       g.x = fmaf(dv, wv.x, g.x); g.y = fmaf(dv, wv.y, g.y); g.z = fmaf(dv, wv.z, g.z); g.w = fmaf(dv, wv.w, g.w);
     }
     if (r < p.B) st4(p.gout + (size_t)r * p.H + c, g);
+  } else {
+    // (waves 4-7 have no element of the tail: the weight-gradient columns are theirs, beside the g loop of waves 0-3)
+    for (int o = tid - 256; o < O * COLS; o += 256) {
+      const int oo = o >> 4, cc = o & 15;
+      float acc = 0.f;
+      for (int rr = 0; rr < p.B; ++rr) acc = fmaf(dys[rr * O + oo], hs[rr * COLS + cc], acc);
+      p.dW2[(size_t)oo * p.H + c0 + cc] = acc;
+    }
   }
   (void)bnbwd_tail(p.lo, g, pre, blk, c, sm);
-  for (int o = tid; o < O * COLS; o += NTHR) {
-    const int oo = o >> 4, cc = o & 15;
-    float acc = 0.f;
-    for (int rr = 0; rr < p.B; ++rr) acc = fmaf(dys[rr * O + oo], hs[rr * COLS + cc], acc);
-    p.dW2[(size_t)oo * p.H + c0 + cc] = acc;
-  }
   if (blockIdx.x == 0 && tid < O) {
     float acc = 0.f;
     for (int rr = 0; rr < p.B; ++rr) acc += dys[rr * O + tid];
