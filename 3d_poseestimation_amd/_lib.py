@@ -191,6 +191,9 @@ SIGNATURES = {
     "pl_conv2d_planes_fwd_hw": (_c.c_int, [_c.c_int, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P,
                                            _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                            _c.c_int, _P, _c.c_float, _P, _P, _P]),
+    "pl_conv2d_planes_fwd_ep_hw": (_c.c_int, [_c.c_int, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64, _P,
+                                              _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                              _c.c_int, _P, _c.c_float, _c.POINTER(PLPlanesEpilogue), _P]),
     "pl_conv2d_planes_wgrad_hw": (_c.c_int, [_c.c_int, _P, _c.c_int64, _P, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64,
                                              _c.c_int64, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                              _c.c_int, _P, _c.c_float, _P, _P, _P]),

@@ -93,6 +93,8 @@ class ResNet(nn.Module):
                 mode = conv._lib.PL_F16X3 if self.compute_dtype == "f16x3" else conv._lib.PL_BF16
                 for name in [k for k, x in f.items() if not isinstance(x, tuple) and k != "conv1"]:
                     f[name + "@p"] = conv._planes_of(f[name], conv.WEIGHT_PLANE_SCALE, mode)
+                # the stem's 7 x 4-tap kernel on pixel pairs (conv.stem_planes; f["conv1"] is OHWI)
+                f["conv1@pairs"] = conv._planes_of(conv._stem_weight_pairs(f["conv1"], ohwi=True), conv.WEIGHT_PLANE_SCALE, mode)
             self._cache = (v, f)
         return self._cache[1]
 
@@ -105,7 +107,13 @@ class ResNet(nn.Module):
         cpe = conv.conv2d_planes_eval
         with torch.no_grad():
             s, b = f["bn1"]
-            x = conv.conv2d_nhwc(x_nhwc.float(), f["conv1"], 2, 3, s, b, relu=1, arith=self.compute_dtype)
+            Bf, Hf, Wf, _ = x_nhwc.shape
+            if _stem_on_planes() and conv.stem_planes_supported(Bf, Hf, Wf, 3, self.conv1.out_channels, 7, 7, 2, 3):
+                # the stem as a planes GEMM on the frame's pixel-pair view, folded BatchNorm + ReLU in its epilogue
+                x, _ = cpe(conv.stem_input_planes(x_nhwc, mode), f["conv1@pairs"], (self.conv1.out_channels, 7, 4, 8), (2, 1), (3, 2, 1),
+                           s, b, relu=1, mode=mode)
+            else:
+                x = conv.conv2d_nhwc(x_nhwc.float(), f["conv1"], 2, 3, s, b, relu=1, arith=self.compute_dtype)
             x = conv.maxpool3x3s2_nhwc(x)
             xp = conv._planes_of(x, conv.ACT_PLANE_SCALE, mode)
             for li in (1, 2, 3, 4):

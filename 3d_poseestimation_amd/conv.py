@@ -899,11 +899,12 @@ def stem_input_planes(frames_nhwc, mode=_lib.PL_F16X3):
     return _planes_of(x4.reshape(B, H, W // 2, 8), ACT_PLANE_SCALE, mode)
 
 
-def _stem_weight_pairs(w_oihw):
-    """[64][3][7][7] -> the 7 x 4-tap kernel on pixel pairs [64][7][4][8]: pixel p of the 8-pixel window is kw = p - 1."""
+def _stem_weight_pairs(w_oihw, ohwi=False):
+    """[64][3][7][7] (or, ohwi: [64][7][7][3]) -> the 7 x 4-tap kernel on pixel pairs [64][7][4][8]: pixel p of the 8-pixel
+    window is kw = p - 1."""
     cout = w_oihw.shape[0]
     wv = torch.zeros(cout, 7, 8, 4, device=w_oihw.device, dtype=torch.float32)
-    wv[:, :, 1:, :3] = w_oihw.float().permute(0, 2, 3, 1)
+    wv[:, :, 1:, :3] = w_oihw.float() if ohwi else w_oihw.float().permute(0, 2, 3, 1)
     return wv.reshape(cout, 7, 4, 8)
 
 
@@ -1125,18 +1126,20 @@ def conv2d_planes_eval(xp, wp, w_shape, stride=1, padding=0, scale=None, shift=N
     import ctypes
     B, H, W, cin = xp.shape
     cout, kh, kw, _ = w_shape
-    ho, wo = (H + 2 * padding - kh) // stride + 1, (W + 2 * padding - kw) // stride + 1
+    sh, sw = stride if isinstance(stride, tuple) else (stride, stride)
+    ph, pw, pwr = padding if isinstance(padding, tuple) else (padding, padding, padding)     # (above = below, left, right)
+    ho, wo = (H + 2 * ph - kh) // sh + 1, (W + pw + pwr - kw) // sw + 1
     y = torch.empty(B, ho, wo, cout, device=xp.device) if want_f32 else None
     yp = torch.empty(B, ho, wo, cout, device=xp.device) if want_planes else None
     opt = [_opt(scale, "scale", cout), _opt(shift, "shift", cout), _opt(bias, "bias", cout),
            _opt(resid, "resid", B * ho * wo * cout)]
     ep = _epilogue(opt[0], opt[1], opt[2], relu, opt[3], yp)
     with _lib.on_device(xp.device):
-        rc = _lib.lib().pl_conv2d_planes_fwd_ep(mode, xp.data_ptr(), B * H * W * cin, B, H, W, cin, wp.data_ptr(),
-                                                cout * kh * kw * cin, cout, kh, kw, stride, padding,
-                                                y.data_ptr() if y is not None else None,
-                                                1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), ctypes.byref(ep),
-                                                _lib.current_stream_ptr())
+        rc = _lib.lib().pl_conv2d_planes_fwd_ep_hw(mode, xp.data_ptr(), B * H * W * cin, B, H, W, cin, wp.data_ptr(),
+                                                   cout * kh * kw * cin, cout, kh, kw, sh, sw, ph, pw, pwr,
+                                                   y.data_ptr() if y is not None else None,
+                                                   1.0 / (ACT_PLANE_SCALE * WEIGHT_PLANE_SCALE), ctypes.byref(ep),
+                                                   _lib.current_stream_ptr())
     _lib.check(rc, "pl_conv2d_planes_fwd_ep")
     return y, yp
 

@@ -1131,11 +1131,19 @@ static int apply_planes_epilogue(GemmArgs& e, int mode, const PLPlanesEpilogue* 
 extern "C" int pl_conv2d_planes_fwd_ep(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W,
                                        int64_t Cin, const void* w_planes, int64_t w_plane, int64_t Cout, int KH, int KW,
                                        int stride, int pad, float* y, float out_scale, const PLPlanesEpilogue* ep, void* stream) {
+  return pl_conv2d_planes_fwd_ep_hw(mode, x_planes, x_plane, B, H, W, Cin, w_planes, w_plane, Cout, KH, KW, stride, stride, pad,
+                                    pad, pad, y, out_scale, ep, stream);
+}
+
+extern "C" int pl_conv2d_planes_fwd_ep_hw(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W,
+                                          int64_t Cin, const void* w_planes, int64_t w_plane, int64_t Cout, int KH, int KW,
+                                          int stride_h, int stride_w, int pad_h, int pad_w, int pad_w_right, float* y,
+                                          float out_scale, const PLPlanesEpilogue* ep, void* stream) {
   if (mode != PL_F16X3 && mode != PL_BF16) PL_FAIL(PL_EDTYPE, "pl_conv2d_planes_fwd_ep: mode %d", mode);
   if (!x_planes || !w_planes || (!y && !(ep && ep->y_planes)) || Cout <= 0) PL_FAIL(PL_EINVAL, "pl_conv2d_planes_fwd_ep: null pointer");
   PlanesGemmArgs g = {};
   int64_t Ho, Wo;
-  PL_TRY(conv_planes_geom(g.e, B, H, W, Cin, KH, KW, stride, pad, &Ho, &Wo, "pl_conv2d_planes_fwd_ep"));
+  PL_TRY(conv_planes_geom(g.e, B, H, W, Cin, KH, KW, stride_h, pad_h, &Ho, &Wo, "pl_conv2d_planes_fwd_ep", stride_w, pad_w, pad_w_right));
   const int64_t K = (int64_t)KH * KW * Cin;
   g.A = static_cast<const unsigned short*>(x_planes); g.B = static_cast<const unsigned short*>(w_planes);
   g.a_plane = x_plane; g.b_plane = w_plane; g.lda = 0; g.ldb = (int)K;

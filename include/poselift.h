@@ -557,6 +557,10 @@ int pl_conv2d_planes_fwd_hw(int mode, const void* x_planes, int64_t x_plane, int
                             const void* w_planes, int64_t w_plane, int64_t Cout, int KH, int KW, int stride_h, int stride_w,
                             int pad_h, int pad_w, int pad_w_right, float* y, float out_scale, const float* dyn_inv, float* stat,
                             void* stream);
+int pl_conv2d_planes_fwd_ep_hw(int mode, const void* x_planes, int64_t x_plane, int64_t B, int64_t H, int64_t W, int64_t Cin,
+                               const void* w_planes, int64_t w_plane, int64_t Cout, int KH, int KW, int stride_h, int stride_w,
+                               int pad_h, int pad_w, int pad_w_right, float* y, float out_scale, const PLPlanesEpilogue* ep,
+                               void* stream);      /* pl_conv2d_planes_fwd_ep with that geometry: the stem in eval mode */
 int pl_conv2d_planes_wgrad_hw(int mode, const void* dz_planes, int64_t dz_plane, const void* x_planes, int64_t x_plane,
                               int64_t B, int64_t H, int64_t W, int64_t Cin, int64_t Cout, int KH, int KW, int stride_h,
                               int stride_w, int pad_h, int pad_w, int pad_w_right, float* dw, float out_scale,
