@@ -1,21 +1,30 @@
 // One hidden layer of the lifter per launch, for SMALL batches (B <= 64 rows: the reference's own batch_size = 64,
-// phase1_lifting/train_1.py:194).
+// phase1_lifting/train_1.py:194) -- and, in evaluation, for every batch off the tile grid (M <= 512).
 //
-// At this size every kernel of the step is launch latency (4.5-9 us each for 256 KB of data) and a hidden layer is four of
+// At this size every kernel of the step is launch latency (4.5-9 us each for 256 KB of data) and a hidden layer was four of
 // them forward (split-K GEMM, its reduce, BatchNorm statistics + apply) and four backward.  BatchNorm is what forces the
 // boundaries -- its statistics need every row of a column -- so here a workgroup OWNS 16 columns for ALL rows:
-//   forward  (small_fwd_kernel):  z = a W^T + b on its columns (K split over the workgroup's eight waves, exact-fp32 MFMA
-//             v_mfma_f32_16x16x4_f32 fed from registers, partials through LDS in wave order), then -- the columns are
-//             complete -- batch statistics, running-statistics update, scale/shift, ReLU, dropout, the residual add and the
-//             ReLU & keep bitmap: Linear + BatchNorm1d + ReLU + Dropout (+ skip) of baselineModel.py:33-37 / 39-45 / 79-95.
-//   backward (small_bwd_kernel):  g = dz W (+ skip gradient) on its columns = the incoming gradient of the layer BELOW, whose
-//             BatchNorm backward (sum dy, sum dy zhat, the coefficients, dz, dgamma, dbeta, the bias gradient) follows in the
-//             same workgroup: the autograd of the same modules.
-// 64 workgroups at H = 1024; the MFMA work of one (2 MFLOP at 256 FLOP/clk) is 3.4 us, the operands come from L2.
+//   small_first_fwd_kernel   the first layer (34 / 51 inputs: contraction on the vector unit), then the forward tail
+//   small_fwd_kernel         z = a W^T + b on its columns -- K split over the workgroup's eight waves, row-contiguous loads
+//                            through a wave-private LDS image, exact-fp32 v_mfma_f32_16x16x4_f32 or (PL_F16X3) three
+//                            v_mfma_f32_16x16x32_f16 on fp16 planes, wave partials through LDS in wave order -- then, the
+//                            columns being complete, the forward tail: batch statistics, running statistics, scale / shift,
+//                            ReLU, dropout, the residual add, the ReLU & keep bitmap (Linear + BatchNorm1d + ReLU + Dropout
+//                            (+ skip), baselineModel.py:33-37 / 39-45 / 79-95); evaluation: the fold on the running
+//                            statistics instead, grid also over 64-row blocks; the last layer also leaves the slabs of the
+//                            output Linear
+//   small_mse_kernel         y = bias + slabs, MSE forward + backward (or, evaluation, y alone)
+//   small_top_bwd_kernel     g = dy W2, BatchNorm backward of the top hidden layer, dW2, db2, loss, step counter
+//   small_bwd_kernel         three roles by workgroup: g = dz W (+ skip gradient) on its columns and the BatchNorm backward
+//                            of the layer BELOW (+ the first layer's weight gradient); the layer's own weight gradient
+//                            dz^T a, one 128 x 64 tile each; a slice of the AdamW step
+// (the autograd of the same modules, train_1.py:95-96).  64 column workgroups at H = 1024: column ownership caps the
+// parallelism, and every one of them reads all of the activations -- what a launch waits for is its 320 KB of operands through
+// one CU's vector memory unit and LDS, then (exact fp32) 3.4 us of MFMA issue.  DESIGN.md 3.7 has the measurements.
 //
-// Bitmap of the layers produced here ("tile format", private to the small path: written by small_fwd_kernel, read by
-// small_bwd_kernel and bn_small_bwd_kernel<.., true>): element (r, c) is bit (r & 15) * 4 + ((c >> 2) & 3) of word
-// (c >> 4) * 16 + (r >> 4) * 4 + (c & 3) -- what a ballot over the epilogue's lanes yields.
+// Bitmap of the layers produced here ("tile format", private to the small path: written by the forward tail, read by the
+// backward tail and by bn_small_bwd_kernel<.., true>): element (r, c) is bit (r & 15) * 4 + ((c >> 2) & 3) of word
+// (c >> 4) * 16 + (r >> 4) * 4 + (c & 3) -- what a ballot over the tail's lanes yields.
 #include <stdlib.h>
 
 #include <algorithm>
