@@ -255,7 +255,7 @@ Ws plan(const PLDesc* d, int64_t B) {
     w.amax = take(std::max((size_t)((H + 255) / 256) * w.RC, (size_t)(B / 64) * (H / 32)) * 2 * 4);
     w.dzscale = take((size_t)w.L * 2 * 4);
   }
-  if (!w.planes && d->dtype == PL_F16X3 && B <= thin_gemm_max_m())
+  if (d->dtype == PL_F16X3 && B <= thin_gemm_max_m())
     for (int l = 0; l + 1 < w.L; ++l) w.sactp.push_back(take(w.act_bytes));           // two fp16 planes = 4 B per element
   w.total = o;
   return w;
@@ -498,7 +498,9 @@ extern "C" int pl_lifter_fwd_eval(const PLDesc* d, const float* x, float* y, int
   // launch leaves: 6 launches instead of 16 at B = 64 (97 -> 47 us), every row the same bits whatever the batch.
   // POSELIFT_SMALL_EVAL=0: the thin-GEMM route (A/B).
   static const bool small_eval_off = [] { const char* e = getenv("POSELIFT_SMALL_EVAL"); return e && e[0] == '0'; }();
-  if (!small_eval_off && d->bn && d->bn_running && !w.planes && B <= thin_gemm_max_m() && small_layer_ok(2, H, H) &&
+  // (whole-tile batches up to 512 rows, too: on the operand-planes path an evaluation of 128 ... 512 rows is ~20 launches of
+  //  8 ... 32 tiles each -- 143 us at any of these sizes -- where the layer kernels take 50 ... 110 us)
+  if (!small_eval_off && d->bn && d->bn_running && B <= thin_gemm_max_m() && small_layer_ok(2, H, H) &&
       small_first_ok(d->in_dim) && small_top_ok(d->out_dim)) {
     const float* a_in = x;
     for (int l = 0; l < w.L; ++l) {
@@ -506,11 +508,13 @@ extern "C" int pl_lifter_fwd_eval(const PLDesc* d, const float* x, float* y, int
       const float* resid = (l >= 2 && (l % 2) == 0) ? f32(ws, w.act[l - 2]) : nullptr;
       const bool last = l == w.L - 1;
       const bool f16 = small_f16_on(d, w);
-      PL_TRY(launch_small_layer_eval(a_in, ly.W, ly.b, ly.gamma, ly.beta, d->bn_eps, ly.rm, ly.rv, resid, f32(ws, w.act[l]),
+      // (a whole-tile batch's plan keeps no fp32 activation for the odd layers: their output goes through the z buffer)
+      float* out = w.act_f32[l] ? f32(ws, w.act[l]) : f32(ws, w.z[l]);
+      PL_TRY(launch_small_layer_eval(a_in, ly.W, ly.b, ly.gamma, ly.beta, d->bn_eps, ly.rm, ly.rv, resid, out,
                                      (int)B, H, ly.K, s, l == 0, last ? d->params + P.off[4 * w.L] : nullptr,
                                      last ? f32(ws, w.slabs) : nullptr, d->out_dim,
                                      (f16 && l > 0) ? u16(ws, w.sactp[l - 1]) : nullptr, (f16 && !last) ? u16(ws, w.sactp[l]) : nullptr));
-      a_in = f32(ws, w.act[l]);
+      a_in = out;
     }
     return launch_small_out(f32(ws, w.slabs), H / 16, (int)B, d->out_dim, d->params + P.off[4 * w.L + 1], y, s);
   }
