@@ -289,6 +289,15 @@ BnrSlab bnr_slab(const PLDesc* d, const Ws& w, void* ws, int rc, int n_amax, boo
 
 inline bool bn_small(const PLDesc* d, const Ws& w, int64_t B) { return bn_small_ok(d, w.planes, B); }
 
+// Training forward of 128 ... 512 rows on the operand-planes path (fp16 pairs, local statistics): the 1024-wide Linears on the
+// layer kernels' contraction (launch_small_linear_stats).  POSELIFT_MID_LINEAR=0: the tile GEMM (same-box A/B).
+inline bool mid_linear_on(const PLDesc* d, const Ws& w, int64_t B) {
+  static const bool off = [] { const char* e = getenv("POSELIFT_MID_LINEAR"); return e && e[0] == '0'; }();
+  // (under SyncBN only where the concatenated batch would come here too: "the shards compute what one process computes on the
+  //  concatenated batch, bit for bit" holds because both sides run the same kernel)
+  return !off && w.planes && w.pkind == 2 && B * sync_world(d) <= 512 && small_layer_ok(2, d->hidden, d->hidden);
+}
+
 // PL_F16X3 descriptors: the small-batch layer kernels contract on fp16 planes (three MFMAs per product) instead of exact fp32
 // MFMAs -- forward and evaluation; the first layer's launch (which must then be one of them) writes the first planes.
 // POSELIFT_SMALL_F16=0: exact fp32 there, as for every other dtype (same-box A/B).
@@ -629,6 +638,10 @@ static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, 
     }
     if (skinny) {
       PL_TRY(launch_skinny_wide_out(a_in, ly.W, ly.b, g.C, (int)B, ly.K, H, false, g.stat_sum, g.stat_m2, s));
+    } else if (w.planes && l > 0 && mid_linear_on(d, w, B)) {
+      // 128 ... 512 rows: the tile GEMM has 8 ... 32 tiles for 256 CUs (22 us whatever the size); one 64-row block x 16 columns
+      // per workgroup on the layer kernels' contraction instead, same operand planes, same statistics partials
+      PL_TRY(launch_small_linear_stats(nullptr, u16(ws, w.actp[l - 1]), ly.W, ly.b, g.C, (int)B, H, H, g.stat_sum, g.stat_m2, groups, s));
     } else if (w.planes && l > 0) {
       PlanesGemmArgs pg = planes_args(w.pkind, u16(ws, w.actp[l - 1]), BH, H, wplane(d, w, ws, l), (int64_t)H * H, H, g.C, (int)B, H, H,
                                       1.0f / (kActPlaneScale * kWeightPlaneScale), nullptr);

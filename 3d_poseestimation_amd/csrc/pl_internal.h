@@ -228,6 +228,10 @@ int launch_small_layer_eval(const float* a, const float* W, const float* bias, c
                             bool first = false, const float* W2 = nullptr, float* ypart = nullptr, int O = 0,
                             const unsigned short* a_planes = nullptr, unsigned short* out_planes = nullptr);
 int launch_small_out(const float* ypart, int NS, int M, int O, const float* bias, float* y, hipStream_t s);
+// the Linear alone with the statistics partials of a tile GEMM's epilogue, for TRAINING batches of 65 ... 512 rows: the tile
+// GEMMs have 8 ... 32 tiles for 256 CUs there (22 us per forward GEMM at any of these sizes; this form: 9-17 us)
+int launch_small_linear_stats(const float* a, const unsigned short* a_planes, const float* W, const float* bias, float* z, int M,
+                              int H, int K, float* stat_sum, float* stat_m2, int groups, hipStream_t s);
 int small_mse_partials(int B, int O);     // partial sums launch_small_mse leaves in mpart (<= 64)
 int launch_small_mse(const float* ypart, int NS, int B, int O, const float* bias, const float* tgt, float grad_scale, float* y,
                      float* dpred, float* mpart, hipStream_t s);

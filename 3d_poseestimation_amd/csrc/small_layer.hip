@@ -310,13 +310,19 @@ struct FwdArgs {
   const unsigned short* ap;
   unsigned short* outp;
   size_t a_plane, o_plane;
+  // the Linear alone, for training batches of 65 ... 512 rows (stats = 1): z = a W^T + b and the partial BatchNorm statistics a
+  // tile GEMM's epilogue emits (per 64-row group: column sums, and sums of squares about the group mean -- stat_sum / stat_m2
+  // [groups][H], zeros for groups past the last row; NULL: none); the grid runs over the groups like an evaluation's
+  int stats;
+  float *stat_sum, *stat_m2;
 };
 
 // the launch's row block: blockIdx.y * 64 .. + 63 of Mtot rows (evaluation; training launches have one block of B rows)
 __device__ __forceinline__ FwdArgs row_block(FwdArgs p) {
-  if (!p.eval) { p.Mtot = p.B; return p; }
+  if (!p.eval && !p.stats) { p.Mtot = p.B; return p; }
   const int r0 = blockIdx.y * ROWS;
   p.B = min(ROWS, p.Mtot - r0);
+  if (p.stats) p.z += (size_t)r0 * p.H;
   p.a += (size_t)r0 * p.K;
   if (p.ap) p.ap += (size_t)r0 * p.K;
   if (p.outp) p.outp += (size_t)r0 * p.H;
@@ -334,7 +340,8 @@ __device__ __forceinline__ FwdPre fwd_prefetch(const FwdArgs& p, int c) {
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   FwdPre q = {zero, zero, zero, zero, zero, zero};
   if (tid < 256) {
-    q.bias = ld4(p.bias + c); q.ga = ld4(p.gamma + c); q.be = ld4(p.beta + c);
+    q.bias = ld4(p.bias + c);
+    if (!p.stats) { q.ga = ld4(p.gamma + c); q.be = ld4(p.beta + c); }
     if (p.resid && r < p.B) q.rv = ld4(p.resid + (size_t)r * p.H + c);
     if (p.eval) { q.rmean = ld4(p.rm + c); q.rvar = ld4(p.rv + c); }
   }
@@ -479,6 +486,30 @@ __device__ __forceinline__ void head_slab(const FwdArgs& p, float4 out, int blk,
   }
 }
 
+// the tail of the Linear-alone form: z (+ bias) stored, the group's partial statistics (every thread of the workgroup calls it)
+__device__ __forceinline__ void stats_tail(const FwdArgs& p, float4 z, const FwdPre& pre, int c, float4 (*sm)[4]) {
+  const int tid = threadIdx.x, r = tid >> 2;
+  const bool live = tid < 256 && r < p.B;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  z.x += pre.bias.x; z.y += pre.bias.y; z.z += pre.bias.z; z.w += pre.bias.w;
+  if (!live) z = zero;
+  if (live) st4(p.z + (size_t)r * p.H + c, z);
+  if (!p.stat_sum) return;                                   // (kernel-uniform)
+  float4 s[1] = {z};
+  colsum<1>(s, sm);
+  const float cnt = (float)p.B;
+  float4 q[1] = {zero};
+  if (live) {
+    const float dx = z.x - s[0].x / cnt, dy = z.y - s[0].y / cnt, dz = z.z - s[0].z / cnt, dw = z.w - s[0].w / cnt;
+    q[0] = make_float4(dx * dx, dy * dy, dz * dz, dw * dw);
+  }
+  colsum<1>(q, sm);
+  if (tid < 4) {
+    st4(p.stat_sum + (size_t)blockIdx.y * p.H + c, s[0]);
+    st4(p.stat_m2 + (size_t)blockIdx.y * p.H + c, q[0]);
+  }
+}
+
 template <int STEPS, int ABL = 0>
 __global__ __launch_bounds__(NTHR) void small_fwd_kernel(FwdArgs p_in) {
   __shared__ float part[NWAVE * ROWS * COLS];
@@ -489,6 +520,14 @@ __global__ __launch_bounds__(NTHR) void small_fwd_kernel(FwdArgs p_in) {
   const int c0 = blk * COLS;
   const int tid = threadIdx.x;
   const int c = c0 + 4 * (tid & 3);
+  if (p.stats && p.B <= 0) {                                 // a statistics group past the last row: zeros (workgroup-uniform)
+    if (p.stat_sum && tid < 4) {
+      const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+      st4(p.stat_sum + (size_t)blockIdx.y * p.H + c, zero);
+      st4(p.stat_m2 + (size_t)blockIdx.y * p.H + c, zero);
+    }
+    return;
+  }
   const FwdPre pre = fwd_prefetch(p, c);
   if (ABL == 0 && p.ap)
     contract_f16<STEPS>(p.ap, p.a_plane, p.K, p.B, p.W, p.K, c0, kWeightPlaneScale, 1.0f / (kActPlaneScale * kWeightPlaneScale), part,
@@ -497,6 +536,7 @@ __global__ __launch_bounds__(NTHR) void small_fwd_kernel(FwdArgs p_in) {
   __syncthreads();
   float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   if (tid < 256) z = gather_part(part);
+  if (p.stats) { stats_tail(p, z, pre, c, sm); return; }
   const float4 out = p.eval ? eval_tail(p, z, pre, c) : fwd_tail(p, z, pre, blk, c, sm);
   if (p.ypart) {
     if (p.eval) __syncthreads();                             // (every thread is done with part)
@@ -926,6 +966,34 @@ int launch_small_layer_eval(const float* a, const float* W, const float* bias, c
   }
   prof_end(prof, s);
   PL_CHECK_LAUNCH("small_layer_eval");
+  return PL_OK;
+}
+
+// z [M][H] = a W^T + bias for M <= 512 rows (any M; one 64-row block x 16 columns per workgroup) and, stat_sum != NULL, the
+// groups partial BatchNorm statistics of a tile GEMM's epilogue ([groups][H] each; groups >= ceil(M / 64): the rest zeros).
+// a_planes != NULL: the input as fp16 planes [M][K] (h, l), contraction as three fp16 MFMAs per product; else a fp32, exact.
+int launch_small_linear_stats(const float* a, const unsigned short* a_planes, const float* W, const float* bias, float* z, int M,
+                              int H, int K, float* stat_sum, float* stat_m2, int groups, hipStream_t s) {
+  if (!small_layer_ok(2, H, K) || M < 1 || groups < (M + ROWS - 1) / ROWS)
+    PL_FAIL(PL_ESHAPE, "small_linear_stats: M=%d H=%d K=%d groups=%d", M, H, K, groups);
+  if ((!a && !a_planes) || !W || !bias || !z || (stat_sum != nullptr) != (stat_m2 != nullptr))
+    PL_FAIL(PL_EINVAL, "small_linear_stats: bad arguments");
+  if (!al16(a) || !al16(a_planes) || !al16(W) || !al16(bias) || !al16(z) || !al16(stat_sum) || !al16(stat_m2))
+    PL_FAIL(PL_EINVAL, "small_linear_stats: 16-byte alignment");
+  FwdArgs p = {};
+  p.a = a; p.W = W; p.bias = bias; p.z = z; p.B = ROWS; p.H = H; p.K = K; p.Mtot = M; p.stats = 1;
+  p.stat_sum = stat_sum; p.stat_m2 = stat_m2;
+  p.ap = a_planes; p.a_plane = (size_t)M * K;
+  if (!a) p.a = reinterpret_cast<const float*>(a_planes);     // (never read: the planes form is taken)
+  const dim3 grid(H / COLS, stat_sum ? groups : (M + ROWS - 1) / ROWS), block(NTHR);
+  void* prof = prof_begin_flops(2.0 * M * H * K, s);
+  switch (K / (NWAVE * 32)) {
+    case 1: hipLaunchKernelGGL(small_fwd_kernel<1>, grid, block, 0, s, p); break;
+    case 2: hipLaunchKernelGGL(small_fwd_kernel<2>, grid, block, 0, s, p); break;
+    default: hipLaunchKernelGGL((small_fwd_kernel<4, 0>), grid, block, 0, s, p); break;
+  }
+  prof_end(prof, s);
+  PL_CHECK_LAUNCH("small_linear_stats");
   return PL_OK;
 }
 

@@ -237,14 +237,26 @@ def test_g2_train_nodrop_vs_reference(pkg, tag):
             else:
                 scale = np.abs(g["gval:" + k]).max()
                 _close(np.linalg.norm(flat.astype(np.float64)), float(g["gnorm:" + k]), 1e-3, 0)
-            _close(flat[g["gidx:" + k]] / scale, g["gval:" + k] / scale, 0, 5e-4)
+            if dtype == "f16x3":
+                # B = 128 on the operand-planes path: the forward Linears run on the layer kernels' contraction (another
+                # summation order than the tile GEMM's and the reference's), and a ReLU decision that flips on a
+                # round-off-sized pre-activation moves the samples of the rows it touches by 1 / B of their size.  With the
+                # decisions forced (tools/r3_mid_accuracy.py, same shape) every gradient tensor is within 7e-7 of the fp64
+                # oracle in relative L2 -- the fp32 oracle itself: 1.3e-6; the tile GEMM: 8e-7 -- and
+                # test_ragged_shapes_vs_oracle[128-1024-2-...-f16x3] holds that in the suite.  Here, against the reference's own
+                # decisions: the typical sample within 1e-3 of the scale, none beyond 2 %.
+                dv = np.abs(flat[g["gidx:" + k]].astype(np.float64) - g["gval:" + k]) / scale
+                assert np.median(dv) < 1e-3 and np.mean(dv > 2e-3) < 0.2 and dv.max() < 2e-2, (k, np.median(dv), dv.max())
+            else:
+                _close(flat[g["gidx:" + k]] / scale, g["gval:" + k] / scale, 0, 5e-4)
     else:
         want = golden_state(g, "grad:")
         _check_grads(got, want, bn)
         if not bn:
             assert m.batch_norm1.weight.grad is None      # unused parameters keep grad None (as in torch)
     sdx = np.abs(g["dx"]).max()
-    _close(x.grad.cpu().numpy().reshape(g["dx"].shape) / sdx, g["dx"] / sdx, 0, 5e-4 if tag == "full" else 2e-5)
+    _close(x.grad.cpu().numpy().reshape(g["dx"].shape) / sdx, g["dx"] / sdx, 0,
+           (2e-2 if dtype == "f16x3" else 5e-4) if tag == "full" else 2e-5)
     sd = {k: v.cpu().numpy() for k, v in m.state_dict().items()}
     for k, v in golden_state(g, "after:").items():
         if "num_batches" in k:
@@ -556,6 +568,9 @@ def test_full_size_properties(pkg, full):
     (1000, 128, 3, 34, 51, False, "fp32"),   # no BatchNorm, three stages
     (4097, 1024, 2, 34, 51, True, "fp32"),   # max bench size + 1
     (200, 36, 0, 20, 7, True, "fp32"),       # generic dims: nothing specialised applies
+    (128, 1024, 2, 34, 51, True, "f16x3"),   # whole tiles, 128 ... 512 rows: the forward Linears on the layer kernels'
+    (384, 256, 2, 34, 51, True, "f16x3"),    #   contraction (launch_small_linear_stats), everything else on the planes path
+    (512, 512, 1, 51, 34, True, "f16x3"),
     (384, 256, 2, 34, 51, True, "bf16"),     # bf16 arithmetic, whole tiles
     (300, 256, 2, 34, 51, True, "bf16"),     # bf16 requested but ragged -> fp32 edge arithmetic
 ])
