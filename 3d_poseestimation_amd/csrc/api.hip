@@ -298,6 +298,12 @@ inline bool mid_linear_on(const PLDesc* d, const Ws& w, int64_t B) {
   return !off && w.planes && w.pkind == 2 && B * sync_world(d) <= 512 && small_layer_ok(2, d->hidden, d->hidden);
 }
 
+inline bool mid_linear_f32_on(const PLDesc* d, int64_t B) {
+  static const bool off = [] { const char* e = getenv("POSELIFT_MID_LINEAR"); return e && e[0] == '0'; }();
+  return !off && d->bn && d->dtype != PL_BF16 && B > kBnSmallRows && B * sync_world(d) <= 512 &&
+         small_layer_ok(2, d->hidden, d->hidden);
+}
+
 // PL_F16X3 descriptors: the small-batch layer kernels contract on fp16 planes (three MFMAs per product) instead of exact fp32
 // MFMAs -- forward and evaluation; the first layer's launch (which must then be one of them) writes the first planes.
 // POSELIFT_SMALL_F16=0: exact fp32 there, as for every other dtype (same-box A/B).
@@ -647,6 +653,10 @@ static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, 
                                       1.0f / (kActPlaneScale * kWeightPlaneScale), nullptr);
       pg.e.bias = ly.b; pg.e.stat_sum = g.stat_sum; pg.e.stat_m2 = g.stat_m2;
       PL_TRY(launch_gemm_planes(kNT, pg, s));
+    } else if (l > 0 && !w.planes && mid_linear_f32_on(d, B)) {
+      // off the planes path (ragged rows, exact-fp32 / bf16x6 descriptors), up to 512 rows: the same kernel on fp32 operands
+      // (exact-fp32 MFMA) instead of the thin GEMM + its reduce or an 8 ... 32-tile GEMM
+      PL_TRY(launch_small_linear_stats(a_in, nullptr, ly.W, ly.b, g.C, (int)B, H, H, g.stat_sum, g.stat_m2, groups, s));
     } else {
       PL_TRY(launch_gemm_f32(kNT, g, s));
     }
