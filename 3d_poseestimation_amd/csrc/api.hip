@@ -298,6 +298,14 @@ inline bool mid_linear_on(const PLDesc* d, const Ws& w, int64_t B) {
   return !off && w.planes && w.pkind == 2 && B * sync_world(d) <= 512 && small_layer_ok(2, d->hidden, d->hidden);
 }
 
+// The BatchNorm statistics finalize inside the apply launch (bn_apply_kernel, BnFin): local statistics, <= 4 groups (256
+// rows).  Measured same-box, step in ms with / without (POSELIFT_BN_FIN_FUSED=0): B = 96 0.312 / 0.319, 128 0.295 / 0.300,
+// 256 0.298 / 0.304 -- and, when tried up to 16 groups, 512 0.353 / 0.351, 1,024 0.419 / 0.391: the dependent prologue in
+// every workgroup costs what the 4.9 us launch did as soon as there are more than a few groups (round 2 saw the same at 64).
+inline bool fin_in_apply(const PLDesc* d, int groups) {
+  static const bool off = [] { const char* e = getenv("POSELIFT_BN_FIN_FUSED"); return e && e[0] == '0'; }();
+  return !off && sync_world(d) == 1 && groups >= 1 && groups <= 4 && d->hidden % 4 == 0;
+}
 inline bool mid_linear_f32_on(const PLDesc* d, int64_t B) {
   static const bool off = [] { const char* e = getenv("POSELIFT_MID_LINEAR"); return e && e[0] == '0'; }();
   return !off && d->bn && d->dtype != PL_BF16 && B > kBnSmallRows && B * sync_world(d) <= 512 &&
@@ -661,12 +669,19 @@ static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, 
       PL_TRY(launch_gemm_f32(kNT, g, s));
     }
     const float *scale = nullptr, *shift = nullptr;
+    BnFinalizeArgs fin = {};
+    bool use_fin = false;
     if (d->bn && eval_bn) {
       float* sc = f32(ws, w.scale) + (size_t)l * H;
       float* sh = f32(ws, w.shift) + (size_t)l * H;
       PL_TRY(launch_bn_eval_stats(ly.gamma, ly.beta, ly.rm, ly.rv, d->bn_eps, H, f32(ws, w.mean[l]), f32(ws, w.rstd[l]),
                                   sc, sh, s));
       scale = sc; shift = sh;
+    } else if (d->bn && !small && fin_in_apply(d, groups)) {
+      // local statistics of at most 4 groups (<= 256 rows): finalized inside the apply launch below
+      fin = BnFinalizeArgs{stat, groups, 64, ly.gamma, ly.beta, d->bn_eps, d->bn_momentum, ly.rm, ly.rv, ly.nbt,
+                           f32(ws, w.mean[l]), f32(ws, w.rstd[l])};
+      use_fin = true;
     } else if (d->bn && !small) {
       float* sc = f32(ws, w.scale) + (size_t)l * H;
       float* sh = f32(ws, w.shift) + (size_t)l * H;
@@ -690,7 +705,7 @@ static int fwd_saved_impl(const PLDesc* d, const float* x, float* y, int64_t B, 
     PL_TRY(launch_bn_apply(g.C, scale, shift, resid, act, u64(ws, w.bits[l]), (int)B, H,
                            eval_bn ? 0.f : d->p_dropout, seed, step, l,
                            inject_keep ? inject_keep + (size_t)l * inj_stride : nullptr, s, &po,
-                           eval_bn ? nullptr : d->step_dev));
+                           eval_bn ? nullptr : d->step_dev, use_fin ? &fin : nullptr));
     a_in = act;
   }
   if (head_slabs) return PL_OK;

@@ -416,12 +416,27 @@ __device__ __forceinline__ void bn_apply_rows(
   }
 }
 
+// The statistics finalize inside the apply launch (BnFin::stat != NULL; local statistics, at most 16 groups = 1,024 rows):
+// every workgroup re-derives mean / rstd / scale / shift of its four columns per lane from the partials -- with <= 16 groups
+// bn_finalize_kernel's part p holds group p alone, so its result is the sum over the groups in order, which is what is done
+// here, bit for bit -- and the workgroups with blockIdx.y == 0 write mean, rstd and the running statistics.  At B = 4096 (64
+// groups, 128 KB of partials per workgroup) this cost more than the launch it removes (round 2); at 128 ... 512 rows the
+// prologue is 2 ... 8 float4 pairs per lane and the 4.9 us finalize launch is a twentieth of the step.
+struct BnFin {
+  const float* stat;            // [2][G][H]
+  const float *gamma, *beta;
+  float *running_mean, *running_var, *mean_out, *rstd_out;
+  int64_t* batches;
+  float eps, momentum;
+  int G, Br, gs;
+};
+
 __global__ __launch_bounds__(NTHR) void bn_apply_kernel(
     const float* __restrict__ z, const float* __restrict__ scale, const float* __restrict__ shift,
     const float* resid, float* act, uint64_t* __restrict__ bits, int B, int H, int mode,
     uint32_t thr, float kscale, uint32_t k0, uint32_t k1, uint32_t c3, uint32_t layer,
     const uint64_t* __restrict__ inject, int Hc, PlaneOut po, const uint64_t* __restrict__ step_dev,
-    uint32_t seed_hi) {
+    uint32_t seed_hi, BnFin fin) {
   const PlaneDst pd = plane_dst(po);
   if (step_dev) {
     // graph replay: the step number is base (baked into c3 / k1's slot as the low / high word) + the device counter
@@ -435,7 +450,56 @@ __global__ __launch_bounds__(NTHR) void bn_apply_kernel(
   mode &= 7;
   const int c = blockIdx.x * 256 + (threadIdx.x & 63) * 4;
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (c < H && scale) { sc = ld4(scale + c % Hc); sh = ld4(shift + c % Hc); }
+  if (fin.stat) {                                           // (kernel-uniform; Hc == H on this route)
+    if (c < H) {
+      const size_t GH = (size_t)fin.G * H;
+      float4 ks[16], km[16];
+#pragma unroll
+      for (int g = 0; g < 16; ++g)
+        if (g < fin.G) { ks[g] = ld4(fin.stat + (size_t)g * H + c); km[g] = ld4(fin.stat + GH + (size_t)g * H + c); }
+      const float4 ga = ld4(fin.gamma + c), be = ld4(fin.beta + c);
+      const float Bt = (float)fin.Br;
+      float s4[4] = {0.f, 0.f, 0.f, 0.f}, m4[4] = {0.f, 0.f, 0.f, 0.f}, mean4[4];
+#pragma unroll
+      for (int g = 0; g < 16; ++g)
+        if (g < fin.G) { s4[0] += ks[g].x; s4[1] += ks[g].y; s4[2] += ks[g].z; s4[3] += ks[g].w; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mean4[j] = s4[j] / Bt;
+#pragma unroll
+      for (int g = 0; g < 16; ++g)
+        if (g < fin.G) {
+          const int n = max(0, min(fin.gs, fin.Br - g * fin.gs));
+          if (n > 0) {
+            m4[0] += bn_m2_term(ks[g].x, km[g].x, (float)n, mean4[0]); m4[1] += bn_m2_term(ks[g].y, km[g].y, (float)n, mean4[1]);
+            m4[2] += bn_m2_term(ks[g].z, km[g].z, (float)n, mean4[2]); m4[3] += bn_m2_term(ks[g].w, km[g].w, (float)n, mean4[3]);
+          }
+        }
+      const float g4[4] = {ga.x, ga.y, ga.z, ga.w}, b4[4] = {be.x, be.y, be.z, be.w};
+      float var4[4], rs4[4], sc4[4], sh4[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        var4[j] = m4[j] / Bt;
+        rs4[j] = 1.0f / sqrtf(var4[j] + fin.eps);
+        sc4[j] = g4[j] * rs4[j];
+        sh4[j] = bn_shift_of(b4[j], mean4[j], sc4[j]);
+      }
+      sc = make_float4(sc4[0], sc4[1], sc4[2], sc4[3]);
+      sh = make_float4(sh4[0], sh4[1], sh4[2], sh4[3]);
+      if (blockIdx.y == 0 && threadIdx.x < 64) {
+        st4(fin.mean_out + c, make_float4(mean4[0], mean4[1], mean4[2], mean4[3]));
+        st4(fin.rstd_out + c, make_float4(rs4[0], rs4[1], rs4[2], rs4[3]));
+        if (fin.running_mean) {
+          float4 rm = ld4(fin.running_mean + c), rv = ld4(fin.running_var + c);
+          bn_running_update(rm.x, rv.x, mean4[0], var4[0], Bt, fin.momentum);
+          bn_running_update(rm.y, rv.y, mean4[1], var4[1], Bt, fin.momentum);
+          bn_running_update(rm.z, rv.z, mean4[2], var4[2], Bt, fin.momentum);
+          bn_running_update(rm.w, rv.w, mean4[3], var4[3], Bt, fin.momentum);
+          st4(fin.running_mean + c, rm); st4(fin.running_var + c, rv);
+        }
+      }
+    }
+    if (fin.batches && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) fin.batches[0] += 1;
+  } else if (c < H && scale) { sc = ld4(scale + c % Hc); sh = ld4(shift + c % Hc); }
   if (resid) bn_apply_rows<true>(z, sc, sh, resid, act, bits, B, H, mode, norelu, thr, kscale, k0, k1, c3, layer, inject, pd, resid_first);
   else bn_apply_rows<false>(z, sc, sh, resid, act, bits, B, H, mode, norelu, thr, kscale, k0, k1, c3, layer, inject, pd, resid_first);
 }
@@ -1382,7 +1446,7 @@ int launch_bn_finalize(const float* stat, int G, int world, int B, int H,
 int launch_bn_apply(const float* z, const float* scale, const float* shift, const float* resid,
                     float* act, uint64_t* bits, int B, int H, float p, uint64_t seed, uint64_t step,
                     int layer, const uint64_t* inject_keep, hipStream_t s, const PlaneOut* planes,
-                    const uint64_t* step_dev) {
+                    const uint64_t* step_dev, const BnFinalizeArgs* finalize) {
   int mode = 0;
   PlaneOut po = planes ? *planes : PlaneOut{nullptr, nullptr, 1.f, nullptr, 0};
   po.nt = (nontemporal_on() && (int64_t)B * H * 4 >= kNontemporalBytes) ? 1 : 0;
@@ -1399,8 +1463,18 @@ int launch_bn_apply(const float* z, const float* scale, const float* shift, cons
   const uint32_t k1 = step_dev ? (uint32_t)(step >> 32) : seed_hi ^ (uint32_t)(step >> 32);
   const int strips = (H + 255) / 256;
   dim3 grid(strips, stream_rows_grid(B, strips));
+  BnFin fin = {};
+  if (finalize) {
+    const BnFinalizeArgs& f = *finalize;
+    if (!f.stat || !f.gamma || !f.beta || !f.mean || !f.rstd || f.G < 1 || f.G > 16 || (H & 3) ||
+        (f.running_mean != nullptr) != (f.running_var != nullptr))
+      PL_FAIL(PL_EINVAL, "bn_apply: statistics finalize (G=%d)", f.G);
+    fin.stat = f.stat; fin.gamma = f.gamma; fin.beta = f.beta; fin.running_mean = f.running_mean; fin.running_var = f.running_var;
+    fin.mean_out = f.mean; fin.rstd_out = f.rstd; fin.batches = f.batches; fin.eps = f.eps; fin.momentum = f.momentum;
+    fin.G = f.G; fin.Br = B; fin.gs = f.group_rows;
+  }
   hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NTHR), 0, s, z, scale, shift, resid, act, bits, B, H,
-                     mode, thr, kscale, k0, k1, (uint32_t)step, (uint32_t)layer, inject_keep, H, po, step_dev, seed_hi);
+                     mode, thr, kscale, k0, k1, (uint32_t)step, (uint32_t)layer, inject_keep, H, po, step_dev, seed_hi, fin);
   PL_CHECK_LAUNCH("bn_apply");
   return PL_OK;
 }
@@ -1982,7 +2056,7 @@ extern "C" int pl_bn_train_fwd_ex(const float* z, int64_t rows, int64_t C, const
   if (join && !relu) PL_FAIL(PL_EINVAL, "pl_bn_train_fwd_ex: a join without its ReLU");
   hipLaunchKernelGGL(bn_apply_kernel, grid, dim3(NTHR), 0, s, z, scale, shift, join, y, bits, B, H,
                      (relu ? 0 : 8) | (join ? 32 : 0), 0u, 1.0f, 0u, 0u, 0u, 0u, (const uint64_t*)nullptr, Hc, ypo,
-                     (const uint64_t*)nullptr, 0u);
+                     (const uint64_t*)nullptr, 0u, BnFin{});
   PL_CHECK_LAUNCH("bn_apply");
   return PL_OK;
 }

@@ -165,10 +165,22 @@ int launch_bn_finalize(const float* stat, int G, int world, int B, int H,
 
 // act = [resid +] dropout(relu(z*scale + shift)); bits = keep&positive bitmap
 // planes: also (act == NULL: only) write the activation as GEMM operand planes
+// finalize != NULL: the statistics finalize (launch_bn_finalize's job: local statistics, at most 16 groups) inside this launch;
+// scale / shift are then not read
+struct BnFinalizeArgs {
+  const float* stat;            // [2][G][H] partials of this process
+  int G, group_rows;
+  const float *gamma, *beta;
+  float eps, momentum;
+  float *running_mean, *running_var;
+  int64_t* batches;
+  float *mean, *rstd;
+};
 int launch_bn_apply(const float* z, const float* scale, const float* shift, const float* resid,
                     float* act, uint64_t* bits, int B, int H, float p, uint64_t seed,
                     uint64_t step, int layer, const uint64_t* inject_keep, hipStream_t s,
-                    const PlaneOut* planes = nullptr, const uint64_t* step_dev = nullptr);
+                    const PlaneOut* planes = nullptr, const uint64_t* step_dev = nullptr,
+                    const BnFinalizeArgs* finalize = nullptr);
 // pl_mse_fwd_bwd + (tick != NULL) tick[0] += 1 once the loss is written (PLDesc.step_dev, graph replay)
 int mse_fwd_bwd_tick(const float* pred, const float* tgt, int64_t n, float grad_scale, float* dpred, float* loss_out,
                      void* scratch, uint64_t* tick, void* stream);
